@@ -1,0 +1,202 @@
+"""Golden-vector generator (test infrastructure; run in the BUILD container only).
+
+Imports the reference's three hot-path modules from /root/reference (never copied into this
+repo), fills the reference `SimpleUnet` with `oracle.unet_ref.closed_form_params`, and writes
+small input/output fixtures to tests/golden/*.npz.  The fixtures are data only.
+
+    PYTHONPATH=/root/reference python -m oracle.make_golden
+
+RNG-consuming reference calls are driven by seeding torch's CPU generator and replaying the
+same draw order here to capture the drawn values into the fixture (tests never rely on torch's
+RNG stream being reproducible across versions).
+"""
+import os
+import sys
+from functools import partial
+
+import numpy as np
+import torch
+
+REF = os.environ.get("GMS_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+from gms.diffusion import diffusion_utils as R_du        # noqa: E402
+from gms.diffusion import gaussian_diffusion as R_gd     # noqa: E402
+from gms.diffusion import simple_unet as R_su            # noqa: E402
+
+from oracle import unet_ref                              # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def ref_net(C):
+    net = R_su.SimpleUnet(C, 0.0)
+    sd = unet_ref.closed_form_params(C)
+    missing = net.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    # the oracle's inventory must match the reference's state-dict order exactly
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    return net.eval()
+
+
+def inputs(B, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    x0 = (torch.rand((B, 1, S, S), generator=g) * 2 - 1)
+    x0[:, :, : S // 4] = -1.0            # MNIST-like saturated background rows (exercises the clip)
+    y = torch.randint(0, 10, (B,), generator=g)
+    y[0] = -1                            # one unconditional row (simple_unet.py:54-57)
+    return x0, y
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def gen_schedule():
+    sched = R_du.get_logsnr_schedule("cosine", logsnr_min=-20.0, logsnr_max=20.0)
+    u = torch.tensor([0.0, 1e-3, 0.1, 0.25, 0.5, 0.75, 0.9, 0.999, 1.0], dtype=torch.float32)
+    out = {"u": u, "logsnr": sched(u)}
+    # sampler index arithmetic (gaussian_diffusion.py:288-290), every i for T in {4, 8, 200, 250, 1000}
+    for T in (4, 8, 200, 250, 1000):
+        ut, us, lt, ls = [], [], [], []
+        for i in range(T):
+            ti = torch.tensor(i)
+            a = (ti + 1.0) / T
+            b = ti / T
+            ut.append(a); us.append(b); lt.append(sched(a)); ls.append(sched(b))
+        out[f"T{T}_u_t"] = torch.stack(ut); out[f"T{T}_u_s"] = torch.stack(us)
+        out[f"T{T}_logsnr_t"] = torch.stack(lt); out[f"T{T}_logsnr_s"] = torch.stack(ls)
+    t = torch.tensor([20.0, 0.0, -20.0, 1.7626188, -9.682026], dtype=torch.float32)
+    out["temb_t"] = t
+    out["temb_256"] = R_su.timestep_embedding(timesteps=t, dim=64, max_period=256)
+    w = torch.tensor([0.0, 0.5, 1.0, 3.999], dtype=torch.float32)
+    out["temb_w"] = w
+    out["temb_4"] = R_su.timestep_embedding(timesteps=w, dim=64, max_period=4)
+    l = torch.tensor([-20.0, -3.0, 0.0, 2.5, 20.0])
+    z = torch.tensor([0.3, -1.2, 0.7, 0.1, -0.5]); e = torch.tensor([1.0, -0.4, 0.2, 2.0, -1.5])
+    out["alg_logsnr"], out["alg_z"], out["alg_e"] = l, z, e
+    out["alg_x_from_eps"] = R_du.predict_x_from_eps(z=z, eps=e, logsnr=l)
+    out["alg_eps_from_x"] = R_du.predict_eps_from_x(z=z, x=e, logsnr=l)
+    out["alg_v"] = R_du.predict_v_from_x_and_eps(x=z, eps=e, logsnr=l)
+    out["alg_x_from_v"] = R_du.predict_x_from_v(z=z, v=e, logsnr=l)
+    fw = R_du.diffusion_forward(x=z, logsnr=l)
+    out["alg_fw_mean"], out["alg_fw_std"] = fw["mean"], fw["std"]
+    ls_ = l + 0.7
+    rv = R_du.diffusion_reverse(x=e, z_t=z, logsnr_s=ls_, logsnr_t=l, x_logvar="large")
+    out["alg_rev_mean"], out["alg_rev_std"] = rv["mean"], rv["std"]
+    save("schedule.npz", **out)
+
+
+def gen_unet(C, S, B, seed, name):
+    net = ref_net(C)
+    x0, y = inputs(B, S, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    logsnr = (torch.rand(B, generator=g) * 40 - 20)
+    z = torch.randn((B, 1, S, S), generator=g)
+    with torch.no_grad():
+        v = net(z, logsnr, guide=y)
+        v_nog = net(z, logsnr)
+        w = 4 * torch.rand(B, generator=g)
+        v_w = net(z, logsnr, guide=y, cond_w=w)
+    save(name, z=z, logsnr=logsnr, guide=y, v=v, v_noguide=v_nog, cond_w=w, v_condw=v_w)
+
+
+def gen_train(C, S, B, seed, name):
+    net = ref_net(C).train()
+    x0, y = inputs(B, S, seed)
+    diff = R_gd.GaussianDiffusion(mean_type="v", num_steps=250, sampler="ddim", sample_cond_w=-1.0)
+    # replay of the draw order in training_losses (gaussian_diffusion.py:83,94)
+    torch.manual_seed(seed)
+    eps = torch.randn(x0.shape)
+    u = torch.rand(size=(B,))
+    opt = torch.optim.Adam(net.parameters(), lr=3e-4)
+    p0 = {k: v.detach().clone() for k, v in net.named_parameters()}
+    out = {"x0": x0, "y": y, "eps": eps, "u": u}
+    for step in range(2):
+        opt.zero_grad()
+        torch.manual_seed(seed)          # same (eps, u) both steps
+        losses = diff.training_losses(net=partial(net, guide=y), x=x0)["loss"]
+        loss = losses.mean()
+        loss.backward()
+        if step == 0:
+            out["loss_b"] = losses.detach()
+            out["loss"] = loss.detach()
+            names = [k for k, _ in net.named_parameters()]
+            out["grad_names"] = np.array(names)
+            out["grad_norms"] = torch.stack([p.grad.norm() if p.grad is not None else torch.tensor(0.0)
+                                             for _, p in net.named_parameters()])
+            for k, p in net.named_parameters():
+                if k in ("down.seq.0.conv.weight", "out.2.weight", "time_embed.0.weight", "guide_embed.0.weight",
+                         "turn.emb_layers.1.weight", "down.seq.3.conv.bias", "up.seq.3.1.conv.bias",
+                         "up.seq.6.in_layers.0.weight", "up.seq.6.skip_connection.bias", "out.0.bias"):
+                    out["grad__" + k] = p.grad.detach().clone()
+                if k in ("turn.in_layers.2.weight", "up.seq.0.0.skip_connection.weight", "down.seq.6.conv.weight",
+                         "up.seq.3.1.conv.weight", "up.seq.1.in_layers.2.weight"):
+                    out["gradslice__" + k] = p.grad.detach()[:4, :6].clone()
+        opt.step()
+        out[f"delta_norms_step{step + 1}"] = torch.stack([(p.detach() - p0[k]).norm()
+                                                          for k, p in net.named_parameters()])
+        out[f"delta_stem_step{step + 1}"] = (net.down.seq[0].conv.weight.detach() - p0["down.seq.0.conv.weight"])
+        out[f"loss_step{step + 1}"] = loss.detach()
+    # intermediate anchors of step 0 recomputed without RNG
+    sched = R_du.get_logsnr_schedule("cosine", logsnr_min=-20.0, logsnr_max=20.0)
+    logsnr = sched(u)
+    l4 = R_du.broadcast_from_left(logsnr, x0.shape)
+    fw = R_du.diffusion_forward(x=x0, logsnr=l4)
+    out["logsnr"] = logsnr
+    out["z_t"] = fw["mean"] + fw["std"] * eps
+    save(name, **out)
+
+
+def gen_sample(C, S, B, T, seed, name):
+    net = ref_net(C)
+    _, y = inputs(B, S, seed)
+    y = y.clone(); y[0] = 3            # conditional rows only: guidance contrasts cond vs uncond
+    g = torch.Generator().manual_seed(seed + 2)
+    init = torch.randn((B, 1, S, S), generator=g)
+    out = {"init": init, "y": y}
+    with torch.no_grad():
+        # (1) DDIM, guidance off — the `evaluate` path (diffusion_model.py:102-104)
+        d = R_gd.GaussianDiffusion(mean_type="v", num_steps=T, sampler="ddim", sample_cond_w=-1.0)
+        zs, xs, es = d.sample(net=partial(net, guide=y), init_x=init)
+        out["ddim_zs"], out["ddim_xs"], out["ddim_eps"] = zs, xs, es
+        # (2) DDIM, guidance on with the random per-sample weight — the `sample` path (:86, :247-257)
+        torch.manual_seed(seed + 3)
+        w = 4.0 * torch.rand(B)
+        torch.manual_seed(seed + 3)
+        zs, xs, es = d.sample(net=partial(net, guide=y), init_x=init, cond_w=0.5)
+        out["cfg_w"], out["cfg_zs"], out["cfg_xs"] = w, zs, xs
+        # (3) ancestral ('noisy') sampler, guidance off; noise order = loop order i = T-1 .. 0
+        dn = R_gd.GaussianDiffusion(mean_type="v", num_steps=T, sampler="noisy", sample_cond_w=-1.0)
+        torch.manual_seed(seed + 4)
+        noises = [torch.randn(init.shape) for _ in range(T)]       # noises[k] used at i = T-1-k
+        torch.manual_seed(seed + 4)
+        zs, xs, es = dn.sample(net=partial(net, guide=y), init_x=init)
+        out["anc_noise"] = torch.stack(noises[::-1])                # indexed by i
+        out["anc_zs"], out["anc_xs"] = zs, xs
+    save(name, **out)
+
+
+def main():
+    torch.set_num_threads(4)
+    gen_schedule()
+    gen_unet(32, 8, 3, 10, "unet_c32_s8.npz")
+    gen_unet(32, 12, 2, 11, "unet_c32_s12.npz")
+    gen_unet(32, 16, 2, 12, "unet_c32_s16.npz")
+    gen_unet(128, 28, 2, 13, "unet_c128_s28.npz")
+    # C=32 has one channel per GroupNorm group, which cancels the embedding broadcast-add exactly;
+    # C=64 (2 channels/group) is the smallest width whose outputs depend on the embedding path.
+    gen_unet(64, 8, 3, 14, "unet_c64_s8.npz")
+    gen_train(64, 8, 3, 23, "train_c64_s8.npz")
+    gen_train(32, 8, 4, 20, "train_c32_s8.npz")
+    gen_train(32, 16, 2, 21, "train_c32_s16.npz")
+    gen_train(128, 28, 2, 22, "train_c128_s28.npz")
+    gen_sample(32, 8, 3, 4, 30, "sample_c32_s8_T4.npz")
+    gen_sample(32, 12, 2, 8, 31, "sample_c32_s12_T8.npz")
+
+
+if __name__ == "__main__":
+    main()
