@@ -1,0 +1,157 @@
+"""Plugin surface shared by models and the driver — mirror of the parts of reference gms/common.py that the
+diffusion hot path sits behind: `AttrDict` (:24-26), `convert_camel_to_snake` (:33-35),
+`discover_models` (:38-55), `args_type` (:85-92), `count_vars` (:95-96), `GM` (:138-174), `dump_logger` (:65-82).
+
+The evaluation / visualisation utilities of the reference file (FID, precision-recall, tensorboard grids, the
+MNIST loader) are outside the hot path and are not reproduced here.
+"""
+import importlib
+import re
+import subprocess
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+import numpy as np
+import torch
+import yaml
+from torch import nn
+
+
+class AttrDict(dict):
+    __setattr__ = dict.__setitem__
+    __getattr__ = dict.__getitem__
+
+
+def prefix_dict(name, d):
+    return {name + key: d[key] for key in d}
+
+
+def convert_camel_to_snake(name):
+    s1 = re.sub("(.)([A-Z][a-z]+)", r"\1_\2", name)
+    return re.sub("([a-z0-9])([A-Z])", r"\1_\2", s1).lower()
+
+
+class GM(nn.Module):
+    """GenerativeModel base class: the contract the training driver relies on (gms/common.py:138-174)."""
+
+    DG = AttrDict()   # per-model default flags; every key becomes a --flag of the driver
+
+    def __init__(self, G):
+        super().__init__()
+        self.G = G
+        self.optimizer = None
+
+    def save(self, path, test_x=None, test_y=None):
+        torch.save(self.state_dict(), Path(path) / "model.pt")
+
+    def train_step(self, x, y):
+        """Default step for models that only define `loss` (gms/common.py:158-169)."""
+        assert hasattr(self, "loss"), (
+            "you are using the default train_step. this requires you to define a loss function that returns loss, metrics")
+        if self.optimizer is None:
+            self.optimizer = torch.optim.Adam(self.parameters(), self.G.lr)
+        self.optimizer.zero_grad()
+        loss, metrics = self.loss(x, y)
+        loss.backward()
+        self.optimizer.step()
+        return metrics
+
+    def evaluate(self, writer, x, y, epoch):
+        assert False, "you need to implement the evaluate method. make some samples or something."
+
+
+def discover_models(package="generative_models_amd"):
+    """{snake_case(class name): class} for every GM subclass found in the package's modules whose file name does
+    not contain '__init__', 'main' or 'common' (the reference's filter, gms/common.py:45).  The reference CLI
+    spelling `--model=diffusion` (run_all.sh:16) is registered as an alias of `diffusion_model`."""
+    models = {}
+    pkg = importlib.import_module(package)
+    root = Path(pkg.__file__).parent
+    for file in sorted(root.rglob("*.py")):
+        if "__init__" in file.name or "main" in file.name or "common" in file.name:
+            continue
+        rel = file.relative_to(root.parent)
+        modname = str(rel).replace("/", ".")[: -len(".py")]
+        if not _defines_gm(file):
+            continue
+        module = importlib.import_module(modname)
+        for key in dir(module):
+            obj = getattr(module, key)
+            if type(obj) == type and issubclass(obj, GM) and obj is not GM:
+                models[convert_camel_to_snake(key)] = obj
+    if "diffusion_model" in models:
+        models["diffusion"] = models["diffusion_model"]
+    return models
+
+
+def _defines_gm(file):
+    """Only import modules that can define a plugin (keeps discovery from importing kernels/bindings needlessly)."""
+    try:
+        text = file.read_text()
+    except OSError:
+        return False
+    return re.search(r"^\s*class\s+\w+\(.*GM\w*\)", text, flags=re.M) is not None
+
+
+def to_numpy(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x
+
+
+def args_type(default):
+    """Flag parser chosen from the default's type (gms/common.py:85-92): bools are 'True'/'False', ints accept
+    '1e3'-style floats, Paths are expanded."""
+    if isinstance(default, bool):
+        return lambda x: bool(["False", "True"].index(x))
+    if isinstance(default, int):
+        return lambda x: float(x) if ("e" in x or "." in x) else int(x)
+    if isinstance(default, Path):
+        return lambda x: Path(x).expanduser()
+    return type(default)
+
+
+def count_vars(module):
+    return sum([np.prod(p.shape) for p in module.parameters()])
+
+
+class NullWriter:
+    """Stand-in for tensorboard's SummaryWriter (not installed in this image): keeps the call surface, stores scalars."""
+
+    def __init__(self, logdir=None):
+        self.logdir = logdir
+        self.scalars = defaultdict(list)
+
+    def add_scalar(self, key, val, step):
+        self.scalars[key].append((step, float(val)))
+
+    def add_image(self, *a, **k):
+        pass
+
+    def add_video(self, *a, **k):
+        pass
+
+    def flush(self):
+        pass
+
+
+def dump_logger(logger, writer, i, G):
+    """Print + write the epoch means and hps.yaml (gms/common.py:65-82).  The git hash is best-effort: the
+    reference requires a checkout; outside one it is recorded as 'unknown'."""
+    print("=" * 30)
+    print(i)
+    for key in logger:
+        val = np.mean(logger[key])
+        writer.add_scalar(key, val, i)
+        print(key, val)
+    G.full_cmd = "python " + " ".join(sys.argv)
+    try:
+        G.commit_hash = subprocess.check_output(["git", "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode("ascii").strip()
+    except Exception:
+        G.commit_hash = "unknown"
+    print(G.full_cmd)
+    Path(G.logdir).mkdir(parents=True, exist_ok=True)
+    with open(Path(G.logdir) / "hps.yaml", "w") as f:
+        yaml.dump(dict(G), f, width=float("inf"))
+    print("=" * 30)
+    writer.flush()
+    return defaultdict(lambda: [])

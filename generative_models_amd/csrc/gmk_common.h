@@ -1,0 +1,86 @@
+// gmk — gfx950 (MI355X) kernels for the diffusion hot path.  Internal helpers shared by the .hip files.
+// Device code is written for CDNA4 only: 64-lane waves, MFMA 32x32 tiles, 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gmk.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define GMK_LDS __attribute__((address_space(3)))
+
+// ---- host-side error plumbing (no exceptions cross the C ABI) -------------------------------
+void gmk_set_error(const char* fmt, ...);
+int gmk_check_launch(const char* what);   // returns 0 or the positive hipError_t of the launch
+
+#define GMK_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            gmk_set_error(__VA_ARGS__);        \
+            return GMK_ERR_ARG;                \
+        }                                      \
+    } while (0)
+
+static inline hipStream_t gmk_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int gmk_esize(int dtype) { return dtype == GMK_BF16 ? 2 : 4; }
+
+// ---- device helpers ---------------------------------------------------------------------------
+template <typename T> struct Vec8;   // 8 activation elements as the natural 16/32-byte vector
+
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+}
+__device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = a;
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
+    bf16x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x4*>(p) = a;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x / (1.0f + __expf(-x)); }
+
+// 64-lane wave sum (butterfly; every lane ends with the total)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}

@@ -1,0 +1,26 @@
+// Error plumbing of the C ABI (include/gmk.h): per-thread message, no exceptions.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "gmk_common.h"
+
+static thread_local char g_err[512] = "";
+
+void gmk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int gmk_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gmk_set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+extern "C" int gmk_version(void) { return 1; }
+extern "C" const char* gmk_last_error(void) { return g_err; }

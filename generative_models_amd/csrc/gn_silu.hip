@@ -1,0 +1,349 @@
+// GroupNorm + SiLU forward/backward on NHWC activations, plus the small reductions that travel with them.
+// Replaces nn.GroupNorm(32, C) -> nn.SiLU() pairs (reference gms/diffusion/simple_unet.py:39-40,161-162,169-170)
+// and their autograd backward.  HBM-bound: one 256-thread workgroup per sample streams the sample twice
+// (statistics, then apply); the second sweep is served from L2 (a 28x28x128 bf16 sample is 200 KB).
+// Every thread owns one 8-channel vector (16 B of bf16) of a pixel, so loads are 16 B/lane and a wave covers
+// whole 256-B pixel rows; reductions go per-thread -> LDS -> per-group.
+#include "gmk_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              float* __restrict__ mean, float* __restrict__ rstd,
+                                                              int HW, int C, int G, float eps) {
+    __shared__ float red[kThreads * 4];
+    __shared__ float smean[64], srstd[64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nvec = C >> 3, planes = kThreads / nvec;
+    const int vec = tid % nvec, pl = tid / nvec;
+    const int cpg = C / G;
+    const T* xb = x + (size_t)b * HW * C + vec * 8;
+    T* yb = y + (size_t)b * HW * C + vec * 8;
+
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    for (int p = pl; p < HW; p += planes) {
+        float v[8];
+        load8(xb + (size_t)p * C, v);
+        s0 += (v[0] + v[1]) + (v[2] + v[3]);
+        q0 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        s1 += (v[4] + v[5]) + (v[6] + v[7]);
+        q1 += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
+    }
+    red[tid * 4 + 0] = s0; red[tid * 4 + 1] = q0; red[tid * 4 + 2] = s1; red[tid * 4 + 3] = q1;
+    __syncthreads();
+    if (tid < G) {
+        const int hv_per_g = cpg >> 2;   // 4-channel half-vectors per group
+        float s = 0.f, q = 0.f;
+        for (int j = 0; j < hv_per_g; ++j) {
+            const int hv = tid * hv_per_g + j, vv = hv >> 1, hf = hv & 1;
+            for (int p = 0; p < planes; ++p) {
+                s += red[(p * nvec + vv) * 4 + hf * 2];
+                q += red[(p * nvec + vv) * 4 + hf * 2 + 1];
+            }
+        }
+        const float n = (float)cpg * (float)HW;
+        const float m = s / n;
+        const float var = fmaxf(q / n - m * m, 0.f);
+        const float r = 1.0f / sqrtf(var + eps);
+        smean[tid] = m; srstd[tid] = r;
+        mean[b * G + tid] = m; rstd[b * G + tid] = r;
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = vec * 8 + i, g = c / cpg;
+        sc[i] = srstd[g] * gamma[c];
+        sh[i] = beta[c] - smean[g] * sc[i];
+    }
+    for (int p = pl; p < HW; p += planes) {
+        float v[8];
+        load8(xb + (size_t)p * C, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = siluf_(fmaf(v[i], sc[i], sh[i]));
+        store8(yb + (size_t)p * C, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const T* __restrict__ dadd1,
+    const T* __restrict__ dadd2, T* __restrict__ dx, float* __restrict__ dgp, float* __restrict__ dbp,
+    float* __restrict__ dxsum, int dxsum_stride, int HW, int C, int G) {
+    __shared__ float red[kThreads * 16];
+    __shared__ float chg[256], chb[256];
+    __shared__ float sA[64], sB[64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nvec = C >> 3, planes = kThreads / nvec;
+    const int vec = tid % nvec, pl = tid / nvec;
+    const int cpg = C / G;
+    const size_t base = (size_t)b * HW * C + vec * 8;
+
+    float gam[8], bet[8], mu[8], rs[8];
+    int grp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = vec * 8 + i;
+        grp[i] = c / cpg;
+        gam[i] = gamma[c]; bet[i] = beta[c];
+        mu[i] = mean[b * G + grp[i]]; rs[i] = rstd[b * G + grp[i]];
+    }
+    float ag[8], ab[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+    for (int p = pl; p < HW; p += planes) {
+        float xv[8], dv[8];
+        load8(x + base + (size_t)p * C, xv);
+        load8(dy + base + (size_t)p * C, dv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = (xv[i] - mu[i]) * rs[i];
+            const float g = fmaf(xh, gam[i], bet[i]);
+            const float s = sigmoidf_(g);
+            const float dg = dv[i] * s * (1.f + g * (1.f - s));
+            ag[i] = fmaf(dg, xh, ag[i]);
+            ab[i] += dg;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[tid * 16 + i] = ag[i]; red[tid * 16 + 8 + i] = ab[i]; }
+    __syncthreads();
+    if (tid < C) {
+        const int vv = tid >> 3, i = tid & 7;
+        float a = 0.f, bb = 0.f;
+        for (int p = 0; p < planes; ++p) {
+            a += red[(p * nvec + vv) * 16 + i];
+            bb += red[(p * nvec + vv) * 16 + 8 + i];
+        }
+        chg[tid] = a; chb[tid] = bb;
+        dgp[(size_t)b * C + tid] = a;
+        dbp[(size_t)b * C + tid] = bb;
+    }
+    __syncthreads();
+    if (tid < G) {
+        float A = 0.f, Bq = 0.f;
+        for (int j = 0; j < cpg; ++j) {
+            const int c = tid * cpg + j;
+            A = fmaf(gamma[c], chb[c], A);
+            Bq = fmaf(gamma[c], chg[c], Bq);
+        }
+        const float inv_n = 1.f / ((float)cpg * (float)HW);
+        sA[tid] = A * inv_n; sB[tid] = Bq * inv_n;
+    }
+    __syncthreads();
+    float cA[8], cB[8], xs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { cA[i] = sA[grp[i]]; cB[i] = sB[grp[i]]; xs[i] = 0.f; }
+    for (int p = pl; p < HW; p += planes) {
+        float xv[8], dv[8], o[8];
+        load8(x + base + (size_t)p * C, xv);
+        load8(dy + base + (size_t)p * C, dv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = (xv[i] - mu[i]) * rs[i];
+            const float g = fmaf(xh, gam[i], bet[i]);
+            const float s = sigmoidf_(g);
+            const float dg = dv[i] * s * (1.f + g * (1.f - s));
+            o[i] = rs[i] * (dg * gam[i] - cA[i] - xh * cB[i]);
+        }
+        if (dadd1) {
+            float t[8];
+            load8(dadd1 + base + (size_t)p * C, t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] += t[i];
+        }
+        if (dadd2) {
+            float t[8];
+            load8(dadd2 + base + (size_t)p * C, t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] += t[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xs[i] += o[i];
+        store8(dx + base + (size_t)p * C, o);
+    }
+    if (dxsum) {
+        __syncthreads();   // red is re-used
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[tid * 16 + i] = xs[i];
+        __syncthreads();
+        if (tid < C) {
+            const int vv = tid >> 3, i = tid & 7;
+            float a = 0.f;
+            for (int p = 0; p < planes; ++p) a += red[(p * nvec + vv) * 16 + i];
+            dxsum[(size_t)b * dxsum_stride + tid] = a;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void chansum_kernel(const T* __restrict__ x, float* __restrict__ out,
+                                                          int out_stride, int HW, int C) {
+    __shared__ float red[kThreads * 8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nvec = C >> 3, planes = kThreads / nvec;
+    const int vec = tid % nvec, pl = tid / nvec;
+    const T* xb = x + (size_t)b * HW * C + vec * 8;
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = 0.f;
+    for (int p = pl; p < HW; p += planes) {
+        float v[8];
+        load8(xb + (size_t)p * C, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] += v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[tid * 8 + i] = s[i];
+    __syncthreads();
+    if (tid < C) {
+        const int vv = tid >> 3, i = tid & 7;
+        float a = 0.f;
+        for (int p = 0; p < planes; ++p) a += red[(p * nvec + vv) * 8 + i];
+        out[(size_t)b * out_stride + tid] = a;
+    }
+}
+
+// out[c] (+)= sum_r part[r*stride + c]; block = 32 columns x 8 row lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int64_t stride,
+                                                    float* __restrict__ out, int R, int C, int accumulate) {
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s = 0.f;
+    if (c < C) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int r = rl;
+        for (; r + 24 < R; r += 32) {
+            s0 += part[(int64_t)r * stride + c];
+            s1 += part[(int64_t)(r + 8) * stride + c];
+            s2 += part[(int64_t)(r + 16) * stride + c];
+            s3 += part[(int64_t)(r + 24) * stride + c];
+        }
+        for (; r < R; r += 8) s0 += part[(int64_t)r * stride + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][cl];
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t total,
+                                                        int H, int W, int C) {
+    const int nvec = C >> 3;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int vec = (int)(idx % nvec);
+        int64_t pix = idx / nvec;
+        const int ox = (int)(pix % W);
+        pix /= W;
+        const int oy = (int)(pix % H);
+        const int64_t b = pix / H;
+        const T* p00 = x + (((b * 2 * H + 2 * oy) * 2 * W) + 2 * ox) * (int64_t)C + vec * 8;
+        float a[8], t[8];
+        load8(p00, a);
+        load8(p00 + C, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] += t[i];
+        load8(p00 + (int64_t)2 * W * C, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] += t[i];
+        load8(p00 + (int64_t)2 * W * C + C, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] += t[i];
+        store8(y + ((b * H + oy) * W + ox) * (int64_t)C + vec * 8, a);
+    }
+}
+
+bool gn_shape_ok(int C, int G) {
+    if (C <= 0 || C > 256 || (C & 7) || 256 % (C >> 3)) return false;
+    if (G <= 0 || G > 64 || C % G) return false;
+    const int cpg = C / G;
+    return cpg == 4 || cpg == 8 || cpg == 16;
+}
+
+}  // namespace
+
+extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                               int B, int HW, int C, int groups, float eps, int dtype, void* stream) {
+    GMK_REQUIRE(x && y && gamma && beta && mean && rstd, "gmk_gn_silu_fwd: null pointer");
+    GMK_REQUIRE(B > 0 && HW > 0 && gn_shape_ok(C, groups), "gmk_gn_silu_fwd: unsupported shape B=%d HW=%d C=%d G=%d", B,
+                HW, C, groups);
+    if (dtype == GMK_BF16)
+        gn_silu_fwd_kernel<bf16_t><<<B, kThreads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta,
+                                                                            mean, rstd, HW, C, groups, eps);
+    else if (dtype == GMK_F32)
+        gn_silu_fwd_kernel<float><<<B, kThreads, 0, gmk_stream(stream)>>>((const float*)x, (float*)y, gamma, beta,
+                                                                          mean, rstd, HW, C, groups, eps);
+    else
+        GMK_REQUIRE(false, "gmk_gn_silu_fwd: bad dtype %d", dtype);
+    return gmk_check_launch("gmk_gn_silu_fwd");
+}
+
+extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                               const float* rstd, const void* dadd1, const void* dadd2, void* dx, float* dgamma_part,
+                               float* dbeta_part, float* dxsum, int dxsum_stride, int B, int HW, int C, int groups,
+                               int dtype, void* stream) {
+    GMK_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma_part && dbeta_part,
+                "gmk_gn_silu_bwd: null pointer");
+    GMK_REQUIRE(B > 0 && HW > 0 && gn_shape_ok(C, groups), "gmk_gn_silu_bwd: unsupported shape B=%d HW=%d C=%d G=%d", B,
+                HW, C, groups);
+    GMK_REQUIRE(!dxsum || dxsum_stride >= C, "gmk_gn_silu_bwd: dxsum_stride %d < C %d", dxsum_stride, C);
+    if (dtype == GMK_BF16)
+        gn_silu_bwd_kernel<bf16_t><<<B, kThreads, 0, gmk_stream(stream)>>>(
+            (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2,
+            (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups);
+    else if (dtype == GMK_F32)
+        gn_silu_bwd_kernel<float><<<B, kThreads, 0, gmk_stream(stream)>>>(
+            (const float*)dy, (const float*)x, gamma, beta, mean, rstd, (const float*)dadd1, (const float*)dadd2,
+            (float*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups);
+    else
+        GMK_REQUIRE(false, "gmk_gn_silu_bwd: bad dtype %d", dtype);
+    return gmk_check_launch("gmk_gn_silu_bwd");
+}
+
+extern "C" int gmk_chansum(const void* x, float* out, int out_stride, int B, int HW, int C, int dtype, void* stream) {
+    GMK_REQUIRE(x && out, "gmk_chansum: null pointer");
+    GMK_REQUIRE(B > 0 && HW > 0 && C > 0 && C <= 256 && !(C & 7) && 256 % (C >> 3) == 0 && out_stride >= C,
+                "gmk_chansum: unsupported shape B=%d HW=%d C=%d stride=%d", B, HW, C, out_stride);
+    if (dtype == GMK_BF16)
+        chansum_kernel<bf16_t><<<B, kThreads, 0, gmk_stream(stream)>>>((const bf16_t*)x, out, out_stride, HW, C);
+    else if (dtype == GMK_F32)
+        chansum_kernel<float><<<B, kThreads, 0, gmk_stream(stream)>>>((const float*)x, out, out_stride, HW, C);
+    else
+        GMK_REQUIRE(false, "gmk_chansum: bad dtype %d", dtype);
+    return gmk_check_launch("gmk_chansum");
+}
+
+extern "C" int gmk_colsum(const float* part, int64_t stride, float* out, int R, int C, int accumulate, void* stream) {
+    GMK_REQUIRE(part && out, "gmk_colsum: null pointer");
+    GMK_REQUIRE(R > 0 && C > 0 && stride >= C, "gmk_colsum: bad shape R=%d C=%d stride=%lld", R, C, (long long)stride);
+    colsum_kernel<<<(C + 31) / 32, 256, 0, gmk_stream(stream)>>>(part, stride, out, R, C, accumulate);
+    return gmk_check_launch("gmk_colsum");
+}
+
+extern "C" int gmk_sumpool2x2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+    GMK_REQUIRE(x && y, "gmk_sumpool2x2: null pointer");
+    GMK_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && !(C & 7), "gmk_sumpool2x2: bad shape");
+    const int64_t total = (int64_t)B * H * W * (C >> 3);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype == GMK_BF16)
+        sumpool2x2_kernel<bf16_t><<<blocks, 256, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, total, H, W, C);
+    else if (dtype == GMK_F32)
+        sumpool2x2_kernel<float><<<blocks, 256, 0, gmk_stream(stream)>>>((const float*)x, (float*)y, total, H, W, C);
+    else
+        GMK_REQUIRE(false, "gmk_sumpool2x2: bad dtype %d", dtype);
+    return gmk_check_launch("gmk_sumpool2x2");
+}

@@ -1,0 +1,124 @@
+"""`DiffusionModel` plugin — drop-in for reference gms/diffusion/diffusion_model.py:14-111 on the HIP path.
+
+Same class name (registry key `diffusion_model`, alias `diffusion`), same `DG` keys and defaults (:15-29), same
+method surface the driver calls: train_step(x, y) -> {'loss', 'loss_scale'}, loss(x, y) -> (loss, metrics),
+sample(n, y) -> [n, C, S, S] in [-1, 1], evaluate(writer, x, y, epoch), save (inherited).  State-dict keys are
+`net.<reference names>`.
+
+How it differs underneath: bf16 MFMA compute with fp32 master weights instead of fp16 autocast + GradScaler
+(bf16 needs no loss scaling; `loss_scale` is reported as 1.0 to keep the metric key); one fused pass
+(forward -> loss -> explicit backward -> bucketed RCCL all-reduce -> fused Adam) instead of autograd + per-tensor
+optimiser; RNG from counter-based Philox streams on the device.  `make_plugin(base)` builds the same class on top of
+the REFERENCE's `gms.common.GM`, which is what a `gms/` checkout needs for `discover_models()` to pick it up
+(INTEGRATION.md).
+"""
+import random
+from functools import partial
+from pathlib import Path
+
+import torch
+
+from .. import common, parallel
+from .gaussian_diffusion import GaussianDiffusion, PhiloxStream
+from .optim import FusedAdam
+from .simple_unet import SimpleUnet
+
+_DTYPES = {"bf16": torch.bfloat16, "fp32": torch.float32}
+
+
+def make_plugin(GMBase, AttrDict):
+    class DiffusionModel(GMBase):
+        DG = AttrDict()  # default G  (diffusion_model.py:15-29)
+        DG.binarize = 0
+        DG.timesteps = 250
+        DG.hidden_size = 128
+        DG.dropout = 0.0
+        DG.sampler = "ddim"
+        DG.mean_type = "v"
+        DG.eval_heavy = 1
+        DG.class_cond = 1
+        DG.sample_cond_w = -1.0
+        DG.cf_drop_prob = 0.1
+        DG.teacher_path = Path(".")
+        DG.teacher_mode = "step1"
+        DG.lr_scheduler = "none"
+        # additions of the HIP path
+        DG.compute_dtype = "bf16"      # 'bf16' (MFMA) or 'fp32' (exact-fp32 MFMA, 1e-3 parity mode)
+        DG.in_channels = 1             # reference: 1 (simple_unet.py:93,41)
+        DG.seed = 0
+
+        def __init__(self, G):
+            super().__init__(G)
+            get = lambda k: G[k] if k in G else self.DG[k]
+            if Path(get("teacher_path")) != Path("."):
+                raise NotImplementedError("progressive distillation (--teacher_path) is not on the HIP path yet")
+            self.net = SimpleUnet(get("hidden_size"), get("dropout"), in_channels=get("in_channels"),
+                                  compute_dtype=_DTYPES[get("compute_dtype")])
+            self.teacher_net = None
+            seed = int(get("seed")) * 1000 + parallel.rank()
+            self.diffusion = GaussianDiffusion(mean_type=get("mean_type"), num_steps=int(get("timesteps")),
+                                               sampler=get("sampler"), teacher_net=None,
+                                               teacher_mode=get("teacher_mode"), sample_cond_w=get("sample_cond_w"),
+                                               seed=seed)
+            self.optimizer = FusedAdam(self.net, lr=G.lr if "lr" in G else 3e-4)
+            self.size = 32 if ("pad32" in G and G.pad32) else 28
+            self._aux_rng = PhiloxStream(seed + 7919)
+            self._sync = None
+
+        # -- training (diffusion_model.py:63-74)
+        def train_step(self, x, y):
+            B = x.shape[0]
+            # classifier-free label drop (:67); mutates the caller's y in place like the reference, but the mask
+            # comes from the device RNG (the reference's CPU-generated mask forces a host sync every step)
+            drop = self._aux_rng.uniform((B,), x.device) < float(self.G.cf_drop_prob if "cf_drop_prob" in self.G
+                                                                   else self.DG.cf_drop_prob)
+            y.masked_fill_(drop, -1)
+            if self._sync is None:
+                self._sync = parallel.GradSync(self.net)
+            world = parallel.world()
+            out = self.diffusion.train_forward_backward(net=partial(self.net, guide=y), x=x, grad_scale=1.0 / B,
+                                                        on_grads_ready=self._sync.hook)
+            self._sync.finish()
+            self.optimizer.step(grad_scale=1.0 / world)
+            metrics = {"loss": out["loss"].mean()}
+            metrics["loss_scale"] = torch.tensor(1.0)
+            return metrics
+
+        # -- loss (:76-80): differentiable through torch.autograd; used by the driver's test-set pass
+        def loss(self, x, y):
+            metrics = self.diffusion.training_losses(net=partial(self.net, guide=y), x=x)
+            metrics = {key: val.mean() for key, val in metrics.items()}
+            return metrics["loss"], metrics
+
+        # -- sampling (:82-87)
+        def sample(self, n, y=None):
+            with torch.no_grad():
+                dev = self.net.flat_params.device
+                noise = self._aux_rng.normal((n, self.net.in_channels, self.size, self.size), dev)
+                net = partial(self.net, guide=y)
+                cond_w = 0.5 if y is not None else None
+                return self.diffusion.sample(net=net, init_x=noise, cond_w=cond_w, record=False)[0][-1]
+
+        # -- evaluate (:89-111): 25 class-conditional samples without guidance, trajectories as uint8
+        def evaluate(self, writer, x, y, epoch):
+            def proc(t):
+                t = ((t + 1) * 127.5).clamp(0, 255).to(torch.uint8).cpu()
+                if "pad32" in self.G and self.G.pad32:
+                    t = t[..., 2:-2, 2:-2]
+                return t
+
+            stream = PhiloxStream(0)                                  # :99 torch.manual_seed(0)
+            noise = stream.normal((25, self.net.in_channels, self.size, self.size), x.device)
+            labels = torch.arange(25, dtype=torch.long, device=x.device) % 10   # :101
+            zs, xs, eps = self.diffusion.sample(net=partial(self.net, guide=labels), init_x=noise)
+            zs, xs, eps = proc(zs), proc(xs), proc(eps)
+            self.last_eval = {"samples": zs[-1], "sampling_process": zs, "eps": eps, "x": xs}
+            if writer is not None and hasattr(writer, "add_image"):
+                grid = zs[-1].reshape(5, 5, *zs.shape[-2:]).permute(0, 2, 1, 3).reshape(1, 5 * zs.shape[-2], 5 * zs.shape[-1])
+                writer.add_image("samples", grid, epoch)
+            random.randint(0, 2 ** 32)                                # :111 keeps the host RNG consumption
+
+    return DiffusionModel
+
+
+DiffusionModel = make_plugin(common.GM, common.AttrDict)

@@ -1,0 +1,488 @@
+"""HIP-backed `SimpleUnet` — host-side mirror of reference gms/diffusion/simple_unet.py:16-72.
+
+Same constructor, call signature and state-dict keys as the reference module, so reference
+checkpoints load; every arithmetic op runs in libgmk.so (include/gmk.h).  Differences in *how*:
+
+* parameters are views into ONE flat fp32 arena (`net.flat_params`), gradients into a second one
+  (`net.flat_grads`): the optimiser is a single fused kernel over the arena and the data-parallel gradient
+  exchange is a handful of large RCCL all-reduces over contiguous ranges instead of 160 small tensors;
+* activations are NHWC in `compute_dtype` (bf16 by default, fp32 for the 1e-3 parity mode); convolution weights
+  are re-packed into K-contiguous tiles for the MFMA implicit GEMM whenever the parameters change;
+* torch.cat([x, skip]) (simple_unet.py:150), F.interpolate(nearest) (:120), the embedding broadcast add (:184)
+  and the residual add (:186) are folded into the convolution kernels' gather / epilogue;
+* forward and backward are explicit schedules of kernel launches (no autograd graph); `SimpleUnetFunction`
+  exposes the pair to torch.autograd so `loss.backward()` style code keeps working.
+
+Extension over the reference: `in_channels` (the reference hard-codes 1, simple_unet.py:93,41).
+Restriction: `channels` must be a multiple of 128 (the MFMA tile width); other widths raise.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .. import ops
+
+MAX_TIMESTEPS = 256  # simple_unet.py:13
+
+
+# ----------------------------------------------------------------------------------------------------------
+# parameter inventory (reference registration order)
+# ----------------------------------------------------------------------------------------------------------
+def _res_names(prefix, cin, cout, emb):
+    out = [
+        (f"{prefix}.in_layers.0.weight", (cin,)), (f"{prefix}.in_layers.0.bias", (cin,)),
+        (f"{prefix}.in_layers.2.weight", (cout, cin, 3, 3)), (f"{prefix}.in_layers.2.bias", (cout,)),
+        (f"{prefix}.emb_layers.1.weight", (cout, emb)), (f"{prefix}.emb_layers.1.bias", (cout,)),
+        (f"{prefix}.out_layers.0.weight", (cout,)), (f"{prefix}.out_layers.0.bias", (cout,)),
+        (f"{prefix}.out_layers.3.weight", (cout, cout, 3, 3)), (f"{prefix}.out_layers.3.bias", (cout,)),
+    ]
+    if cin != cout:
+        out += [(f"{prefix}.skip_connection.weight", (cout, cin, 1, 1)), (f"{prefix}.skip_connection.bias", (cout,))]
+    return out
+
+
+RES_BLOCKS = ["down.seq.1", "down.seq.2", "down.seq.4", "down.seq.5", "turn", "up.seq.0.0", "up.seq.1", "up.seq.2",
+              "up.seq.3.0", "up.seq.4", "up.seq.5", "up.seq.6"]
+
+
+def param_inventory(C, in_channels=1):
+    E = 2 * C
+    inv = []
+    for name, fan_in in (("time_embed", 64), ("cond_w_embed", 64), ("guide_embed", 10)):
+        inv += [(f"{name}.0.weight", (E, fan_in)), (f"{name}.0.bias", (E,)),
+                (f"{name}.2.weight", (E, E)), (f"{name}.2.bias", (E,))]
+    inv += [("down.seq.0.conv.weight", (C, in_channels, 3, 3)), ("down.seq.0.conv.bias", (C,))]
+    inv += _res_names("down.seq.1", C, C, E) + _res_names("down.seq.2", C, C, E)
+    inv += [("down.seq.3.conv.weight", (C, C, 3, 3)), ("down.seq.3.conv.bias", (C,))]
+    inv += _res_names("down.seq.4", C, C, E) + _res_names("down.seq.5", C, C, E)
+    inv += [("down.seq.6.conv.weight", (C, C, 3, 3)), ("down.seq.6.conv.bias", (C,))]
+    inv += _res_names("turn", C, C, E)
+    for i in range(7):
+        if i in (0, 3):
+            inv += _res_names(f"up.seq.{i}.0", 2 * C, C, E)
+            inv += [(f"up.seq.{i}.1.conv.weight", (C, C, 3, 3)), (f"up.seq.{i}.1.conv.bias", (C,))]
+        else:
+            inv += _res_names(f"up.seq.{i}", 2 * C, C, E)
+    inv += [("out.0.weight", (C,)), ("out.0.bias", (C,)), ("out.2.weight", (in_channels, C, 3, 3)),
+            ("out.2.bias", (in_channels,))]
+    return inv
+
+
+def _attach(root, dotted, param):
+    """Register `param` under the nested attribute path `dotted`, creating container modules on the way."""
+    parts = dotted.split(".")
+    mod = root
+    for part in parts[:-1]:
+        if part not in mod._modules:
+            mod.add_module(part, nn.Module())
+        mod = mod._modules[part]
+    mod.register_parameter(parts[-1], param)
+
+
+class SimpleUnet(nn.Module):
+    def __init__(self, channels, dropout=0.0, in_channels=1, compute_dtype=torch.bfloat16):
+        super().__init__()
+        if channels % 128 != 0 or channels > 256:
+            raise ValueError(f"the HIP path supports hidden_size 128 or 256 (MFMA tile width 128); got {channels}")
+        if dropout != 0.0:
+            raise NotImplementedError("dropout > 0 is not implemented on the HIP path (reference default is 0.0)")
+        if not 1 <= in_channels <= 4:
+            raise ValueError("in_channels must be 1..4")
+        if compute_dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("compute_dtype must be torch.bfloat16 or torch.float32")
+        self.channels, self.in_channels, self.compute_dtype = channels, in_channels, compute_dtype
+        self._inventory = param_inventory(channels, in_channels)
+        # arena order: the 12 emb_layers Linear weights, then their biases (one batched GEMM serves all 12
+        # ResBlocks), then everything else in reference order; every tensor starts on a 16-byte boundary.
+        emb_w = [f"{b}.emb_layers.1.weight" for b in RES_BLOCKS]
+        emb_b = [f"{b}.emb_layers.1.bias" for b in RES_BLOCKS]
+        shapes = dict(self._inventory)
+        order = emb_w + emb_b + [n for n, _ in self._inventory if n not in set(emb_w + emb_b)]
+        self._offsets = OrderedDict()
+        off = 0
+        for n in order:
+            self._offsets[n] = off
+            off += (math.prod(shapes[n]) + 3) // 4 * 4
+        self._arena_size = off
+        flat = torch.zeros(off, dtype=torch.float32)
+        self._init_values(flat, shapes)
+        # registration order = reference order, so state_dict() lists keys exactly like the reference
+        for n, shp in self._inventory:
+            _attach(self, n, nn.Parameter(flat[self._offsets[n]:self._offsets[n] + math.prod(shp)].view(shp)))
+        self._shapes = shapes
+        self._bind(flat)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_params_changed())
+
+    # ---- initialisation: torch defaults for Linear / Conv2d / GroupNorm, `out_layers.3` zeroed (simple_unet.py:172)
+    def _init_values(self, flat, shapes):
+        for n, shp in self._inventory:
+            view = flat[self._offsets[n]:self._offsets[n] + math.prod(shp)].view(shp)
+            base, kind = n.rsplit(".", 1)
+            wshape = shapes.get(base + ".weight")
+            if len(wshape) >= 2:                      # Linear / Conv2d: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                bound = 1.0 / math.sqrt(math.prod(wshape[1:]))
+                if ".out_layers.3" in n:
+                    view.zero_()
+                else:
+                    view.uniform_(-bound, bound)
+            else:                                      # GroupNorm affine
+                view.fill_(1.0 if kind == "weight" else 0.0)
+
+    # ---- flat arena management -------------------------------------------------------------------------
+    def _bind(self, flat):
+        self.flat_params = flat
+        self.flat_grads = torch.zeros_like(flat)
+        named = dict(self.named_parameters())
+        self._pv, self._gv = {}, {}
+        for n, shp in self._inventory:
+            o, k = self._offsets[n], math.prod(shp)
+            p = named[n]
+            p.data = flat[o:o + k].view(shp)
+            p.grad = self.flat_grads[o:o + k].view(shp)
+            self._pv[n] = p.data
+            self._gv[n] = p.grad
+        self._packs = None
+        self._packs_stale = True
+        self._freqs = {}
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        # .to()/.cuda() moved every parameter separately: rebuild the arena on the new device and re-point the views
+        named = dict(self.named_parameters())
+        dev = next(iter(named.values())).device
+        flat = torch.zeros(self._arena_size, dtype=torch.float32, device=dev)
+        for n, shp in self._inventory:
+            o, k = self._offsets[n], math.prod(shp)
+            flat[o:o + k].copy_(named[n].data.reshape(-1).float())
+        self._bind(flat)
+        return self
+
+    def mark_params_changed(self):
+        self._packs_stale = True
+
+    def param(self, name):
+        return self._pv[name]
+
+    def grad(self, name):
+        return self._gv[name]
+
+    def arena_range(self, names):
+        """(start, end) of the contiguous arena range spanned by `names` (used for gradient buckets)."""
+        starts = [self._offsets[n] for n in names]
+        ends = [self._offsets[n] + (math.prod(self._shapes[n]) + 3) // 4 * 4 for n in names]
+        return min(starts), max(ends)
+
+    # ---- weight packs ----------------------------------------------------------------------------------
+    def _conv_names(self):
+        names = ["down.seq.3.conv", "down.seq.6.conv", "up.seq.0.1.conv", "up.seq.3.1.conv"]
+        for b in RES_BLOCKS:
+            names += [f"{b}.in_layers.2", f"{b}.out_layers.3"]
+            if f"{b}.skip_connection.weight" in self._shapes:
+                names.append(f"{b}.skip_connection")
+        return names
+
+    def _repack(self):
+        dev = self.flat_params.device
+        if dev.type != "cuda":
+            raise RuntimeError("SimpleUnet (HIP) must live on a GPU device: call .to('cuda') first; no CPU fallback")
+        names = self._conv_names()
+        if self._packs is None:
+            total = sum(2 * math.prod(self._shapes[n + ".weight"]) for n in names)
+            self._pack_buf = torch.empty(total, device=dev, dtype=self.compute_dtype)
+            self._packs = {}
+            off = 0
+            for n in names:
+                k = math.prod(self._shapes[n + ".weight"])
+                self._packs[n] = (self._pack_buf[off:off + k], self._pack_buf[off + k:off + 2 * k])
+                off += 2 * k
+        for n in names:
+            wf, wd = self._packs[n]
+            ops.pack_conv_weight(self._pv[n + ".weight"], wf, wd)
+        self._packs_stale = False
+
+    # ---- embedding path (simple_unet.py:45-64 + the 12 emb_layers of :166) --------------------------------
+    def _freq_table(self, max_period, dev):
+        key = (max_period, dev)
+        if key not in self._freqs:
+            self._freqs[key] = ops.timestep_freqs(max_period, dev)
+        return self._freqs[key]
+
+    def _mlp_fwd(self, prefix, x, ctx, rowscale=None, out=None):
+        P = self._pv
+        h1 = ops.gemm(x, P[f"{prefix}.0.weight"].t(), bias=P[f"{prefix}.0.bias"])
+        y = ops.gemm(h1, P[f"{prefix}.2.weight"].t(), out=out, bias=P[f"{prefix}.2.bias"], rowscale=rowscale,
+                     silu_a=True, accumulate=out is not None)
+        if ctx is not None:
+            ctx[prefix] = (x, h1, rowscale)
+        return y
+
+    def _mlp_bwd(self, prefix, ctx, demb):
+        P, G = self._pv, self._gv
+        x, h1, rowscale = ctx[prefix]
+        d = ops.scale_rows(demb, rowscale) if rowscale is not None else demb
+        ops.gemm(d.t(), h1, out=G[f"{prefix}.2.weight"], silu_b=True)      # dW2 = d^T . silu(h1)
+        ops.colsum(d, G[f"{prefix}.2.bias"])
+        dsh = ops.gemm(d, P[f"{prefix}.2.weight"])
+        dh1 = ops.silu_bwd(dsh, h1)
+        ops.gemm(dh1.t(), x, out=G[f"{prefix}.0.weight"])
+        ops.colsum(dh1, G[f"{prefix}.0.bias"])
+
+    def _embed_fwd(self, logsnr, guide, cond_w, ctx):
+        dev = logsnr.device
+        C = self.channels
+        te = ops.timestep_embedding(logsnr.float().contiguous(), self._freq_table(MAX_TIMESTEPS, dev))
+        emb = self._mlp_fwd("time_embed", te, ctx)
+        if guide is not None:
+            onehot, keep = ops.guide_onehot(guide.contiguous())
+            self._mlp_fwd("guide_embed", onehot, ctx, rowscale=keep, out=emb)
+        if cond_w is not None:
+            ce = ops.timestep_embedding(cond_w.float().contiguous(), self._freq_table(4, dev))
+            self._mlp_fwd("cond_w_embed", ce, ctx, out=emb)
+        # all 12 ResBlock emb_layers (SiLU -> Linear(2C -> C)) as one GEMM over the arena-contiguous weights
+        o0 = self._offsets[f"{RES_BLOCKS[0]}.emb_layers.1.weight"]
+        wcat = self.flat_params[o0:o0 + 12 * C * 2 * C].view(12 * C, 2 * C)
+        b0 = self._offsets[f"{RES_BLOCKS[0]}.emb_layers.1.bias"]
+        bcat = self.flat_params[b0:b0 + 12 * C]
+        emb_all = ops.gemm(emb, wcat.t(), bias=bcat, silu_a=True)
+        if ctx is not None:
+            ctx["emb"] = emb
+        return emb_all
+
+    def _embed_bwd(self, ctx, demb_all):
+        C = self.channels
+        emb = ctx["emb"]
+        o0 = self._offsets[f"{RES_BLOCKS[0]}.emb_layers.1.weight"]
+        b0 = self._offsets[f"{RES_BLOCKS[0]}.emb_layers.1.bias"]
+        wcat = self.flat_params[o0:o0 + 12 * C * 2 * C].view(12 * C, 2 * C)
+        gw = self.flat_grads[o0:o0 + 12 * C * 2 * C].view(12 * C, 2 * C)
+        gb = self.flat_grads[b0:b0 + 12 * C]
+        ops.gemm(demb_all.t(), emb, out=gw, silu_b=True)        # dWcat[n][k] = sum_b dE[b][n] * silu(emb)[b][k]
+        ops.colsum(demb_all, gb)
+        dsemb = ops.gemm(demb_all, wcat)
+        demb = ops.silu_bwd(dsemb, emb)
+        self._mlp_bwd("time_embed", ctx, demb)
+        if "guide_embed" in ctx:
+            self._mlp_bwd("guide_embed", ctx, demb)
+        if "cond_w_embed" in ctx:
+            self._mlp_bwd("cond_w_embed", ctx, demb)
+
+    # ---- ResBlock (simple_unet.py:155-186) ---------------------------------------------------------------
+    def _res_fwd(self, name, srcs, emb_all, blk, ctx):
+        P, C = self._pv, self.channels
+        B, H, W, _ = srcs[0].shape
+        gpc = 32 // len(srcs)                                    # GroupNorm(32, cin): 16 groups per 128-ch source
+        a, stats1 = [], []
+        for i, s in enumerate(srcs):
+            g = P[f"{name}.in_layers.0.weight"][i * C:(i + 1) * C]
+            b = P[f"{name}.in_layers.0.bias"][i * C:(i + 1) * C]
+            y, mean, rstd = ops.gn_silu_fwd(s, g, b, gpc)
+            a.append(y); stats1.append((mean, rstd))
+        wf1, _ = self._packs[f"{name}.in_layers.2"]
+        h = ops.conv_igemm(a, wf1, C, 3, ops.NORMAL, (H, W), bias=P[f"{name}.in_layers.2.bias"],
+                           emb=emb_all[:, blk * C:(blk + 1) * C])
+        a2, mean2, rstd2 = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], 32)
+        if len(srcs) == 2:
+            wfs, _ = self._packs[f"{name}.skip_connection"]
+            res = ops.conv_igemm(srcs, wfs, C, 1, ops.NORMAL, (H, W), bias=P[f"{name}.skip_connection.bias"])
+        else:
+            res = srcs[0]
+        wf2, _ = self._packs[f"{name}.out_layers.3"]
+        out = ops.conv_igemm([a2], wf2, C, 3, ops.NORMAL, (H, W), bias=P[f"{name}.out_layers.3.bias"], residual=res)
+        if ctx is not None:
+            ctx[name] = (srcs, a, stats1, h, a2, (mean2, rstd2))
+        return out
+
+    def _res_bwd(self, name, ctx, dout, dout_sum, demb_all, blk, extra_add=None):
+        """dout: gradient of the block output (NHWC); dout_sum: its per-sample channel sums [B, C].
+        extra_add: per-source optional extra gradient tensors added into the returned source gradients.
+        Returns [(dsrc, dsrc_sum)] per source."""
+        P, G, C = self._pv, self._gv, self.channels
+        srcs, a, stats1, h, a2, (mean2, rstd2) = ctx.pop(name)
+        B, H, W, _ = dout.shape
+        two = len(srcs) == 2
+        # conv2 (out_layers.3)
+        ops.colsum(dout_sum, G[f"{name}.out_layers.3.bias"])
+        ops.conv_wgrad(dout, [a2], 3, ops.NORMAL, G[f"{name}.out_layers.3.weight"])
+        _, wd2 = self._packs[f"{name}.out_layers.3"]
+        da2 = ops.conv_igemm([dout], wd2, C, 3, ops.NORMAL, (H, W))
+        dh, dgp, dbp = ops.gn_silu_bwd(da2, h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], mean2,
+                                       rstd2, dxsum=demb_all[:, blk * C:(blk + 1) * C])
+        ops.colsum(dgp, G[f"{name}.out_layers.0.weight"]); ops.colsum(dbp, G[f"{name}.out_layers.0.bias"])
+        # conv1 (in_layers.2): bias gradient = column sum of the embedding gradient slice (both are sum_hw dh)
+        ops.colsum(demb_all[:, blk * C:(blk + 1) * C], G[f"{name}.in_layers.2.bias"])
+        ops.conv_wgrad(dh, a, 3, ops.NORMAL, G[f"{name}.in_layers.2.weight"])
+        _, wd1 = self._packs[f"{name}.in_layers.2"]
+        if two:
+            ops.colsum(dout_sum, G[f"{name}.skip_connection.bias"])
+            ops.conv_wgrad(dout, srcs, 1, ops.NORMAL, G[f"{name}.skip_connection.weight"])
+            _, wds = self._packs[f"{name}.skip_connection"]
+        outs = []
+        gw, gb = G[f"{name}.in_layers.0.weight"], G[f"{name}.in_layers.0.bias"]
+        for i, s in enumerate(srcs):
+            da = ops.conv_igemm([dh], wd1, len(srcs) * C, 3, ops.NORMAL, (H, W), n0=i * C)
+            if two:
+                dskip = ops.conv_igemm([dout], wds, 2 * C, 1, ops.NORMAL, (H, W), n0=i * C)
+            else:
+                dskip = dout
+            add2 = extra_add[i] if extra_add is not None else None
+            ssum = torch.empty((B, C), device=dout.device, dtype=torch.float32)
+            ds, dgp, dbp = ops.gn_silu_bwd(da, s, P[f"{name}.in_layers.0.weight"][i * C:(i + 1) * C],
+                                           P[f"{name}.in_layers.0.bias"][i * C:(i + 1) * C], stats1[i][0], stats1[i][1],
+                                           dadd1=dskip, dadd2=add2, dxsum=ssum)
+            ops.colsum(dgp, gw[i * C:(i + 1) * C]); ops.colsum(dbp, gb[i * C:(i + 1) * C])
+            outs.append((ds, ssum))
+        return outs
+
+    # ---- whole network ---------------------------------------------------------------------------------
+    def forward_hip(self, x, logsnr, guide=None, cond_w=None, ctx=None):
+        """x: NCHW fp32 [B, in_channels, H, W]; returns NCHW fp32.  ctx: dict receiving what backward needs."""
+        if self._packs_stale:
+            self._repack()
+        P, C, T = self._pv, self.channels, self.compute_dtype
+        B, cin, H, W = x.shape
+        if cin != self.in_channels or H % 4 or W % 4:
+            raise ValueError(f"input {tuple(x.shape)}: need {self.in_channels} channels and H, W divisible by 4")
+        x = x.contiguous().float()
+        emb_all = self._embed_fwd(logsnr, guide, cond_w, ctx)
+        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+        t0 = ops.stem_fwd(x, P["down.seq.0.conv.weight"], P["down.seq.0.conv.bias"], C, T)
+        t1 = self._res_fwd("down.seq.1", [t0], emb_all, 0, ctx)
+        t2 = self._res_fwd("down.seq.2", [t1], emb_all, 1, ctx)
+        t3 = ops.conv_igemm([t2], self._packs["down.seq.3.conv"][0], C, 3, ops.STRIDE2, (H2, W2),
+                            bias=P["down.seq.3.conv.bias"])
+        t4 = self._res_fwd("down.seq.4", [t3], emb_all, 2, ctx)
+        t5 = self._res_fwd("down.seq.5", [t4], emb_all, 3, ctx)
+        t6 = ops.conv_igemm([t5], self._packs["down.seq.6.conv"][0], C, 3, ops.STRIDE2, (H4, W4),
+                            bias=P["down.seq.6.conv.bias"])
+        t7 = self._res_fwd("turn", [t6], emb_all, 4, ctx)
+        u0r = self._res_fwd("up.seq.0.0", [t7, t6], emb_all, 5, ctx)
+        u0 = ops.conv_igemm([u0r], self._packs["up.seq.0.1.conv"][0], C, 3, ops.UPSAMPLE2, (H2, W2),
+                            bias=P["up.seq.0.1.conv.bias"])
+        u1 = self._res_fwd("up.seq.1", [u0, t5], emb_all, 6, ctx)
+        u2 = self._res_fwd("up.seq.2", [u1, t4], emb_all, 7, ctx)
+        u3r = self._res_fwd("up.seq.3.0", [u2, t3], emb_all, 8, ctx)
+        u3 = ops.conv_igemm([u3r], self._packs["up.seq.3.1.conv"][0], C, 3, ops.UPSAMPLE2, (H, W),
+                            bias=P["up.seq.3.1.conv.bias"])
+        u4 = self._res_fwd("up.seq.4", [u3, t2], emb_all, 9, ctx)
+        u5 = self._res_fwd("up.seq.5", [u4, t1], emb_all, 10, ctx)
+        u6 = self._res_fwd("up.seq.6", [u5, t0], emb_all, 11, ctx)
+        ao, mo, ro = ops.gn_silu_fwd(u6, P["out.0.weight"], P["out.0.bias"], 32)
+        out = ops.head_fwd(ao, P["out.2.weight"], P["out.2.bias"])
+        if ctx is not None:
+            ctx["net"] = (x, t2, t5, u0r, u3r, u6, ao, mo, ro)
+            ctx["dims"] = (B, H, W)
+        return out
+
+    def grad_buckets(self):
+        """Contiguous arena ranges [(start, end)] in the order their gradients become final during backward_hip:
+        up.seq.4..out, up.seq.0..up.seq.3, down.seq.0..turn, then the embedding MLPs + the 12 emb_layers."""
+        names = [n for n, _ in self._inventory]
+        def rng(pred):
+            return self.arena_range([n for n in names if pred(n)])
+        late = ("up.seq.4", "up.seq.5", "up.seq.6", "out.")
+        mid = ("up.seq.0", "up.seq.1", "up.seq.2", "up.seq.3")
+        emb = ("time_embed", "cond_w_embed", "guide_embed")
+        is_emb = lambda n: n.startswith(emb) or ".emb_layers." in n
+        b0 = rng(lambda n: n.startswith(late) and not is_emb(n))
+        b1 = rng(lambda n: n.startswith(mid) and not is_emb(n))
+        b2 = rng(lambda n: (n.startswith("down.") or n.startswith("turn.")) and not is_emb(n))
+        b3 = rng(is_emb)
+        buckets = [b0, b1, b2, b3]
+        assert sorted(buckets)[0][0] == 0 and sorted(buckets)[-1][1] == self._arena_size
+        srt = sorted(buckets)
+        assert all(srt[i][1] == srt[i + 1][0] for i in range(3)), "gradient buckets must tile the arena"
+        return buckets
+
+    def backward_hip(self, ctx, dout, on_grads_ready=None):
+        """dout: NCHW fp32 gradient of the network output.  Fills `flat_grads` (overwrites every touched slice).
+        on_grads_ready(k): called as soon as bucket k of grad_buckets() is final (overlapped gradient all-reduce)."""
+        ready = on_grads_ready if on_grads_ready is not None else (lambda k: None)
+        P, G, C, T = self._pv, self._gv, self.channels, self.compute_dtype
+        B, H, W = ctx["dims"]
+        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+        x, t2, t5, u0r, u3r, u6, ao, mo, ro = ctx["net"]
+        dev = dout.device
+        dout = dout.contiguous().float()
+        demb_all = torch.empty((B, 12 * C), device=dev, dtype=torch.float32)
+
+        # head: out.2 conv + out.0 GroupNorm/SiLU
+        o = self._offsets["out.2.weight"]
+        nhead = self.in_channels * C * 9
+        assert self._offsets["out.2.bias"] == o + (nhead + 3) // 4 * 4 == o + nhead
+        ops.head_wgrad(dout, ao, self.flat_grads[o:o + nhead + self.in_channels])
+        dao = ops.head_dgrad(dout, P["out.2.weight"], T)
+        s6 = torch.empty((B, C), device=dev, dtype=torch.float32)
+        du6, dgp, dbp = ops.gn_silu_bwd(dao, u6, P["out.0.weight"], P["out.0.bias"], mo, ro, dxsum=s6)
+        ops.colsum(dgp, G["out.0.weight"]); ops.colsum(dbp, G["out.0.bias"])
+
+        (du5, s5), (dt0a, _) = self._res_bwd("up.seq.6", ctx, du6, s6, demb_all, 11)
+        (du4, s4), (dt1a, _) = self._res_bwd("up.seq.5", ctx, du5, s5, demb_all, 10)
+        (du3, s3), (dt2a, _) = self._res_bwd("up.seq.4", ctx, du4, s4, demb_all, 9)
+        ready(0)
+        # up.seq.3.1: nearest x2 + conv
+        ops.colsum(s3, G["up.seq.3.1.conv.bias"])
+        ops.conv_wgrad(du3, [u3r], 3, ops.UPSAMPLE2, G["up.seq.3.1.conv.weight"])
+        dU = ops.conv_igemm([du3], self._packs["up.seq.3.1.conv"][1], C, 3, ops.NORMAL, (H, W))
+        du3r = ops.sumpool2x2(dU)
+        s3r = ops.chansum(du3r)
+        (du2, s2), (dt3a, _) = self._res_bwd("up.seq.3.0", ctx, du3r, s3r, demb_all, 8)
+        (du1, s1), (dt4a, _) = self._res_bwd("up.seq.2", ctx, du2, s2, demb_all, 7)
+        (du0, s0), (dt5a, _) = self._res_bwd("up.seq.1", ctx, du1, s1, demb_all, 6)
+        ops.colsum(s0, G["up.seq.0.1.conv.bias"])
+        ops.conv_wgrad(du0, [u0r], 3, ops.UPSAMPLE2, G["up.seq.0.1.conv.weight"])
+        dU = ops.conv_igemm([du0], self._packs["up.seq.0.1.conv"][1], C, 3, ops.NORMAL, (H2, W2))
+        du0r = ops.sumpool2x2(dU)
+        s0r = ops.chansum(du0r)
+        (dt7, s7), (dt6a, _) = self._res_bwd("up.seq.0.0", ctx, du0r, s0r, demb_all, 5)
+        ready(1)
+        ((dt6, s6t),) = self._res_bwd("turn", ctx, dt7, s7, demb_all, 4, extra_add=[dt6a])
+        # down.seq.6: stride-2 conv; its data gradient is the transposed gather
+        ops.colsum(s6t, G["down.seq.6.conv.bias"])
+        ops.conv_wgrad(dt6, [t5], 3, ops.STRIDE2, G["down.seq.6.conv.weight"])
+        dt5 = ops.conv_igemm([dt6], self._packs["down.seq.6.conv"][1], C, 3, ops.TRANSPOSED2, (H2, W2), residual=dt5a)
+        s5t = ops.chansum(dt5)
+        ((dt4, s4t),) = self._res_bwd("down.seq.5", ctx, dt5, s5t, demb_all, 3, extra_add=[dt4a])
+        ((dt3, s3t),) = self._res_bwd("down.seq.4", ctx, dt4, s4t, demb_all, 2, extra_add=[dt3a])
+        ops.colsum(s3t, G["down.seq.3.conv.bias"])
+        ops.conv_wgrad(dt3, [t2], 3, ops.STRIDE2, G["down.seq.3.conv.weight"])
+        dt2 = ops.conv_igemm([dt3], self._packs["down.seq.3.conv"][1], C, 3, ops.TRANSPOSED2, (H, W), residual=dt2a)
+        s2t = ops.chansum(dt2)
+        ((dt1, s1t),) = self._res_bwd("down.seq.2", ctx, dt2, s2t, demb_all, 1, extra_add=[dt1a])
+        ((dt0, s0t),) = self._res_bwd("down.seq.1", ctx, dt1, s1t, demb_all, 0, extra_add=[dt0a])
+        ops.colsum(s0t, G["down.seq.0.conv.bias"])
+        ops.stem_wgrad(x, dt0, G["down.seq.0.conv.weight"])
+        ready(2)
+        self._embed_bwd(ctx, demb_all)
+        ready(3)
+
+    def zero_grad_arena(self):
+        self.flat_grads.zero_()
+
+    def forward(self, x, timesteps, guide=None, cond_w=None):
+        """Reference signature (simple_unet.py:44).  Differentiable through SimpleUnetFunction when grad is enabled."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return SimpleUnetFunction.apply(self, x, timesteps, guide, cond_w, *self.parameters())
+        return self.forward_hip(x, timesteps, guide, cond_w)
+
+
+class SimpleUnetFunction(torch.autograd.Function):
+    """torch.autograd bridge: forward = forward_hip, backward = backward_hip.  Parameter gradients are ACCUMULATED
+    into `p.grad` (the arena views) like autograd would; there is no gradient w.r.t. x (the reference never needs it)."""
+
+    @staticmethod
+    def forward(ctx, net, x, timesteps, guide, cond_w, *params):
+        store = {}
+        out = net.forward_hip(x, timesteps, guide, cond_w, ctx=store)
+        ctx.net, ctx.store = net, store
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        net = ctx.net
+        prev = net.flat_grads.clone()
+        net.backward_hip(ctx.store, dout)
+        net.flat_grads.add_(prev)
+        # gradients were written in place into p.grad (views of the arena): return None for every input
+        return (None,) * (5 + len(list(net.parameters())))

@@ -1,0 +1,357 @@
+"""Thin torch-tensor wrappers over the C ABI (include/gmk.h).  torch supplies device memory and streams only.
+
+Every wrapper checks shapes/dtypes/contiguity on the host before launching (a kernel fault on this hardware can
+take the whole node down) and enqueues on torch's current HIP stream.
+"""
+import math
+
+import torch
+
+from ._lib import check, lib
+
+F32, BF16 = 0, 1
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+NORMAL, STRIDE2, UPSAMPLE2, TRANSPOSED2 = 0, 1, 2, 3
+
+
+def dt_code(dtype):
+    return _DT[dtype]
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if t.data_ptr() % 16:
+        raise ValueError(f"{name}: data pointer not 16-byte aligned")
+    return t
+
+
+def _f32(t, name):
+    return _chk(t, torch.float32, name)
+
+
+# ---- packing ---------------------------------------------------------------------------------------------
+def pack_conv_weight(w, w_fwd, w_dgrad):
+    _f32(w, "w")
+    cout, cin, k, _ = w.shape
+    ref = w_fwd if w_fwd is not None else w_dgrad
+    for t in (w_fwd, w_dgrad):
+        if t is not None:
+            _chk(t, ref.dtype, "pack")
+            assert t.numel() == w.numel()
+    check(lib.gmk_pack_conv_weight(_p(w), _p(w_fwd), _p(w_dgrad), cout, cin, k, _DT[ref.dtype], _s()), "pack_conv_weight")
+
+
+# ---- GroupNorm + SiLU ------------------------------------------------------------------------------------
+def gn_silu_fwd(x, gamma, beta, groups, eps=1e-5):
+    """x NHWC [B,H,W,C] -> (y, mean[B,G], rstd[B,G])"""
+    _chk(x, name="x"); _f32(gamma, "gamma"); _f32(beta, "beta")
+    B, H, W, C = x.shape
+    assert gamma.numel() == C and beta.numel() == C
+    y = torch.empty_like(x)
+    mean = torch.empty((B, groups), device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    check(lib.gmk_gn_silu_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), B, H * W, C, groups, eps,
+                              _DT[x.dtype], _s()), "gn_silu_fwd")
+    return y, mean, rstd
+
+
+def gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=None, dadd2=None, dxsum=None):
+    """-> (dx, dgamma_part[B,C], dbeta_part[B,C]); dxsum (optional fp32 [B, >=C] view with row stride) is filled."""
+    _chk(x, name="x"); _chk(dy, x.dtype, "dy")
+    assert dy.shape == x.shape
+    for t in (dadd1, dadd2):
+        if t is not None:
+            _chk(t, x.dtype, "dadd"); assert t.shape == x.shape
+    B, H, W, C = x.shape
+    G = mean.shape[1]
+    dx = torch.empty_like(x)
+    dgp = torch.empty((B, C), device=x.device, dtype=torch.float32)
+    dbp = torch.empty_like(dgp)
+    stride = 0
+    if dxsum is not None:
+        assert dxsum.dtype == torch.float32 and dxsum.shape == (B, C) and dxsum.stride(1) == 1
+        stride = dxsum.stride(0)
+    check(lib.gmk_gn_silu_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dadd1), _p(dadd2), _p(dx),
+                              _p(dgp), _p(dbp), _p(dxsum), stride, B, H * W, C, G, _DT[x.dtype], _s()), "gn_silu_bwd")
+    return dx, dgp, dbp
+
+
+def chansum(x, out=None):
+    _chk(x, name="x")
+    B, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((B, C), device=x.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.shape == (B, C) and out.stride(1) == 1
+    check(lib.gmk_chansum(_p(x), _p(out), out.stride(0), B, H * W, C, _DT[x.dtype], _s()), "chansum")
+    return out
+
+
+def colsum(part, out, accumulate=False):
+    """out[c] (+)= sum_r part[r, c]; part fp32 [R, C] with unit column stride, out fp32 [C] (any contiguous view)."""
+    assert part.dtype == torch.float32 and part.dim() == 2 and part.stride(1) == 1 and part.is_cuda
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == part.shape[1]
+    check(lib.gmk_colsum(_p(part), part.stride(0), _p(out), part.shape[0], part.shape[1], int(accumulate), _s()), "colsum")
+    return out
+
+
+def sumpool2x2(x):
+    _chk(x, name="x")
+    B, H2, W2, C = x.shape
+    assert H2 % 2 == 0 and W2 % 2 == 0
+    y = torch.empty((B, H2 // 2, W2 // 2, C), device=x.device, dtype=x.dtype)
+    check(lib.gmk_sumpool2x2(_p(x), _p(y), B, H2 // 2, W2 // 2, C, _DT[x.dtype], _s()), "sumpool2x2")
+    return y
+
+
+# ---- convolutions ----------------------------------------------------------------------------------------
+def out_size(mode, hs, ws):
+    if mode == NORMAL:
+        return hs, ws
+    if mode == STRIDE2:
+        return (hs - 1) // 2 + 1, (ws - 1) // 2 + 1
+    if mode == UPSAMPLE2:
+        return 2 * hs, 2 * ws
+    raise ValueError(mode)
+
+
+def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, emb=None, residual=None):
+    """srcs: list of 1-2 NHWC tensors (same B,H,W); w: packed weights [taps][w_rows][sum C]; -> out NHWC [B,ho,wo,cout]."""
+    s0 = _chk(srcs[0], name="src0")
+    s1 = _chk(srcs[1], s0.dtype, "src1") if len(srcs) > 1 else None
+    B, hs, ws, c0 = s0.shape
+    c1 = 0
+    if s1 is not None:
+        assert s1.shape[:3] == s0.shape[:3]
+        c1 = s1.shape[3]
+    _chk(w, s0.dtype, "w")
+    assert w.numel() == ksize * ksize * w_rows * (c0 + c1), (w.numel(), ksize, w_rows, c0, c1)
+    ho, wo = out_hw
+    out = torch.empty((B, ho, wo, cout), device=s0.device, dtype=s0.dtype)
+    emb_stride = 0
+    if emb is not None:
+        assert emb.dtype == torch.float32 and emb.shape == (B, cout) and emb.stride(1) == 1 and emb.data_ptr() % 16 == 0
+        emb_stride = emb.stride(0)
+        assert emb_stride % 4 == 0
+    if bias is not None:
+        _f32(bias, "bias"); assert bias.numel() == cout
+    if residual is not None:
+        _chk(residual, s0.dtype, "residual"); assert residual.shape == out.shape
+    check(lib.gmk_conv_igemm(_p(s0), _p(s1), c0, c1, B, hs, ws, ho, wo, ksize, mode, _p(w), w_rows, n0, cout, _p(bias),
+                             _p(emb), emb_stride, _p(residual), _p(out), cout, _DT[s0.dtype], _s()), "conv_igemm")
+    return out
+
+
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
+        _WS[key] = ws
+    return ws
+
+
+def conv_wgrad(dy, srcs, ksize, mode, dw):
+    """dw (fp32 [cout][sum C][k][k], a contiguous view into the gradient arena) = weight gradient."""
+    _chk(dy, name="dy")
+    s0 = _chk(srcs[0], dy.dtype, "src0")
+    s1 = _chk(srcs[1], dy.dtype, "src1") if len(srcs) > 1 else None
+    B, hs, ws_, c0 = s0.shape
+    c1 = s1.shape[3] if s1 is not None else 0
+    _, ho, wo, cout = dy.shape
+    assert dy.shape[0] == B
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * (c0 + c1) * ksize * ksize
+    need = lib.gmk_conv_wgrad_workspace_bytes(B * ho * wo, ksize * ksize, cout, c0 + c1)
+    assert need > 0
+    wsbuf = _workspace(need, dy.device)
+    check(lib.gmk_conv_wgrad(_p(dy), cout, _p(s0), _p(s1), c0, c1, B, hs, ws_, ho, wo, ksize, mode, _p(dw), cout,
+                             _p(wsbuf), wsbuf.numel(), _DT[dy.dtype], _s()), "conv_wgrad")
+    return dw
+
+
+def stem_fwd(x, w, bias, C, dtype):
+    _f32(x, "x"); _f32(w, "w"); _f32(bias, "bias")
+    B, cin, H, W = x.shape
+    assert w.shape == (C, cin, 3, 3)
+    y = torch.empty((B, H, W, C), device=x.device, dtype=dtype)
+    check(lib.gmk_stem_fwd(_p(x), _p(w), _p(bias), _p(y), B, cin, H, W, C, _DT[dtype], _s()), "stem_fwd")
+    return y
+
+
+def stem_wgrad(x, dy, dw):
+    _f32(x, "x"); _chk(dy, name="dy")
+    B, cin, H, W = x.shape
+    C = dy.shape[3]
+    nb = lib.gmk_stem_wgrad_blocks(B * H * W)
+    part = torch.empty((nb, C * cin * 9), device=x.device, dtype=torch.float32)
+    check(lib.gmk_stem_wgrad(_p(x), _p(dy), _p(part), B, cin, H, W, C, _DT[dy.dtype], _s()), "stem_wgrad")
+    return colsum(part, dw)
+
+
+def head_fwd(a, w, bias):
+    _chk(a, name="a"); _f32(w, "w"); _f32(bias, "bias")
+    B, H, W, C = a.shape
+    cout = w.shape[0]
+    assert w.shape == (cout, C, 3, 3)
+    out = torch.empty((B, cout, H, W), device=a.device, dtype=torch.float32)
+    check(lib.gmk_head_fwd(_p(a), _p(w), _p(bias), _p(out), B, cout, H, W, C, _DT[a.dtype], _s()), "head_fwd")
+    return out
+
+
+def head_dgrad(dout, w, dtype):
+    _f32(dout, "dout"); _f32(w, "w")
+    B, cout, H, W = dout.shape
+    C = w.shape[1]
+    da = torch.empty((B, H, W, C), device=dout.device, dtype=dtype)
+    check(lib.gmk_head_dgrad(_p(dout), _p(w), _p(da), B, cout, H, W, C, _DT[dtype], _s()), "head_dgrad")
+    return da
+
+
+def head_wgrad(dout, a, dwb):
+    """dwb: contiguous fp32 view of [weight (cout*C*9) | bias (cout)] in the gradient arena."""
+    _f32(dout, "dout"); _chk(a, name="a")
+    B, cout, H, W = dout.shape
+    C = a.shape[3]
+    n = cout * C * 9 + cout
+    assert dwb.numel() == n
+    nb = lib.gmk_head_wgrad_blocks(B * H * W)
+    part = torch.empty((nb, n), device=a.device, dtype=torch.float32)
+    check(lib.gmk_head_wgrad(_p(dout), _p(a), _p(part), B, cout, H, W, C, _DT[a.dtype], _s()), "head_wgrad")
+    return colsum(part, dwb)
+
+
+# ---- embedding path --------------------------------------------------------------------------------------
+def timestep_freqs(max_period, device):
+    """simple_unet.py:215-219 evaluated with the same torch fp32 ops (host), as a 32-entry table."""
+    half = 32
+    return torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(device)
+
+
+def timestep_embedding(t, freqs):
+    _f32(t, "t"); _f32(freqs, "freqs")
+    B = t.numel()
+    out = torch.empty((B, 64), device=t.device, dtype=torch.float32)
+    check(lib.gmk_timestep_embedding(_p(t), _p(freqs), _p(out), B, _s()), "timestep_embedding")
+    return out
+
+
+def guide_onehot(guide):
+    _chk(guide, torch.int64, "guide")
+    B = guide.numel()
+    onehot = torch.empty((B, 10), device=guide.device, dtype=torch.float32)
+    keep = torch.empty((B,), device=guide.device, dtype=torch.float32)
+    check(lib.gmk_guide_onehot(_p(guide), _p(onehot), _p(keep), B, _s()), "guide_onehot")
+    return onehot, keep
+
+
+def gemm(A, B, out=None, bias=None, rowscale=None, silu_a=False, silu_b=False, accumulate=False):
+    """out[M,N] (+)= rowscale * (bias + fa(A) @ fb(B)) for 2-D fp32 views A [M,K], B [K,N] with arbitrary strides."""
+    assert A.dtype == torch.float32 and B.dtype == torch.float32 and A.is_cuda and B.is_cuda
+    M, K = A.shape
+    K2, N = B.shape
+    assert K == K2
+    if out is None:
+        assert not accumulate
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    if rowscale is not None:
+        assert rowscale.dtype == torch.float32 and rowscale.numel() == M and rowscale.is_contiguous()
+    check(lib.gmk_gemm_f32(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(out), out.stride(0), M, N, K,
+                           _p(bias), _p(rowscale), int(silu_a) | (int(silu_b) << 1), int(accumulate), _s()), "gemm_f32")
+    return out
+
+
+def silu_bwd(dpost, pre, rowscale=None):
+    _f32(dpost, "dpost"); _f32(pre, "pre")
+    assert dpost.shape == pre.shape
+    out = torch.empty_like(pre)
+    check(lib.gmk_silu_bwd(_p(dpost), _p(pre), _p(rowscale), _p(out), pre.numel(), pre.shape[-1], _s()), "silu_bwd")
+    return out
+
+
+def scale_rows(x, rowscale):
+    _f32(x, "x"); _f32(rowscale, "rowscale")
+    out = torch.empty_like(x)
+    check(lib.gmk_scale_rows(_p(x), _p(rowscale), _p(out), x.numel(), x.shape[-1], _s()), "scale_rows")
+    return out
+
+
+# ---- diffusion algebra -----------------------------------------------------------------------------------
+def rng_normal(shape, seed, offset, device):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    check(lib.gmk_rng_normal(_p(out), out.numel(), seed, offset, _s()), "rng_normal")
+    return out
+
+
+def rng_uniform(shape, seed, offset, device):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    check(lib.gmk_rng_uniform(_p(out), out.numel(), seed, offset, _s()), "rng_uniform")
+    return out
+
+
+def q_sample(x, eps, u):
+    _f32(x, "x"); _f32(eps, "eps"); _f32(u, "u")
+    B = x.shape[0]
+    n = x.numel() // B
+    assert eps.shape == x.shape and u.numel() == B
+    logsnr = torch.empty((B,), device=x.device, dtype=torch.float32)
+    z = torch.empty_like(x)
+    check(lib.gmk_q_sample(_p(x), _p(eps), _p(u), _p(logsnr), _p(z), B, n, _s()), "q_sample")
+    return logsnr, z
+
+
+def v_loss(v, z, x, eps, logsnr, grad_scale=None):
+    """-> (loss_b, x_mse, eps_mse, dv or None)."""
+    for t, nm in ((v, "v"), (z, "z"), (x, "x"), (eps, "eps"), (logsnr, "logsnr")):
+        _f32(t, nm)
+    B = x.shape[0]
+    n = x.numel() // B
+    assert v.shape == x.shape == z.shape == eps.shape and logsnr.numel() == B
+    loss_b = torch.empty((B,), device=x.device, dtype=torch.float32)
+    xm = torch.empty_like(loss_b); em = torch.empty_like(loss_b)
+    dv = torch.empty_like(v) if grad_scale is not None else None
+    check(lib.gmk_v_loss(_p(v), _p(z), _p(x), _p(eps), _p(logsnr), _p(loss_b), _p(xm), _p(em), _p(dv),
+                         float(grad_scale or 0.0), B, n, _s()), "v_loss")
+    return loss_b, xm, em, dv
+
+
+def sampler_step(v, z, logsnr_t, logsnr_s, is_last, v_uncond=None, cond_w=None, noise=None, want_pred=False):
+    _f32(v, "v"); _f32(z, "z")
+    B = z.shape[0]
+    n = z.numel() // B
+    assert v.shape == z.shape
+    for t in (v_uncond, noise):
+        if t is not None:
+            _f32(t, "aux"); assert t.shape == z.shape
+    if cond_w is not None:
+        _f32(cond_w, "cond_w"); assert cond_w.numel() == B
+    z_next = torch.empty_like(z)
+    xp = torch.empty_like(z) if want_pred else None
+    ep = torch.empty_like(z) if want_pred else None
+    check(lib.gmk_sampler_step(_p(v), _p(v_uncond), _p(cond_w), _p(z), _p(noise), float(logsnr_t), float(logsnr_s),
+                               int(is_last), _p(z_next), _p(xp), _p(ep), B, n, _s()), "sampler_step")
+    return z_next, xp, ep
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _f32(t, nm)
+    assert p.numel() == g.numel() == m.numel() == v.numel()
+    check(lib.gmk_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _s()), "adam_step")

@@ -1,0 +1,151 @@
+/* gmk.h — C ABI of libgmk.so: MI355X (gfx950) kernels for the DDPM train + sample hot path.
+ *
+ * The reference (matwilso/generative_models) has no FFI: every arithmetic op of its diffusion path is a
+ * stock torch op.  Each entry point below names the reference call site(s) it replaces (paths relative to
+ * the reference checkout).  Conventions:
+ *   - returns 0 on success, GMK_ERR_ARG (<0) for an argument error, or a positive hipError_t;
+ *     gmk_last_error() returns a per-thread message.  No exceptions, no allocation, no synchronisation.
+ *   - every pointer is a BORROWED device pointer (e.g. torch `tensor.data_ptr()`), contiguous, 16-byte aligned;
+ *     workspaces are passed in by the caller; all work is enqueued on `stream` (a hipStream_t).
+ *   - re-entrant: callable from any host thread (autograd's backward thread, one process per GPU).
+ *   - activations inside the network are NHWC `[B][H][W][C]` in `dtype` (GMK_F32 or GMK_BF16), C a
+ *     multiple of 128; parameters, statistics, embeddings and everything in the diffusion algebra are fp32;
+ *     images at the model boundary are NCHW fp32 exactly as the reference passes them.
+ */
+#ifndef GMK_H
+#define GMK_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMK_F32 0
+#define GMK_BF16 1
+#define GMK_ERR_ARG (-1)
+
+/* gather modes of the implicit-GEMM convolution (how an output pixel + filter tap maps to a source pixel) */
+#define GMK_CONV_NORMAL 0      /* stride 1                      simple_unet.py:163,172,117 */
+#define GMK_CONV_STRIDE2 1     /* stride 2 (Downsample)         simple_unet.py:81,97,100   */
+#define GMK_CONV_UPSAMPLE2 2   /* nearest x2 folded into a stride-1 conv   simple_unet.py:120-121 */
+#define GMK_CONV_TRANSPOSED2 3 /* data-gradient of GMK_CONV_STRIDE2 (a transposed convolution) */
+
+int gmk_version(void);
+const char* gmk_last_error(void);
+/* number of bytes of scratch gmk_conv_wgrad needs for the given problem (split-K slabs) */
+int64_t gmk_conv_wgrad_workspace_bytes(int64_t n_pixels, int taps, int cout, int ktot);
+
+/* ---- parameter packing -------------------------------------------------------------------------------
+ * nn.Conv2d weight `[Cout][Cin][k][k]` fp32 (simple_unet.py:81,117,163,172,177) ->
+ *   w_fwd   `[tap][Cout][Cin]`  dtype  (K-contiguous rows for the forward implicit GEMM)
+ *   w_dgrad `[tap'][Cin][Cout]` dtype, tap' = spatially flipped tap (rows for the data-gradient GEMM)
+ * either output may be NULL. */
+int gmk_pack_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int cout, int cin, int ksize, int dtype,
+                         void* stream);
+
+/* ---- GroupNorm + SiLU (simple_unet.py:39-40,161-162,169-170; always adjacent in the reference) ---------
+ * x,y: NHWC [B][HW][C]; `groups` groups over these C channels (a 2C-channel concatenated input is handled as
+ * two calls of 16 groups each, simple_unet.py:150,161); mean/rstd: fp32 [B][groups] (written). */
+int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                    int B, int HW, int C, int groups, float eps, int dtype, void* stream);
+/* backward of the above.  dx = d/dx + dadd1 + dadd2 (optional NHWC addends, e.g. the identity-skip gradient).
+ * dgamma_part/dbeta_part: fp32 [B][C] per-sample partials (reduce with gmk_colsum); dxsum: optional fp32
+ * [B][dxsum_stride] per-sample channel sums of the final dx (bias / embedding gradients). */
+int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                    const float* rstd, const void* dadd1, const void* dadd2, void* dx, float* dgamma_part,
+                    float* dbeta_part, float* dxsum, int dxsum_stride, int B, int HW, int C, int groups,
+                    int dtype, void* stream);
+/* out[b][c] = sum over pixels of x[b][:, c]  (NHWC, fp32 result [B][out_stride]) */
+int gmk_chansum(const void* x, float* out, int out_stride, int B, int HW, int C, int dtype, void* stream);
+/* out[c] (+)= sum_r part[r*stride + c], r < R, c < C  (fp32) */
+int gmk_colsum(const float* part, int64_t stride, float* out, int R, int C, int accumulate, void* stream);
+/* 2x2 sum-pool NHWC [B][2H][2W][C] -> [B][H][W][C]: backward of F.interpolate(nearest, x2), simple_unet.py:120 */
+int gmk_sumpool2x2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+
+/* ---- 3x3 / 1x1 convolution, C_out = 128-wide tiles, MFMA implicit GEMM ---------------------------------
+ * out[b][oy][ox][n] = bias[n] + emb[b*emb_stride + n] + residual[b][oy][ox][n]
+ *                     + sum_{tap,k} srcK[b][sy][sx][k] * w[tap][n][k]
+ * src0/src1: NHWC sources of c0 / c1 channels (c1 = 0: one source) — the channel concatenation
+ * torch.cat([x, skip], 1) (simple_unet.py:150) is never materialised.  (hs, ws): source spatial size;
+ * (ho, wo): output spatial size; `mode` one of GMK_CONV_*.  w: packed rows `[tap][w_rows][c0+c1]` of
+ * `dtype`; output channels n0 .. n0+cout-1 use rows n0.. of each tap (cout % 128 == 0).  bias/emb/residual
+ * may be NULL.  Forward convolutions pass a w_fwd pack; data gradients pass a w_dgrad pack. */
+int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1, int B, int hs, int ws, int ho, int wo,
+                   int ksize, int mode, const void* w, int w_rows, int n0, int cout, const float* bias,
+                   const float* emb, int emb_stride, const void* residual, void* out, int out_cstride,
+                   int dtype, void* stream);
+/* weight gradient: dw[n][k][tap] (reference layout `[Cout][Cin][k][k]`, fp32, overwritten or accumulated) =
+ *   sum_pixels dy[b][oy][ox][n0_dy + n] * srcK[b][sy][sx][k],  same gather as the forward of `mode`.
+ * workspace: gmk_conv_wgrad_workspace_bytes(B*ho*wo, ksize*ksize, cout, c0+c1) bytes. */
+int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B,
+                   int hs, int ws, int ho, int wo, int ksize, int mode, float* dw, int cout, void* workspace,
+                   int64_t workspace_bytes, int dtype, void* stream);
+
+/* ---- stem / head convolutions (degenerate channel counts; simple_unet.py:92-94 and :41) ----------------
+ * stem: x NCHW fp32 [B][cin][H][W] (cin <= 4) -> y NHWC [B][H][W][C]; w [C][cin][3][3], bias [C] */
+int gmk_stem_fwd(const float* x, const float* w, const float* bias, void* y, int B, int cin, int H, int W, int C,
+                 int dtype, void* stream);
+/* dw_part: fp32 [nblk][C*cin*9] partials in the reference layout [C][cin][3][3], nblk = gmk_stem_wgrad_blocks(B*H*W);
+ * reduce over nblk with gmk_colsum */
+int gmk_stem_wgrad_blocks(int64_t n_pixels);
+int gmk_stem_wgrad(const float* x, const void* dy, float* dw_part, int B, int cin, int H, int W, int C, int dtype,
+                   void* stream);
+/* head: a NHWC [B][H][W][C] -> out NCHW fp32 [B][cout][H][W] (cout <= 4); w [cout][C][3][3], bias [cout] */
+int gmk_head_fwd(const void* a, const float* w, const float* bias, float* out, int B, int cout, int H, int W, int C,
+                 int dtype, void* stream);
+int gmk_head_dgrad(const float* dout, const float* w, void* da, int B, int cout, int H, int W, int C, int dtype,
+                   void* stream);
+/* dw_part: fp32 [nblk][cout*C*9 + cout]: weight partials in the reference layout [cout][C][3][3], then cout bias
+ * partials; nblk = gmk_head_wgrad_blocks(B*H*W); reduce over nblk with gmk_colsum */
+int gmk_head_wgrad_blocks(int64_t n_pixels);
+int gmk_head_wgrad(const float* dout, const void* a, float* dw_part, int B, int cout, int H, int W, int C, int dtype,
+                   void* stream);
+
+/* ---- embedding path (simple_unet.py:20-34,45-64,166,205-224), fp32 -------------------------------------- */
+/* out[b][0:32] = cos(t[b]*f_k), out[b][32:64] = sin(t[b]*f_k); freqs: fp32 [32] table computed by the host
+ * exactly as simple_unet.py:215-219 does */
+int gmk_timestep_embedding(const float* t, const float* freqs, float* out, int B, void* stream);
+/* onehot[b][0:10]: F.one_hot(guide with -1 -> 0) as fp32 (simple_unet.py:53-56); keep[b] = guide[b] != -1 */
+int gmk_guide_onehot(const int64_t* guide, float* onehot, float* keep, int B, void* stream);
+/* C[i][j] = (accumulate ? C[i][j] : 0) + rowscale[i] * (bias[j] + sum_k fa(A[i*sa0 + k*sa1]) * fb(B[k*sb0 + j*sb1]))
+ * fa / fb = SiLU when bit 0 / bit 1 of `silu` is set, else identity; bias / rowscale may be NULL (rowscale = the
+ * `guide != -1` row mask of simple_unet.py:57).  Small strided fp32 GEMM behind every nn.Linear forward/backward
+ * of the embedding path. */
+int gmk_gemm_f32(const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1, float* C,
+                 int64_t ldc, int M, int N, int K, const float* bias, const float* rowscale, int silu,
+                 int accumulate, void* stream);
+/* dpre[i] = dpost[i] * SiLU'(pre[i]) * (rowscale ? rowscale[i / ncols] : 1) */
+int gmk_silu_bwd(const float* dpost, const float* pre, const float* rowscale, float* dpre, int64_t n, int ncols,
+                 void* stream);
+/* out[i] = in[i] * rowscale[i / ncols] */
+int gmk_scale_rows(const float* in, const float* rowscale, float* out, int64_t n, int ncols, void* stream);
+
+/* ---- diffusion algebra (gaussian_diffusion.py, diffusion_utils.py), fp32, images as flat [B][n] ---------- */
+/* counter-based Philox4x32-10 streams: element i of stream (seed, offset) is reproducible anywhere */
+int gmk_rng_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+int gmk_rng_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* logsnr[b] = -2 log(tan(a u[b] + b)) (diffusion_utils.py:198-201); z = x sqrt(sigmoid(l)) + eps sqrt(sigmoid(-l))
+ * (gaussian_diffusion.py:95-100, diffusion_utils.py:65-73) */
+int gmk_q_sample(const float* x, const float* eps, const float* u, float* logsnr, float* z, int B, int64_t n,
+                 void* stream);
+/* gaussian_diffusion.py:61-77,165-169 and their backward in one pass over each sample:
+ * x_hat = clip(alpha z - sigma v); eps_hat = eps_from_x; loss_b = max(mean (x_hat-x)^2, mean (eps_hat-eps)^2);
+ * dv (optional) = d(grad_scale * sum_b loss_b)/dv.  loss_b/x_mse/eps_mse: fp32 [B]. */
+int gmk_v_loss(const float* v, const float* z, const float* x, const float* eps, const float* logsnr, float* loss_b,
+               float* x_mse, float* eps_mse, float* dv, float grad_scale, int B, int64_t n, void* stream);
+/* one reverse step on a batch (gaussian_diffusion.py:189-243,174-187,292):
+ *   v: conditional net output; v_uncond/cond_w: NULL or the unconditional output + per-sample guidance weight;
+ *   noise: NULL -> DDIM update, else ancestral ('noisy') update with that noise; is_last: the i == 0 select.
+ *   z_next is written; x_pred / eps_pred are optional outputs. */
+int gmk_sampler_step(const float* v, const float* v_uncond, const float* cond_w, const float* z, const float* noise,
+                     float logsnr_t, float logsnr_s, int is_last, float* z_next, float* x_pred, float* eps_pred,
+                     int B, int64_t n, void* stream);
+
+/* ---- optimiser (torch.optim.Adam defaults as diffusion_model.py:56 uses it), flat fp32 arena ------------- */
+int gmk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMK_H */

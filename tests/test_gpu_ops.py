@@ -1,0 +1,284 @@
+"""GPU parity tests, per kernel family: libgmk.so (through the C ABI) vs torch-CPU fp32 restatements of the same op
+(the reference's arithmetic is stock torch ops).  Tolerances: fp32 path 1e-3 of the output
+scale (north_star), bf16 path 1e-2 of the output scale with inputs pre-rounded to bf16; integer / index work
+(one-hot, masks, sampler select) bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from generative_models_amd import ops as o
+    return o
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).abs().max() / max(1e-6, float(b.abs().max())))
+
+
+def q(x, dtype):
+    """round a CPU fp32 tensor through `dtype`"""
+    return x.to(dtype).float()
+
+
+def nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+
+
+def nchw(y):
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,G,S", [(128, 32, 28), (128, 16, 14), (128, 32, 7), (256, 32, 8), (256, 16, 4)])
+def test_gn_silu_fwd_bwd(ops, dtype, C, G, S):
+    B = 3
+    x = q(rnd(B, C, S, S, seed=1) * 1.5 + 0.3, dtype).requires_grad_(True)
+    gamma = (1 + 0.1 * rnd(C, seed=2)).requires_grad_(True)
+    beta = (0.1 * rnd(C, seed=3)).requires_grad_(True)
+    y_ref = F.silu(F.group_norm(x, G, gamma, beta, 1e-5))
+    dy = q(rnd(B, C, S, S, seed=4), dtype)
+    add1 = q(rnd(B, C, S, S, seed=5), dtype)
+    y_ref.backward(dy)
+    xd = nhwc(x.detach(), dtype)
+    y, mean, rstd = ops.gn_silu_fwd(xd, gamma.detach().cuda(), beta.detach().cuda(), G)
+    assert rel_err(nchw(y), y_ref) < TOL[dtype]
+    m_ref = x.detach().reshape(B, G, -1).mean(-1)
+    assert rel_err(mean, m_ref) < 1e-4
+    dxsum = torch.zeros((B, C + 128), device="cuda")[:, 64:64 + C]
+    dx, dgp, dbp = ops.gn_silu_bwd(nhwc(dy, dtype), xd, gamma.detach().cuda(), beta.detach().cuda(), mean, rstd,
+                                   dadd1=nhwc(add1, dtype), dxsum=dxsum)
+    dx_ref = x.grad + add1
+    assert rel_err(nchw(dx), dx_ref) < TOL[dtype]
+    assert rel_err(dgp.sum(0), gamma.grad) < TOL[dtype]
+    assert rel_err(dbp.sum(0), beta.grad) < TOL[dtype]
+    assert rel_err(dxsum, nchw(dx).sum((2, 3))) < 1e-3
+    # helpers
+    out = torch.empty(C, device="cuda")
+    ops.colsum(dgp, out)
+    assert rel_err(out, dgp.sum(0)) < 1e-5
+    assert rel_err(ops.chansum(xd), nchw(xd).sum((2, 3))) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sumpool(ops, dtype):
+    x = q(rnd(2, 128, 8, 12, seed=7), dtype)
+    y = ops.sumpool2x2(nhwc(x, dtype))
+    ref = F.avg_pool2d(x, 2) * 4
+    assert rel_err(nchw(y), ref) < TOL[dtype]
+
+
+def conv_ref(mode, srcs, w, bias):
+    x = torch.cat(srcs, 1)
+    if mode == 0:
+        return F.conv2d(x, w, bias, padding=w.shape[-1] // 2)
+    if mode == 1:
+        return F.conv2d(x, w, bias, stride=2, padding=1)
+    if mode == 2:
+        return F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, bias, padding=1)
+    raise ValueError
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode,two,ks,S,B", [(0, False, 3, 28, 2), (0, True, 3, 14, 3), (0, True, 1, 7, 5), (1, False, 3, 28, 2),
+                                             (1, False, 3, 14, 3), (2, False, 3, 7, 3), (2, False, 3, 14, 2),
+                                             (0, False, 3, 7, 1), (0, False, 3, 8, 37)])
+def test_conv_fwd_dgrad_wgrad(ops, dtype, mode, two, ks, S, B):
+    C = 128
+    cin = 2 * C if two else C
+    srcs = [q(rnd(B, C, S, S, seed=10 + i), dtype).requires_grad_(True) for i in range(2 if two else 1)]
+    w = q(rnd(C, cin, ks, ks, seed=20) / math.sqrt(cin * ks * ks), dtype).requires_grad_(True)
+    bias = 0.1 * rnd(C, seed=21)
+    out_ref = conv_ref(mode, srcs, w, bias)
+    ho, wo = out_ref.shape[2:]
+    emb = rnd(B, C, seed=22)
+    res = q(rnd(B, C, ho, wo, seed=23), dtype)
+    full_ref = out_ref + emb[:, :, None, None] + res
+    T = dtype
+    wf = torch.empty(w.numel(), device="cuda", dtype=T)
+    wd = torch.empty(w.numel(), device="cuda", dtype=T)
+    ops.pack_conv_weight(w.detach().cuda(), wf, wd)
+    sd = [nhwc(s.detach(), T) for s in srcs]
+    embd = torch.zeros((B, 3 * C), device="cuda")
+    embd[:, C:2 * C] = emb.cuda()
+    out = ops.conv_igemm(sd, wf, C, ks, mode, (ho, wo), bias=bias.cuda(), emb=embd[:, C:2 * C], residual=nhwc(res, T))
+    assert rel_err(nchw(out), full_ref) < TOL[dtype], "forward"
+    # backward
+    dy = q(rnd(B, C, ho, wo, seed=30), dtype)
+    out_ref.backward(dy)
+    dyd = nhwc(dy, T)
+    # data gradient
+    for i, s in enumerate(srcs):
+        if mode == 0:
+            dx = ops.conv_igemm([dyd], wd, cin, ks, 0, (S, S), n0=i * C)
+        elif mode == 1:
+            dx = ops.conv_igemm([dyd], wd, cin, ks, 3, (S, S), n0=i * C)
+        else:
+            dx = ops.sumpool2x2(ops.conv_igemm([dyd], wd, cin, ks, 0, (2 * S, 2 * S), n0=i * C))
+        tol = TOL[dtype] * (2 if (mode == 2 and dtype == torch.bfloat16) else 1)   # one extra bf16 rounding before the pool
+        assert rel_err(nchw(dx), s.grad) < tol, f"dgrad src{i}"
+    # weight gradient
+    dw = torch.empty_like(w.detach()).cuda()
+    ops.conv_wgrad(dyd, sd, ks, mode, dw)
+    assert rel_err(dw, w.grad) < TOL[dtype], "wgrad"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cs,S,B", [(1, 28, 3), (3, 16, 2)])
+def test_stem_head(ops, dtype, cs, S, B):
+    C = 128
+    x = rnd(B, cs, S, S, seed=40).clamp(-1, 1)
+    w = (rnd(C, cs, 3, 3, seed=41) / 3).requires_grad_(True)
+    b = 0.1 * rnd(C, seed=42)
+    y_ref = F.conv2d(x, w, b, padding=1)
+    y = ops.stem_fwd(x.cuda(), w.detach().cuda(), b.cuda(), C, dtype)
+    assert rel_err(nchw(y), y_ref) < TOL[dtype]
+    dy = q(rnd(B, C, S, S, seed=43), dtype)
+    y_ref.backward(dy)
+    dw = torch.empty_like(w.detach()).cuda()
+    ops.stem_wgrad(x.cuda(), nhwc(dy, dtype), dw)
+    assert rel_err(dw, w.grad) < TOL[dtype]
+    # head
+    a = q(rnd(B, C, S, S, seed=44), dtype).requires_grad_(True)
+    wh = (rnd(cs, C, 3, 3, seed=45) / math.sqrt(9 * C)).requires_grad_(True)
+    bh = (0.1 * rnd(cs, seed=46)).requires_grad_(True)
+    o_ref = F.conv2d(a, wh, bh, padding=1)
+    o = ops.head_fwd(nhwc(a.detach(), dtype), wh.detach().cuda(), bh.detach().cuda())
+    assert rel_err(o, o_ref) < TOL[dtype]
+    do = rnd(B, cs, S, S, seed=47)
+    o_ref.backward(do)
+    da = ops.head_dgrad(do.cuda(), wh.detach().cuda(), dtype)
+    assert rel_err(nchw(da), a.grad) < TOL[dtype]
+    dwb = torch.empty(cs * C * 9 + cs, device="cuda")
+    ops.head_wgrad(do.cuda(), nhwc(a.detach(), dtype), dwb)
+    assert rel_err(dwb[:cs * C * 9].view_as(wh), wh.grad) < TOL[dtype]
+    assert rel_err(dwb[cs * C * 9:], bh.grad) < 1e-3
+
+
+def test_embedding_path(ops, golden):
+    g = golden("schedule.npz")
+    t = torch.from_numpy(g["temb_t"]).cuda()
+    te = ops.timestep_embedding(t, ops.timestep_freqs(256, "cuda"))
+    assert rel_err(te, torch.from_numpy(g["temb_256"])) < 1e-5
+    w = torch.from_numpy(g["temb_w"]).cuda()
+    assert rel_err(ops.timestep_embedding(w, ops.timestep_freqs(4, "cuda")), torch.from_numpy(g["temb_4"])) < 1e-5
+    # integer label path is bit-exact (row I2)
+    guide = torch.tensor([3, -1, 0, 9, -1, 5], device="cuda")
+    oh, keep = ops.guide_onehot(guide)
+    gg = guide.cpu().clone(); mask = gg == -1; gg[mask] = 0
+    assert torch.equal(oh.cpu(), F.one_hot(gg, 10).float())
+    assert torch.equal(keep.cpu(), (~mask).float())
+    # strided GEMM in all three layouts + fused SiLU / bias / row mask / accumulate
+    A, Bm = rnd(37, 70, seed=50), rnd(70, 45, seed=51)
+    bias, rs = rnd(45, seed=52), (rnd(37, seed=53) > 0).float()
+    ref = rs[:, None] * (F.silu(A) @ Bm + bias)
+    out = ops.gemm(A.cuda(), Bm.cuda(), bias=bias.cuda(), rowscale=rs.cuda(), silu_a=True)
+    assert rel_err(out, ref) < 1e-5
+    out2 = ops.gemm(A.t().contiguous().cuda().t(), Bm.t().contiguous().cuda().t(), out=out.clone(), accumulate=True)
+    assert rel_err(out2, ref + A @ Bm) < 1e-5
+    out3 = ops.gemm(A.cuda().t(), A.cuda(), silu_b=True)
+    assert rel_err(out3, A.t() @ F.silu(A)) < 1e-5
+    pre = rnd(9, 33, seed=54).requires_grad_(True)
+    d = rnd(9, 33, seed=55)
+    F.silu(pre).backward(d)
+    assert rel_err(ops.silu_bwd(d.cuda(), pre.detach().cuda()), pre.grad) < 1e-5
+
+
+def test_q_sample_and_loss(ops):
+    from oracle import diffusion_ref as D
+    B, n = 5, 784
+    x = rnd(B, 1, 28, 28, seed=60).clamp(-1, 1)
+    x[:, :, :7] = -1.0
+    eps = rnd(B, 1, 28, 28, seed=61)
+    u = torch.tensor([0.0, 0.03, 0.4, 0.77, 0.999])
+    logsnr, z = ops.q_sample(x.cuda(), eps.cuda(), u.cuda())
+    l_ref = D.logsnr_schedule_cosine(u)
+    assert rel_err(logsnr, l_ref) < 1e-5
+    assert rel_err(z, D.q_sample(x, l_ref, eps)) < 1e-5
+    v = rnd(B, 1, 28, 28, seed=62).requires_grad_(True)
+    out = D.model_outputs(v, z.cpu(), logsnr.cpu())
+    x_mse = (out["model_x"] - x).square().flatten(1).mean(1)
+    e_mse = (out["model_eps"] - eps).square().flatten(1).mean(1)
+    loss = torch.maximum(x_mse, e_mse)
+    (loss.sum() * 0.25).backward()
+    lb, xm, em, dv = ops.v_loss(v.detach().cuda(), z, x.cuda(), eps.cuda(), logsnr, grad_scale=0.25)
+    assert rel_err(lb, loss) < 1e-4 and rel_err(xm, x_mse) < 1e-4 and rel_err(em, e_mse) < 1e-4
+    assert rel_err(dv, v.grad) < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["ddim", "cfg", "noisy"])
+def test_sampler_step(ops, mode):
+    from oracle import diffusion_ref as D
+    B = 4
+    z = rnd(B, 1, 12, 12, seed=70)
+    v = rnd(B, 1, 12, 12, seed=71)
+    vu = rnd(B, 1, 12, 12, seed=72)
+    w = torch.tensor([0.0, 0.5, 2.0, 3.9])
+    noise = rnd(B, 1, 12, 12, seed=73)
+    for (i, T) in [(7, 8), (3, 8), (0, 8), (199, 200)]:
+        u_t, u_s = D.sampler_times(i, T)
+        lt = D.logsnr_schedule_cosine(torch.tensor(u_t)); ls = D.logsnr_schedule_cosine(torch.tensor(u_s))
+        ltv = lt.expand(B)
+        o = D.model_outputs(v, z, ltv)
+        xp, ep = o["model_x"], o["model_eps"]
+        if mode == "cfg":
+            ou = D.model_outputs(vu, z, ltv)
+            ww = D.bcast(w, z.shape)
+            e = (1 + ww) * ep + (-ww) * ou["model_eps"]
+            xp = torch.clip(D.predict_x_from_eps(z, e, ltv), -1, 1)
+            ep = D.predict_eps_from_x(z, xp, ltv)
+        if mode == "noisy":
+            alpha_st = torch.sqrt((1 + torch.exp(-lt)) / (1 + torch.exp(-ls)))
+            r = torch.exp(lt - ls); omr = -torch.expm1(lt - ls)
+            zs = r * alpha_st * z + omr * torch.sqrt(torch.sigmoid(ls)) * xp + torch.sqrt(omr * torch.sigmoid(-lt)) * noise
+        else:
+            zs = torch.sqrt(torch.sigmoid(ls)) * xp + torch.sqrt(torch.sigmoid(-ls)) * ep
+        z_ref = xp if i == 0 else zs
+        zn, xo, eo = ops.sampler_step(v.cuda(), z.cuda(), float(lt), float(ls), i == 0,
+                                      v_uncond=vu.cuda() if mode == "cfg" else None,
+                                      cond_w=w.cuda() if mode == "cfg" else None,
+                                      noise=noise.cuda() if mode == "noisy" else None, want_pred=True)
+        scale = 1e-4 if float(lt) > -15 else 2e-3     # c1 = sqrt(1+e^l) amplifies rounding at the noisiest steps
+        assert rel_err(xo, xp) < 1e-4 and rel_err(eo, ep) < scale and rel_err(zn, z_ref) < scale
+        if i == 0:
+            assert torch.equal(zn, xo)      # the i == 0 select is exact (row I1)
+
+
+def test_rng_and_adam(ops):
+    from oracle import diffusion_ref as D
+    n = 1 << 20
+    a = ops.rng_normal((n,), 1234, 0, "cuda")
+    b = ops.rng_normal((n,), 1234, 0, "cuda")
+    assert torch.equal(a, b)
+    c = ops.rng_normal((n,), 1234, n // 4, "cuda")
+    assert not torch.equal(a, c)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
+    assert abs(float((a ** 4).mean()) - 3) < 0.1
+    u = ops.rng_uniform((n,), 99, 0, "cuda")
+    assert float(u.min()) >= 0 and float(u.max()) < 1 and abs(float(u.mean()) - 0.5) < 2e-3
+    # Adam vs torch.optim.Adam, 3 steps, odd length (tail path)
+    p0 = rnd(1003, seed=80); p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=3e-4)
+    pd = p0.clone().cuda(); m = torch.zeros_like(pd); v = torch.zeros_like(pd)
+    for step in range(1, 4):
+        g = rnd(1003, seed=80 + step) * 0.01
+        p.grad = g.clone(); opt.step()
+        ops.adam_step(pd, (g * 8).cuda(), m, v, 3e-4, 0.9, 0.999, 1e-8, step, grad_scale=0.125)
+        assert float((pd.cpu() - p.detach()).abs().max()) < 1e-6 * step + 1e-7

@@ -1,0 +1,189 @@
+"""CPU tests (no GPU): host logic of the plugin surface, the C-ABI library's exports, arena / bucket layout,
+the multi-rank gradient exchange over gloo, and the rule that the product never touches the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_args_type_truth_table():
+    """Restates gms/common.py:85-92."""
+    from generative_models_amd.common import args_type
+    assert args_type(True)("True") is True and args_type(False)("False") is False
+    with pytest.raises(ValueError):
+        args_type(True)("1")
+    assert args_type(5)("7") == 7 and isinstance(args_type(5)("7"), int)
+    assert args_type(5)("1e3") == 1000.0 and isinstance(args_type(5)("1e3"), float)
+    assert args_type(5)("2.5") == 2.5
+    assert args_type(Path("."))("~/x") == Path("~/x").expanduser()
+    assert args_type(3e-4) is float and args_type("abc") is str
+
+
+def test_registry_keys():
+    """gms/common.py:33-35,38-55: snake-cased class name; `diffusion` alias (run_all.sh:16)."""
+    from generative_models_amd import common
+    assert common.convert_camel_to_snake("DiffusionModel") == "diffusion_model"
+    assert common.convert_camel_to_snake("VQVAE") == "vqvae"
+    assert common.convert_camel_to_snake("PixelCNN") == "pixel_cnn"
+    models = common.discover_models()
+    assert set(models) == {"diffusion_model", "diffusion"}
+    M = models["diffusion_model"]
+    assert issubclass(M, common.GM)
+    ref_defaults = dict(binarize=0, timesteps=250, hidden_size=128, dropout=0.0, sampler="ddim", mean_type="v",
+                        eval_heavy=1, class_cond=1, sample_cond_w=-1.0, cf_drop_prob=0.1, teacher_path=Path("."),
+                        teacher_mode="step1", lr_scheduler="none")          # diffusion_model.py:15-29
+    for k, v in ref_defaults.items():
+        assert M.DG[k] == v, k
+
+
+def test_make_plugin_on_foreign_base():
+    """the same class can be built on the reference's own GM base."""
+    from torch import nn
+    from generative_models_amd.diffusion.diffusion_model import make_plugin
+
+    class ForeignGM(nn.Module):
+        def __init__(self, G):
+            super().__init__()
+            self.G = G
+
+    class AD(dict):
+        __setattr__ = dict.__setitem__
+        __getattr__ = dict.__getitem__
+
+    cls = make_plugin(ForeignGM, AD)
+    assert issubclass(cls, ForeignGM) and cls.__name__ == "DiffusionModel" and cls.DG.timesteps == 250
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    from generative_models_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 29
+    dll = ctypes.CDLL(_lib.LIBPATH)
+    for name in protos:
+        assert hasattr(dll, name), name
+    assert dll.gmk_version() == 1
+    # argument errors are reported without touching a GPU
+    rc = dll.gmk_colsum(None, ctypes.c_int64(4), None, 1, 1, 0, None)
+    assert rc == -1
+    _lib.lib.gmk_last_error.restype = ctypes.c_char_p
+    assert b"gmk_colsum" in _lib.lib.gmk_last_error()
+    assert _lib.lib.gmk_conv_wgrad_workspace_bytes(1024 * 784, 9, 128, 128) > 0
+    assert _lib.lib.gmk_conv_wgrad_workspace_bytes(64, 9, 128, 100) == -1
+
+
+def test_header_cites_reference_for_every_entry_point():
+    text = open(os.path.join(ROOT, "include", "gmk.h")).read()
+    assert text.count(".py:") >= 15
+
+
+def test_param_inventory_and_arena():
+    from generative_models_amd.diffusion.simple_unet import SimpleUnet, param_inventory
+    inv = param_inventory(128)
+    assert len(inv) == 160 and sum(int(np.prod(s)) for _, s in inv) == 6033665
+    net = SimpleUnet(128)
+    assert [k for k, _ in net.state_dict().items()] == [n for n, _ in inv]
+    # zero-initialised out_layers.3 (simple_unet.py:172), GroupNorm affine 1/0
+    assert float(net.param("turn.out_layers.3.weight").abs().max()) == 0.0
+    assert float(net.param("out.0.weight").min()) == 1.0 and float(net.param("out.0.bias").abs().max()) == 0.0
+    b = net.grad_buckets()
+    assert sorted(b)[0][0] == 0 and sorted(b)[-1][1] == net.flat_params.numel()
+    assert sum(e - s for s, e in b) == net.flat_params.numel()
+    for name, _ in inv:                       # 16-byte alignment of every tensor in the arena
+        assert net._offsets[name] % 4 == 0
+    # parameters and grads are views of the arenas, and survive load_state_dict
+    sd = {k: torch.full_like(v, 0.5) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    assert float(net.flat_params[net._offsets["turn.in_layers.2.weight"]]) == 0.5 and net._packs_stale
+    with pytest.raises(ValueError):
+        SimpleUnet(32)
+    net3 = SimpleUnet(128, in_channels=3)
+    assert sum(p.numel() for p in net3.parameters()) == 6038275
+
+
+def test_cpu_use_fails_loudly():
+    from generative_models_amd.diffusion.simple_unet import SimpleUnet
+    net = SimpleUnet(128)
+    with pytest.raises((RuntimeError, ValueError)):
+        net.forward_hip(torch.zeros(1, 1, 8, 8), torch.zeros(1))
+
+
+def test_sampler_index_arithmetic_bit_exact(golden):
+    from generative_models_amd.diffusion.gaussian_diffusion import logsnr_schedule_cosine_host, sampler_times
+    g = golden("schedule.npz")
+    for steps in (4, 8, 200, 250, 1000):
+        ut = np.array([sampler_times(i, steps)[0] for i in range(steps)], np.float32)
+        us = np.array([sampler_times(i, steps)[1] for i in range(steps)], np.float32)
+        assert ut.tobytes() == g[f"T{steps}_u_t"].tobytes() and us.tobytes() == g[f"T{steps}_u_s"].tobytes()
+        lt = np.array([logsnr_schedule_cosine_host(u) for u in ut], np.float32)
+        ref = g[f"T{steps}_logsnr_t"]
+        assert np.all(np.abs(lt - ref) <= 2e-6 * np.maximum(1.0, np.abs(ref)))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = Path(ROOT) / "generative_models_amd"
+    for f in pkg.rglob("*.py"):
+        text = f.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+        assert "/root/reference" not in text, f
+    for f in (pkg / "csrc").glob("*"):
+        if f.suffix in (".hip", ".h", ".cpp"):
+            assert "oracle" not in f.read_text()
+
+
+def test_synthetic_data_source():
+    from generative_models_amd.main import SyntheticMNIST
+    ds = SyntheticMNIST(4, 2, pad32=1, binarize=0, device="cpu", seed=0)
+    batches = list(ds)
+    assert len(batches) == 2
+    x, y = batches[0]
+    assert x.shape == (4, 1, 32, 32) and x.dtype == torch.float32 and y.dtype == torch.int64
+    assert float(x.min()) >= -1 and float(x.max()) <= 1 and float(x[:, :, :2].abs().max()) == 0.0   # pad32 pads with 0
+    assert int(y.min()) >= 0 and int(y.max()) <= 9
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from generative_models_amd import parallel
+from generative_models_amd.diffusion.simple_unet import SimpleUnet
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(r)
+net = SimpleUnet(128)                        # CPU arena; only the exchange is exercised here
+sync = parallel.GradSync(net)
+sync.broadcast_params(0)
+ref = [torch.zeros(1) for _ in range(w)]
+dist.all_gather(ref, net.flat_params[123456:123457])
+assert all(float(t) == float(ref[0]) for t in ref)
+g_local = torch.arange(net.flat_grads.numel(), dtype=torch.float32) * (r + 1) * 1e-6
+net.flat_grads.copy_(g_local)
+for k in range(4):
+    sync.hook(k)
+sync.finish()
+expect = torch.arange(net.flat_grads.numel(), dtype=torch.float32) * 1e-6 * sum(range(1, w + 1))
+assert torch.allclose(net.flat_grads, expect, rtol=1e-6, atol=0), float((net.flat_grads - expect).abs().max())
+x = torch.arange(8.0)
+assert parallel.shard_batch(x).tolist() == x[r * 8 // w:(r + 1) * 8 // w].tolist()
+dist.destroy_process_group()
+print("rank", r, "ok")
+"""
+
+
+def test_gradient_exchange_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29531", str(script), ROOT]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2
