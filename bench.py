@@ -1,0 +1,212 @@
+"""Benchmark of the DDPM hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W            (one rank per GPU, RCCL)
+
+A "step" is one full training step of `DiffusionModel.train_step` (label drop, q_sample, U-Net forward, loss,
+backward, bucketed gradient all-reduce, fused Adam) on one batch of synthetic MNIST-shaped images that is already
+resident in HBM.  Workload = BASELINE.json configs[1]: 1x28x28, C=128, per-GPU batch 1024, bf16 compute with fp32
+master weights (weak scaling: the per-GPU batch is fixed).  Rank 0 prints ONE JSON line:
+  value            whole-job train images/s (all ranks), max-over-ranks wall time around exactly K steps
+  sampler          reverse-diffusion steps/s (DDIM, guidance off, batch 1024/GPU), timed separately
+  roofline         dominant kernel = the MFMA implicit-GEMM convolution (forward + data-gradient launches):
+                   algorithmic FLOPs of every launch in the timed region / their HIP-event durations, vs the dense
+                   bf16 MFMA peak
+  cpu_baseline     the oracle (CPU restatement) timed on the host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=28)
+    ap.add_argument("--in_channels", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--sampler_steps", type=int, default=20)
+    ap.add_argument("--cpu_seconds", type=float, default=15.0)
+    ap.add_argument("--no_cpu", action="store_true")
+    ap.add_argument("--no_profile", action="store_true", help="skip the per-launch HIP events")
+    return ap.parse_args()
+
+
+def synthetic_batch(B, C, S, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    raw = torch.rand((B, C, S, S), generator=g) * 2 - 1
+    ink = torch.rand((B, C, S, S), generator=g) < 0.15
+    x = torch.where(ink, raw, -torch.ones_like(raw))       # MNIST-like: 85 % of pixels exactly -1
+    y = torch.randint(0, 10, (B,), generator=g)
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(seconds, S, in_channels):
+    """Oracle train step (forward + autograd backward + Adam restatement) on the host cores, cfg1 shape B=32."""
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as U
+    # the threads this process may actually run on (a GPU box gives one GPU's share of the host, 16 cores)
+    ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("GMK_CPU_THREADS", "16")))
+    torch.set_num_threads(max(1, ncores))
+    B = 32
+    params = {k: v.requires_grad_(True) for k, v in U.reference_init_params(128, in_channels).items()}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in params.items()}
+    x, y = synthetic_batch(B, in_channels, S, "cpu", 7)
+    g = torch.Generator().manual_seed(3)
+    n, t_total, step = 0, 0.0, 0
+    while True:
+        u = torch.rand((B,), generator=g); eps = torch.randn(x.shape, generator=g)
+        t0 = time.perf_counter()
+        loss = D.training_losses(params, x, y, u, eps)["loss"].mean()
+        grads = torch.autograd.grad(loss, [p for k, p in params.items() if not k.startswith("cond_w_embed")])
+        step += 1
+        with torch.no_grad():
+            for (k, p), gr in zip([(k, p) for k, p in params.items() if not k.startswith("cond_w_embed")], grads):
+                pn, m[k], v2[k] = D.adam_step(p, gr, m[k], v2[k], step)
+                p.copy_(pn)
+        dt = time.perf_counter() - t0
+        if step > 1:                      # first iteration is the warm-up
+            n += 1; t_total += dt
+        if t_total >= seconds or step >= 200 or (step == 1 and dt > seconds):
+            if n == 0:
+                n, t_total = 1, dt
+            break
+    return {"value": round(B * n / t_total, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (torch-CPU restatement) train step, B=32, {in_channels}x{S}x{S}, C=128, fp32, "
+                      f"{n} steps in {t_total:.1f} s after 1 warm-up"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from generative_models_amd import common, ops, parallel
+    Model = common.discover_models()["diffusion"]
+    G = common.AttrDict(dict(Model.DG))
+    G.update(lr=3e-4, pad32=0, device=str(dev), timesteps=1000, bs=a.batch, compute_dtype=a.dtype,
+             in_channels=a.in_channels, seed=0)
+    model = Model(G).to(dev)
+    model.size = a.size
+    if world > 1:
+        parallel.GradSync(model.net).broadcast_params(0)
+    x, y = synthetic_batch(a.batch, a.in_channels, a.size, dev, 1000 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    model.train()
+    for _ in range(a.warmup):
+        model.train_step(x, y.clone())
+    barrier()
+    prof = None if a.no_profile else []
+    ops.PROFILE = prof
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        model.train_step(x, y.clone())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.PROFILE = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    images_per_s = world * a.batch * a.steps / elapsed
+
+    # ---- roofline of the dominant kernel from the per-launch HIP events of the timed region (rank 0)
+    roofline = None
+    if prof:
+        torch.cuda.synchronize()
+        peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        by = {}
+        for name, s, e, f in prof:
+            d = by.setdefault(name, [0.0, 0.0, 0])
+            d[0] += s.elapsed_time(e); d[1] += f; d[2] += 1
+        ms, fl, n = by["conv_igemm"]
+        ach = fl / (ms * 1e-3) / 1e12
+        roofline = {"kernel": "conv_igemm_kernel (3x3/1x1 implicit GEMM, forward + data-gradient launches)",
+                    "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "launches_per_step": n // a.steps, "avg_launch_us": round(ms * 1e3 / n, 2),
+                    "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
+        if "conv_wgrad" in by:
+            ms2, fl2, n2 = by["conv_wgrad"]
+            roofline["wgrad"] = {"achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2), "avg_launch_us": round(ms2 * 1e3 / n2, 2),
+                                 "launches_per_step": n2 // a.steps, "share_of_step_time": round(ms2 * 1e-3 / elapsed, 3),
+                                 "note": "split-K kernel + slab reduce"}
+
+    # ---- reverse-diffusion steps/s: DDIM, guidance off (the `evaluate` path), trajectories not recorded
+    from functools import partial
+    model.eval()
+    model.diffusion.num_steps = a.sampler_steps
+    init = model._aux_rng.normal((a.batch, a.in_channels, a.size, a.size), dev)
+    model.diffusion.sample(net=partial(model.net, guide=y), init_x=init, record=False)     # warm-up
+    barrier()
+    t0 = time.perf_counter()
+    model.diffusion.sample(net=partial(model.net, guide=y), init_x=init, record=False)
+    barrier()
+    ts = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([ts], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ts = float(t)
+    sampler = {"steps_per_sec": round(a.sampler_steps / ts, 2),
+               "image_steps_per_sec": round(world * a.batch * a.sampler_steps / ts, 1),
+               "batch_per_gpu": a.batch, "mode": "ddim, guidance off, 1 U-Net forward per step",
+               "timed_steps": a.sampler_steps}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu:
+        cpu = cpu_baseline(a.cpu_seconds, a.size, a.in_channels)
+
+    if rank == 0:
+        fwd_gflop = {(1, 28): 4.3913, (3, 32): 5.7447, (3, 64): 22.9754}.get((a.in_channels, a.size))
+        line = {
+            "metric": "ddpm_train_images_per_sec", "value": round(images_per_s, 1), "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"DDPM train step, MNIST-shape {a.in_channels}x{a.size}x{a.size}, SimpleUnet C=128, "
+                                   f"per-GPU batch {a.batch}, T=1000 (BASELINE.json configs[1])",
+                       "global_batch": world * a.batch, "parallelism": f"dp{world}",
+                       "optimizer": "fused Adam lr=3e-4", "mean_type": "v"},
+            "sampler": sampler,
+        }
+        if fwd_gflop:
+            line["model_tflops"] = round(3 * fwd_gflop * images_per_s / 1e3, 2)   # 3x forward FLOPs per train image
+        if roofline:
+            line["roofline"] = roofline
+        if cpu:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

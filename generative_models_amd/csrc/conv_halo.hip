@@ -1,0 +1,344 @@
+// 3x3 stride-1 convolution with an LDS-resident input halo — the kernel the train step is dominated by
+// (24 ResBlock convolutions forward + their data gradients; reference gms/diffusion/simple_unet.py:163,172).
+//
+// Why: the im2col-style kernels (conv_igemm.hip) re-fetch every input pixel 9 times (once per tap) through the
+// vector-memory -> LDS path, which tops out near 32 B/clk/CU and bounds them at ~900 TFLOP/s.  Here each input pixel
+// enters LDS once per tile: a tile is R whole image rows (R*W <= 256 output pixels, rows taken from the global row
+// list b*H + y so tiles may span images), and its input rows plus a zero/neighbour halo live in LDS as "slots" of
+// 64 channels (128 B).  The 9 taps are 9 different constant slot offsets of the same LDS image, so the MFMA pixel
+// operand is read straight from the halo with per-lane addresses; only the weight tiles (16 KB per K-step) stream.
+//
+// LDS map (160 KiB, one workgroup per CU, 8 waves):
+//   2 x 448 slots x 128 B   halo half-buffers: channels [64*kh, 64*kh+64) of one source; while buffer hb is
+//                           consumed (9 taps = 9 K-steps) the next 64-channel half streams into hb^1
+//   3 x 16 KiB              ring of weight tiles [128 channels][64 k], two K-steps ahead
+// Slot s of a tile = ext-row * (W+2) + x + 1, ext rows = the tile's rows with a pad row above/below every image
+// segment; with E = ext-row + y0 (y0 = first row's position in its image) the layout is (H+2)-periodic:
+// image k = E / (H+2), y = E % (H+2) - 1.  Pad rows / columns and rows of non-existent images read a zero through the
+// buffer descriptor's range check.  Swizzle: physical chunk c of slot s holds logical chunk c ^ ((s>>1)&7) (applied
+// to the DMA source address and to the fragment reads), which keeps ds_read_b128 conflict-free for runs of pixels.
+//
+// Schedule: K-step q = (phase, tap); each step every wave issues the 2 DMA instructions of weight tile q+2 and, for
+// taps 0..6, one 1-KiB piece (8 slots) of the next phase's halo.  The counts are static, so `s_waitcnt vmcnt(N)`
+// (N = ops issued in the previous step, +8 while the epilogue's 8 stores are younger) retires exactly the data the
+// step needs; one raw s_barrier per step.  Persistent workgroups walk the tiles; the next tile's first halo half and
+// weight tiles are already in flight during the epilogue, which runs straight from the accumulators (same
+// D[channel][pixel] orientation + v_permlane32_swap widening as conv_igemm_dma_kernel).
+#include "gmk_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+constexpr int kHaloSlots = 448;
+constexpr int kHB = kHaloSlots * 128;          // 57344 bytes per halo half-buffer
+constexpr int kWOFF = 2 * kHB;                 // weight ring offset
+constexpr int kWST = 16384;
+
+struct HaloParams {
+    const void* src0; const void* src1;
+    int c0, c1, ktot;
+    int B, H, W, WE, R, TP, ntiles, rows_total;
+    const void* w; unsigned w_tap_stride_b; int n0;
+    const float* bias; const float* emb; int emb_stride;
+    const void* residual; void* out; int out_cstride; int M;
+    unsigned nb0, nb1, nbw, nbo;
+    float inv_hp2, inv_h, inv_we, inv_w;       // reciprocals for exact small-integer division
+};
+
+__device__ __forceinline__ int div_small(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
+
+__global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p) {
+    constexpr int ES = 2;
+    __shared__ __attribute__((aligned(16))) char smem[kWOFF + 3 * kWST];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int nblk = blockIdx.y * 128;
+    const int H = p.H, W = p.W, WE = p.WE;
+    const int nph = p.ktot >> 6;                 // 64-channel phases per tile
+    constexpr unsigned kBadPix = 0x00FFFFFFu;
+    constexpr unsigned kBadOff = 0xFFFFFF00u;
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, (int)p.nb0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.c1 ? p.src1 : p.src0), 0, (int)(p.c1 ? p.nb1 : p.nb0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.nbw, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.nbo, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
+
+    // ---- per-lane constants -------------------------------------------------------------------------------
+    const int lrow = lane >> 3, lch = lane & 7;
+    // halo fill: piece j covers slots j*64 + wave*8 + lrow; swizzle term is independent of j
+    const int fs0 = wave * 8 + lrow;
+    const int f_er0 = div_small(fs0, p.inv_we), f_xe0 = fs0 - f_er0 * WE;
+    const int f_der = div_small(64, p.inv_we), f_dxe = 64 - f_der * WE;
+    const unsigned f_ch = (unsigned)((lch ^ ((fs0 >> 1) & 7)) << 4);
+    // weight tile rows: 16*wave + 8*i + lrow
+    unsigned w_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * wave + 8 * i + lrow;
+        w_off[i] = (unsigned)(p.n0 + nblk + row) * (unsigned)p.ktot * ES + (unsigned)((lch ^ ((row >> 1) & 7)) << 4);
+    }
+    // MFMA pixel rows of this lane: m_local = wm*64 + i*32 + r  ->  (row in tile, x)
+    int rit[2], px_x[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ml = wm * 64 + i * 32 + r;
+        rit[i] = div_small(ml, p.inv_w);
+        px_x[i] = ml - rit[i] * W;
+    }
+    unsigned hpix[7];       // source pixel of this lane's slot in each fill piece (tile whose fills are being issued)
+    int cslot[2];           // centre slot of this lane's two MFMA pixel rows (tile being computed)
+
+    auto resolve_fill = [&](int tile) {
+        const bool exists = tile < p.ntiles;
+        const int gr0 = tile * p.R;
+        const int b0 = gr0 / H;
+        const int y0 = gr0 - b0 * H;
+        int er = f_er0, xe = f_xe0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int E = er + y0;
+            const int k = div_small(E, p.inv_hp2);
+            const int y = E - k * (H + 2) - 1;
+            const int x = xe - 1;
+            const int b = b0 + k;
+            const bool ok = exists && y >= 0 && y < H && x >= 0 && x < W && b < p.B;
+            hpix[j] = ok ? (unsigned)((b * H + y) * W + x) : kBadPix;
+            er += f_der; xe += f_dxe;
+            if (xe >= WE) { xe -= WE; ++er; }
+        }
+    };
+    auto resolve_centres = [&](int tile) {
+        const int gr0 = tile * p.R;
+        const int b0 = gr0 / H;
+        const int y0 = gr0 - b0 * H;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = y0 + rit[i];
+            const int k = div_small(t, p.inv_h);
+            const int y = t - k * H;
+            const int er = k * (H + 2) + y + 1 - y0;
+            int s = er * WE + px_x[i] + 1;
+            if (s < WE + 1 || s >= kHaloSlots - WE - 1) s = WE + 1;     // dead rows (m_local >= TP): any in-range slot
+            cslot[i] = s;
+        }
+    };
+
+    // fill piece j of phase `ph` (of the tile hpix describes) into halo buffer hbuf
+    auto issue_fill = [&](int hbuf, int ph, int j) {
+        const int kelem = ph << 6;
+        const bool second = kelem >= p.c0;
+        const unsigned cs_b = (unsigned)(second ? p.c1 : p.c0) * ES;
+        const unsigned koff_b = (unsigned)(second ? kelem - p.c0 : kelem) * ES;
+        GMK_LDS char* dst = (GMK_LDS char*)(smem + hbuf * kHB + j * 8192 + wave * 1024);
+        const unsigned voff = __umul24(hpix[j], cs_b) + koff_b + f_ch;
+        if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (GMK_LDS void*)dst, 16, voff, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (GMK_LDS void*)dst, 16, voff, 0, 0, 0);
+    };
+    // weight tile (tap, phase) into ring slot `stage`
+    auto issue_w = [&](int stage, int tap, int ph) {
+        GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + wave * 2048);
+        const unsigned wk = (unsigned)tap * p.w_tap_stride_b + ((unsigned)ph << 7);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(dst + i * 1024), 16, w_off[i] + wk, 0, 0, 0);
+    };
+
+    f32x16 acc[2][2];     // [j: channel tile][i: pixel tile]
+    const int swz = (r >> 1) & 7;
+    const int b_off = kWOFF + (wn * 64 + r) * 128;
+
+    auto compute = [&](int hbuf, int st, int tapoff) {
+        const char* Hb = smem + hbuf * kHB;
+        const char* Wb = smem + st * kWST + b_off;
+        int rowb[2], sw[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int c = cslot[i];
+            asm volatile("" : "+v"(c));      // keep the per-tap addresses out of loop-invariant hoisting (72 VGPRs)
+            const int s = c + tapoff;
+            rowb[i] = s << 7;
+            sw[i] = (s >> 1) & 7;
+        }
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            bf16x8 px[2], wt[2];
+            px[0] = *reinterpret_cast<const bf16x8*>(Hb + rowb[0] + (((kg * 2 + h) ^ sw[0]) << 4));
+            px[1] = *reinterpret_cast<const bf16x8*>(Hb + rowb[1] + (((kg * 2 + h) ^ sw[1]) << 4));
+            const int coff = ((kg * 2 + h) ^ swz) << 4;
+            wt[0] = *reinterpret_cast<const bf16x8*>(Wb + coff);
+            wt[1] = *reinterpret_cast<const bf16x8*>(Wb + 4096 + coff);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[j], px[i], acc[j][i], 0, 0, 0);
+        }
+    };
+
+    auto epilogue = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ml = wm * 64 + i * 32 + r;
+            const int m = tile * p.TP + ml;
+            const bool live = ml < p.TP && m < p.M;
+            const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
+            const float* embp = nullptr;
+            if (p.emb) {
+                const int b = (live ? m : 0) / (H * W);
+                embp = p.emb + (int64_t)b * p.emb_stride;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cb = nblk + wn * 64 + j * 32;
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = acc[j][i][e];
+                if (p.bias) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        float t[4];
+                        load4(p.bias + cb + 8 * q4 + 4 * h, t);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * q4 + e] += t[e];
+                    }
+                }
+                if (p.emb) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        float t[4];
+                        load4(embp + cb + 8 * q4 + 4 * h, t);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * q4 + e] += t[e];
+                    }
+                }
+                if (p.residual) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const unsigned off = live ? row_b + (unsigned)(cb + 8 * q4 + 4 * h) * ES : kBadOff;
+                        const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rsr, off, 0, 0);
+                        const bf16x4 rb = __builtin_bit_cast(bf16x4, raw);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * q4 + e] += (float)rb[e];
+                    }
+                }
+                unsigned pk[4][2];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    bf16x4 t = {(bf16_t)v[4 * q4], (bf16_t)v[4 * q4 + 1], (bf16_t)v[4 * q4 + 2], (bf16_t)v[4 * q4 + 3]};
+                    const auto u = __builtin_bit_cast(u32x2_t, t);
+                    pk[q4][0] = u[0]; pk[q4][1] = u[1];
+                }
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4 += 2) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[q4][0], pk[q4 + 1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q4][1], pk[q4 + 1][1], false, false);
+                    u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                    const unsigned off = live ? row_b + (unsigned)(cb + 8 * (q4 + h)) * ES : kBadOff;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rso, off, 0, 0);
+                }
+            }
+        }
+    };
+
+    int st = 0, sq = 2;      // weight ring: slot computed next / slot issued next
+    int hbuf = 0;            // halo buffer of the phase computed next
+    int fresh = 0;           // K-steps left whose data is older than the epilogue's 8 stores
+    int tile = blockIdx.x;
+    if (tile >= p.ntiles) return;
+
+    // ---- prologue: whole first halo half + the first two weight tiles
+    resolve_fill(tile);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) issue_fill(0, 0, j);
+    issue_w(0, 0, 0);
+    issue_w(1, 1, 0);
+
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        resolve_centres(tile);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+        for (int ph = 0; ph < nph; ++ph) {
+            const bool last_ph = ph + 1 == nph;
+            if (last_ph) resolve_fill(tile + gridDim.x);        // the next fills belong to the next tile (or are zeros)
+            const int ph_next = last_ph ? 0 : ph + 1;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                // ---- wait: retire everything but the ops issued in the previous step (+ the epilogue's stores)
+                if (tap == 0) {
+                    if (fresh > 0) { --fresh; asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                } else if (tap == 1) {
+                    if (fresh > 0) { --fresh; asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
+                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                } else if (tap == 8) {
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                // ---- issue: weight tile of step q+2, and one piece of the next phase's halo
+                if (tap < 7) issue_w(sq, tap + 2, ph);
+                else issue_w(sq, tap - 7, ph_next);
+                if (tap < 7) issue_fill(hbuf ^ 1, ph_next, tap);
+                // ---- compute
+                compute(hbuf, st, (tap / 3 - 1) * WE + (tap % 3 - 1));
+                st = st == 2 ? 0 : st + 1;
+                sq = sq == 2 ? 0 : sq + 1;
+            }
+            hbuf ^= 1;
+        }
+        asm volatile("" ::: "memory");
+        epilogue(tile);
+        asm volatile("" ::: "memory");
+        fresh = 2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the speculative DMA before the LDS is released
+}
+
+}  // namespace
+
+// Returns 1 if the halo kernel was launched, 0 if the problem is not eligible (caller falls back), <0 / >0 on error.
+int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int B, int H, int W, const void* w, int w_rows,
+                         int n0, int cout, const float* bias, const float* emb, int emb_stride, const void* residual,
+                         void* out, int out_cstride, int min_tiles, hipStream_t stream) {
+    if (c0 % 64 || c1 % 64 || cout % 128) return 0;
+    if (W < 4 || W > 254 || H < 2) return 0;
+    const int R = 256 / W;
+    if (R < 1) return 0;
+    const int TP = R * W;
+    const int crossings = (R - 1 + H - 1) / H;               // image boundaries a tile of R rows can span
+    const int ner = R + 2 + 2 * crossings;
+    if (ner * (W + 2) > kHaloSlots) return 0;
+    const int64_t rows_total = (int64_t)B * H;
+    const int64_t M = rows_total * W;
+    const int64_t nb0 = M * c0 * 2, nb1 = M * c1 * 2;
+    const int64_t nbw = (int64_t)9 * w_rows * (c0 + c1) * 2, nbo = M * out_cstride * 2;
+    const int64_t lim = 0xFFFFFF00ll;
+    if (nb0 >= lim || nb1 >= lim || nbw >= lim || nbo >= lim || M >= 0x00FFFFFF) return 0;
+    if ((int64_t)0x00FFFFFF * c0 * 2 < nb0 || (c1 && (int64_t)0x00FFFFFF * c1 * 2 < nb1)) return 0;
+    const int64_t ntiles = (rows_total + R - 1) / R;
+    if (ntiles < min_tiles) return 0;                         // not enough tiles to fill the chip: im2col kernels
+    HaloParams p;
+    p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.ktot = c0 + c1;
+    p.B = B; p.H = H; p.W = W; p.WE = W + 2; p.R = R; p.TP = TP; p.ntiles = (int)ntiles; p.rows_total = (int)rows_total;
+    p.w = w; p.w_tap_stride_b = (unsigned)w_rows * (unsigned)(c0 + c1) * 2u; p.n0 = n0;
+    p.bias = bias; p.emb = emb; p.emb_stride = emb_stride; p.residual = residual; p.out = out; p.out_cstride = out_cstride;
+    p.M = (int)M;
+    p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1; p.nbw = (unsigned)nbw; p.nbo = (unsigned)nbo;
+    p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 2); p.inv_w = 1.0f / (float)W;
+    dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256), cout / 128);
+    conv3x3_halo_kernel<<<grid, 512, 0, stream>>>(p);
+    return 1;
+}

@@ -21,6 +21,8 @@
 //   ds_read_b64_tr_b16 (window swizzle win ^= px&3, conflict-free), fp32 through plain ds_read_b32 (one k per
 //   lane).  Split-K over pixel ranges into fp32 slabs + a deterministic reduce that also converts to the
 //   reference's [Cout][Cin][k][k] layout.
+#include <stdlib.h>
+
 #include "gmk_common.h"
 
 namespace {
@@ -64,9 +66,11 @@ struct ConvParams {
     const float* bias; const float* emb; int emb_stride;
     const void* residual; void* out; int out_cstride;
     int M;   // B*ho*wo
+    unsigned nb0, nb1, nbw, nbo;   // byte sizes of src0 / src1 / w / out for the buffer descriptors of the LDS-DMA kernel
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
@@ -245,6 +249,307 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             for (int e = 0; e < 4; ++e) v[e] += t[e];
         }
         store4((T*)p.out + o, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for large problems — the kernel the step time is dominated by.
+//   * 256(pixels) x 128(channels) output tile per workgroup, 8 waves (4 along pixels x 2 along channels, 64x64 each).
+//   * 3-slot LDS ring of {pixel tile 256x128 B, weight tile 128x128 B} filled by `buffer_load_dwordx4 ... lds`
+//     (no VGPR staging, no ds_write); two K-steps in flight behind a counted `s_waitcnt vmcnt`, one raw
+//     `s_barrier` per K-step.  Zero padding / masked taps come from the buffer descriptor's range check (an
+//     out-of-range offset feeds zeros), so the gather has no branches.  One DMA instruction writes 1 KiB
+//     lane-linearly (8 rows x 128 B), so the bank swizzle is applied to each lane's SOURCE chunk:
+//     physical chunk (lane&7) holds logical chunk (lane&7) ^ ((row>>1)&7); fragments are read with the same XOR.
+//   * the source pixel of every (tile row, tap) is resolved once per tile (36 registers); the K loop is unrolled
+//     over the taps so those registers are indexed statically, and a DMA issue is one 24-bit multiply-add.
+//   * operands are fed to the MFMA as D[channel][pixel] = W . P^T, so a lane ends up owning 4 consecutive
+//     channels of one pixel: after one v_permlane32_swap per dword every lane stores 16 contiguous bytes straight
+//     from its accumulators (bias / embedding / residual added in fp32 before the rounding) — no LDS round trip,
+//     no barrier in the epilogue.
+//   * persistent workgroups (one per CU) walk the tiles; the first two K-steps of the next tile are issued
+//     before the current tile's epilogue, so the epilogue runs under the next tile's DMA latency.
+// vmcnt bookkeeping (CDNA4 counts loads, stores and LDS-DMA together, in issue order): every K-step is 6 DMA
+// instructions per wave and the epilogue issues exactly kEpiStores buffer stores per wave (masked lanes use an
+// out-of-range offset so the instruction is always issued), hence the first two K-steps after an epilogue wait with
+// vmcnt(6 + kEpiStores) and every other one with vmcnt(6).
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams p) {
+    constexpr int ES = sizeof(T);
+    constexpr int KCH = 128 / ES;
+    constexpr int NS = 3, A_BYTES = 32768, STAGE = 49152;
+    constexpr int kEpiStores = ES == 2 ? 8 : 16;
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int nblk = blockIdx.y * kBN;
+    const GatherParams g = p.g;
+    const int hw_o = g.ho * g.wo;
+    const int ntiles = (p.M + 255) >> 8;
+
+    constexpr unsigned kBadPix = 0x00FFFFFFu;   // kBadPix * bytes-per-pixel lies beyond any buffer (host-checked)
+    constexpr unsigned kBadOff = 0xFFFFFF00u;
+    const int lrow = lane >> 3, lch = lane & 7;
+    unsigned pixi[4][9];
+    unsigned a_ch[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_ch[i] = (unsigned)((lch ^ (((32 * wave + 8 * i + lrow) >> 1) & 7)) << 4);
+    unsigned w_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * wave + 8 * i + lrow;
+        w_off[i] = (unsigned)(p.n0 + nblk + row) * (unsigned)p.ktot * ES + (unsigned)((lch ^ ((row >> 1) & 7)) << 4);
+    }
+    auto resolve_tile = [&](int tile) {      // fills pixi for the rows this lane stages
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = tile * 256 + 32 * wave + 8 * i + lrow;
+            const bool live = m < p.M;
+            const int mm = live ? m : 0;
+            const int b = mm / hw_o;
+            const int rem = mm - b * hw_o;
+            const int oy = rem / g.wo;
+            const int by = oy * g.mul - g.pad, bx = (rem - oy * g.wo) * g.mul - g.pad;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ty = by + t / 3, tx = bx + t % 3;
+                const bool ok = live && ty >= 0 && ty < g.lim_h && tx >= 0 && tx < g.lim_w && !((ty | tx) & g.mask);
+                pixi[i][t] = ok ? (unsigned)((b * g.hs + (ty >> g.shift)) * g.ws + (tx >> g.shift)) : kBadPix;
+            }
+        }
+    };
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, (int)p.nb0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.c1 ? p.src1 : p.src0), 0, (int)(p.c1 ? p.nb1 : p.nb0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.nbw, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.nbo, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
+
+    const int kpt = p.ktot / KCH;            // K chunks per tap (>= 2)
+    const int ntaps = g.ksize * g.ksize;     // 1 or 9 (a 1x1 conv uses tap slot 0: pad 0, offsets (0,0))
+
+    // DMA of K-step (tap, kc) into ring slot `stage`; `tap` is a compile-time constant at every call site
+    auto issue = [&](int stage, const unsigned (&pix)[4], int tap, int kc) {
+        const int kelem = kc * KCH;
+        const bool second = kelem >= p.c0;
+        const unsigned cs_b = (unsigned)(second ? p.c1 : p.c0) * ES;         // bytes per source pixel
+        const unsigned koff_b = (unsigned)(second ? kelem - p.c0 : kelem) * ES;
+        GMK_LDS char* lds_a = (GMK_LDS char*)(smem + stage * STAGE + wave * 4096);
+        if (second) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (GMK_LDS void*)(lds_a + i * 1024), 16,
+                                                         __umul24(pix[i], cs_b) + koff_b + a_ch[i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (GMK_LDS void*)(lds_a + i * 1024), 16,
+                                                         __umul24(pix[i], cs_b) + koff_b + a_ch[i], 0, 0, 0);
+        }
+        GMK_LDS char* lds_b = (GMK_LDS char*)(smem + stage * STAGE + A_BYTES + wave * 2048);
+        const unsigned wk = ((unsigned)tap * (unsigned)p.w_tap_stride + (unsigned)kelem) * ES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(lds_b + i * 1024), 16, w_off[i] + wk, 0, 0, 0);
+    };
+
+    f32x16 acc[2][2];     // [j: channel tile][i: pixel tile]
+
+    const int swz = (r >> 1) & 7;
+    const int a_off = (wm * 64 + r) * 128;
+    const int b_off = A_BYTES + (wn * 64 + r) * 128;
+
+    auto compute = [&](int st) {
+        const char* Sb = smem + st * STAGE;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const int coff = ((kg * 2 + h) ^ swz) << 4;
+            if constexpr (ES == 2) {
+                bf16x8 px[2], wt[2];
+                px[0] = *reinterpret_cast<const bf16x8*>(Sb + a_off + coff);
+                px[1] = *reinterpret_cast<const bf16x8*>(Sb + a_off + 4096 + coff);
+                wt[0] = *reinterpret_cast<const bf16x8*>(Sb + b_off + coff);
+                wt[1] = *reinterpret_cast<const bf16x8*>(Sb + b_off + 4096 + coff);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[j], px[i], acc[j][i], 0, 0, 0);
+            } else {
+                f32x4 px[2], wt[2];
+                px[0] = *reinterpret_cast<const f32x4*>(Sb + a_off + coff);
+                px[1] = *reinterpret_cast<const f32x4*>(Sb + a_off + 4096 + coff);
+                wt[0] = *reinterpret_cast<const f32x4*>(Sb + b_off + coff);
+                wt[1] = *reinterpret_cast<const f32x4*>(Sb + b_off + 4096 + coff);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[j][s], px[i][s], acc[j][i], 0, 0, 0);
+            }
+        }
+    };
+
+    // per-lane bias for its 16 channels of each channel tile: channel = nblk + wn*64 + j*32 + (e&3) + 8*(e>>2) + 4*h
+    float bias_r[2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            bias_r[j][e] = p.bias ? p.bias[nblk + wn * 64 + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
+
+    // ---- epilogue straight from the accumulators
+    auto epilogue = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = tile * 256 + wm * 64 + i * 32 + r;
+            const bool live = m < p.M;
+            const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
+            const float* embp = p.emb ? p.emb + (int64_t)((live ? m : 0) / hw_o) * p.emb_stride : nullptr;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cb = nblk + wn * 64 + j * 32;       // first channel of this 32-channel tile
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = acc[j][i][e] + bias_r[j][e];
+                if (embp) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        float t[4];
+                        load4(embp + cb + 8 * q4 + 4 * h, t);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * q4 + e] += t[e];
+                    }
+                }
+                if (p.residual) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const unsigned off = live ? row_b + (unsigned)(cb + 8 * q4 + 4 * h) * ES : kBadOff;
+                        float t[4];
+                        if constexpr (ES == 2) {
+                            const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rsr, off, 0, 0);
+                            const bf16x4 rb = __builtin_bit_cast(bf16x4, raw);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) t[e] = (float)rb[e];
+                        } else {
+                            const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsr, off, 0, 0);
+                            const f32x4 rf = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) t[e] = rf[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * q4 + e] += t[e];
+                    }
+                }
+                if constexpr (ES == 2) {
+                    // pack to bf16: group q4 = channels cb + 8*q4 + 4*h + {0..3}  ->  2 dwords
+                    unsigned pk[4][2];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        bf16x4 t = {(bf16_t)v[4 * q4], (bf16_t)v[4 * q4 + 1], (bf16_t)v[4 * q4 + 2], (bf16_t)v[4 * q4 + 3]};
+                        const auto u = __builtin_bit_cast(u32x2_t, t);
+                        pk[q4][0] = u[0]; pk[q4][1] = u[1];
+                    }
+                    // exchange between lane l (h=0) and l+32 (h=1): afterwards h=0 holds channels cb+8q..cb+8q+7 of
+                    // group pair (q, q+1) and h=1 holds cb+8(q+1)..cb+8(q+1)+7: 16 contiguous bytes per lane
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4 += 2) {
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[q4][0], pk[q4 + 1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q4][1], pk[q4 + 1][1], false, false);
+                        u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                        const unsigned off = live ? row_b + (unsigned)(cb + 8 * (q4 + h)) * ES : kBadOff;
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rso, off, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        f32x4 t = {v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]};
+                        const unsigned off = live ? row_b + (unsigned)(cb + 8 * q4 + 4 * h) * ES : kBadOff;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rso, off, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    int st = 0;          // ring slot of the K-step computed next
+    int sq = 2;          // ring slot the next issue goes to
+    int fresh = 0;       // K-steps still to run with the epilogue's stores younger than their data
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        resolve_tile(tile);
+        unsigned pix0[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pix0[i] = pixi[i][0];
+        issue(0, pix0, 0, 0);
+        issue(1, pix0, 0, 1);
+    }
+    auto wait_step = [&]() {       // the oldest K-step in flight has landed for this wave, then for everyone
+        if (fresh > 0) {
+            --fresh;
+            if constexpr (ES == 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < ntaps) {
+                unsigned pix[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pix[i] = pixi[i][tap];
+                for (int kc = (tap == 0 ? 2 : 0); kc < kpt; ++kc) {
+                    wait_step();
+                    issue(sq, pix, tap, kc);
+                    compute(st);
+                    st = st == 2 ? 0 : st + 1;
+                    sq = sq == 2 ? 0 : sq + 1;
+                }
+            }
+        }
+        // the last two K-steps of this tile run while the first two of the next tile are issued
+        const int next = tile + gridDim.x;
+        const bool more = next < ntiles;
+        if (more) resolve_tile(next);
+        unsigned pix0[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pix0[i] = pixi[i][0];
+        wait_step();
+        if (more) issue(sq, pix0, 0, 0);
+        compute(st);
+        st = st == 2 ? 0 : st + 1;
+        sq = sq == 2 ? 0 : sq + 1;
+        if (more) {
+            wait_step();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (more) issue(sq, pix0, 0, 1);
+        compute(st);
+        st = st == 2 ? 0 : st + 1;
+        sq = sq == 2 ? 0 : sq + 1;
+        asm volatile("" ::: "memory");
+        epilogue(tile);
+        asm volatile("" ::: "memory");
+        fresh = 2;
     }
 }
 
@@ -510,9 +815,34 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
     p.w = w; p.w_tap_stride = (int64_t)w_rows * (c0 + c1); p.n0 = n0;
     p.bias = bias; p.emb = emb; p.emb_stride = emb_stride; p.residual = residual; p.out = out;
     p.out_cstride = out_cstride; p.M = B * ho * wo;
-    dim3 grid((p.M + kBM - 1) / kBM, cout / kBN);
-    if (dtype == GMK_BF16) conv_igemm_kernel<bf16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
-    else conv_igemm_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(p);
+    // kernel choice: 0 = automatic, 1 = register-staged 128x128, 2 = LDS-DMA im2col 256x128, 3 = LDS halo (3x3 s1 bf16)
+    static const int force = getenv("GMK_CONV_KERNEL") ? atoi(getenv("GMK_CONV_KERNEL")) : 0;
+    if ((force == 0 || force == 3) && dtype == GMK_BF16 && mode == GMK_CONV_NORMAL && ksize == 3) {
+        const int rc = gmk_conv3x3_halo_try(src0, src1, c0, c1, B, hs, ws, w, w_rows, n0, cout, bias, emb, emb_stride, residual,
+                                            out, out_cstride, force == 3 ? 1 : 256, gmk_stream(stream));
+        if (rc == 1) return gmk_check_launch("gmk_conv_igemm(halo)");
+    }
+    const int es = gmk_esize(dtype);
+    const int64_t nb0 = (int64_t)B * hs * ws * c0 * es, nb1 = (int64_t)B * hs * ws * c1 * es;
+    const int64_t nbw = (int64_t)ksize * ksize * w_rows * (c0 + c1) * es;
+    // LDS-DMA kernel: problems with at least ~2 tiles of 256 pixels per CU, buffers addressable with 32-bit offsets
+    const int64_t nbo = (int64_t)p.M * out_cstride * es;
+    const int64_t lim = 0xFFFFFF00ll;      // kBadOff / kBadPix * bytes-per-pixel must lie beyond every buffer
+    const bool fits = nb0 < lim && nb1 < lim && nbw < lim && nbo < lim && (int64_t)B * hs * ws < 0x00FFFFFF &&
+                      (int64_t)0x00FFFFFF * c0 * es >= nb0 && (c1 == 0 || (int64_t)0x00FFFFFF * c1 * es >= nb1);
+    const bool dma = fits && (force == 2 || (force != 1 && p.M >= 256 * 512));
+    if (dma) {
+        p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1; p.nbw = (unsigned)nbw; p.nbo = (unsigned)nbo;
+        int ncu = 256;
+        const int ntiles = (p.M + 255) / 256;
+        dim3 grid(ntiles < ncu ? ntiles : ncu, cout / kBN);
+        if (dtype == GMK_BF16) conv_igemm_dma_kernel<bf16_t><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+        else conv_igemm_dma_kernel<float><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+    } else {
+        dim3 grid((p.M + kBM - 1) / kBM, cout / kBN);
+        if (dtype == GMK_BF16) conv_igemm_kernel<bf16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
+        else conv_igemm_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(p);
+    }
     return gmk_check_launch("gmk_conv_igemm");
 }
 

@@ -27,6 +27,11 @@ int gmk_check_launch(const char* what);   // returns 0 or the positive hipError_
         }                                      \
     } while (0)
 
+// conv_halo.hip: 3x3 stride-1 bf16 convolution with an LDS-resident halo; returns 1 if launched, 0 if not eligible
+int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int B, int H, int W, const void* w, int w_rows,
+                         int n0, int cout, const float* bias, const float* emb, int emb_stride, const void* residual,
+                         void* out, int out_cstride, int min_tiles, hipStream_t stream);
+
 static inline hipStream_t gmk_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int gmk_esize(int dtype) { return dtype == GMK_BF16 ? 2 : 4; }
 

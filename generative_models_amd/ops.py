@@ -13,6 +13,28 @@ F32, BF16 = 0, 1
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 NORMAL, STRIDE2, UPSAMPLE2, TRANSPOSED2 = 0, 1, 2, 3
 
+# bench.py sets this to a list to collect (kernel name, start event, end event, algorithmic FLOPs) per launch of the
+# MFMA convolution kernels; events are recorded on the stream the kernel is launched on.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, name, flops):
+        self.on = PROFILE is not None
+        if self.on:
+            self.name, self.flops = name, flops
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.s.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e.record()
+            PROFILE.append((self.name, self.s, self.e, self.flops))
+
 
 def dt_code(dtype):
     return _DT[dtype]
@@ -149,8 +171,11 @@ def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, 
         _f32(bias, "bias"); assert bias.numel() == cout
     if residual is not None:
         _chk(residual, s0.dtype, "residual"); assert residual.shape == out.shape
-    check(lib.gmk_conv_igemm(_p(s0), _p(s1), c0, c1, B, hs, ws, ho, wo, ksize, mode, _p(w), w_rows, n0, cout, _p(bias),
-                             _p(emb), emb_stride, _p(residual), _p(out), cout, _DT[s0.dtype], _s()), "conv_igemm")
+    mpix = B * hs * ws if mode == TRANSPOSED2 else B * ho * wo     # algorithmic work: that of the stride-2 conv
+    with _Timed("conv_igemm", 2.0 * mpix * cout * (c0 + c1) * ksize * ksize):
+        check(lib.gmk_conv_igemm(_p(s0), _p(s1), c0, c1, B, hs, ws, ho, wo, ksize, mode, _p(w), w_rows, n0, cout,
+                                 _p(bias), _p(emb), emb_stride, _p(residual), _p(out), cout, _DT[s0.dtype], _s()),
+              "conv_igemm")
     return out
 
 
@@ -179,8 +204,9 @@ def conv_wgrad(dy, srcs, ksize, mode, dw):
     need = lib.gmk_conv_wgrad_workspace_bytes(B * ho * wo, ksize * ksize, cout, c0 + c1)
     assert need > 0
     wsbuf = _workspace(need, dy.device)
-    check(lib.gmk_conv_wgrad(_p(dy), cout, _p(s0), _p(s1), c0, c1, B, hs, ws_, ho, wo, ksize, mode, _p(dw), cout,
-                             _p(wsbuf), wsbuf.numel(), _DT[dy.dtype], _s()), "conv_wgrad")
+    with _Timed("conv_wgrad", 2.0 * B * ho * wo * cout * (c0 + c1) * ksize * ksize):
+        check(lib.gmk_conv_wgrad(_p(dy), cout, _p(s0), _p(s1), c0, c1, B, hs, ws_, ho, wo, ksize, mode, _p(dw), cout,
+                                 _p(wsbuf), wsbuf.numel(), _DT[dy.dtype], _s()), "conv_wgrad")
     return dw
 
 

@@ -101,9 +101,10 @@ def closed_form_params(channels, in_channels=1, dtype=torch.float32):
     return params
 
 
-def reference_init_params(channels, in_channels=1, seed=0, dtype=torch.float32):
+def reference_init_params(channels, in_channels=1, seed=0, dtype=torch.float32, zero_out_layers=True):
     """PyTorch-default-style init (kaiming-uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for
-    weights and biases, GroupNorm 1/0, `out_layers.3` zeroed as simple_unet.py:172 does)."""
+    weights and biases, GroupNorm 1/0, `out_layers.3` zeroed as simple_unet.py:172 does unless
+    zero_out_layers=False, which keeps every convolution live at its default-init scale)."""
     g = torch.Generator().manual_seed(seed)
     params = OrderedDict()
     fan = {}
@@ -118,7 +119,7 @@ def reference_init_params(channels, in_channels=1, seed=0, dtype=torch.float32):
         if base in fan:
             bound = 1.0 / math.sqrt(fan[base])
             v = (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * bound
-            if ".out_layers.3" in name:
+            if ".out_layers.3" in name and zero_out_layers:
                 v = torch.zeros(shape, dtype=torch.float64)
         else:  # GroupNorm affine
             v = torch.ones(shape, dtype=torch.float64) if kind == "weight" else torch.zeros(shape, dtype=torch.float64)

@@ -69,7 +69,7 @@ def test_gn_silu_fwd_bwd(ops, dtype, C, G, S):
     assert rel_err(nchw(dx), dx_ref) < TOL[dtype]
     assert rel_err(dgp.sum(0), gamma.grad) < TOL[dtype]
     assert rel_err(dbp.sum(0), beta.grad) < TOL[dtype]
-    assert rel_err(dxsum, nchw(dx).sum((2, 3))) < 1e-3
+    assert rel_err(dxsum, nchw(dx).sum((2, 3))) < TOL[dtype]      # fp32 sums of the unrounded dx vs sums of the stored dx
     # helpers
     out = torch.empty(C, device="cuda")
     ops.colsum(dgp, out)
