@@ -325,9 +325,8 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     const int64_t M = rows_total * W;
     const int64_t nb0 = M * c0 * 2, nb1 = M * c1 * 2;
     const int64_t nbw = (int64_t)9 * w_rows * (c0 + c1) * 2, nbo = M * out_cstride * 2;
-    const int64_t lim = 0xFFFFFF00ll;
-    if (nb0 >= lim || nb1 >= lim || nbw >= lim || nbo >= lim || M >= 0x00FFFFFF) return 0;
-    if ((int64_t)0x00FFFFFF * c0 * 2 < nb0 || (c1 && (int64_t)0x00FFFFFF * c1 * 2 < nb1)) return 0;
+    const int64_t lim = 0xFFFF0000ll;     // below (kBadPix * bytes-per-pixel) mod 2^32 for pixels of up to 4 KiB
+    if (nb0 >= lim || nb1 >= lim || nbw >= lim || nbo >= lim || M >= 0x00FFFFFF || c0 > 2048 || c1 > 2048) return 0;
     const int64_t ntiles = (rows_total + R - 1) / R;
     if (ntiles < min_tiles) return 0;                         // not enough tiles to fill the chip: im2col kernels
     HaloParams p;

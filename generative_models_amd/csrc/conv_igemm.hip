@@ -772,8 +772,12 @@ int wgrad_nsplit(int64_t n_pixels, int taps, int cout, int ktot, int* chunk) {
 extern "C" int64_t gmk_conv_wgrad_workspace_bytes(int64_t n_pixels, int taps, int cout, int ktot) {
     if (n_pixels <= 0 || taps <= 0 || cout % 128 || ktot % 128) return -1;
     int chunk;
-    const int ns = wgrad_nsplit(n_pixels, taps, cout, ktot, &chunk);
-    return (int64_t)ns * taps * cout * ktot * 4;
+    int64_t ns = wgrad_nsplit(n_pixels, taps, cout, ktot, &chunk);
+    if (taps == 9) {
+        const int64_t ns2 = gmk_wgrad_slots_nsplit(cout, ktot);
+        if (ns2 > ns) ns = ns2;
+    }
+    return ns * taps * cout * ktot * 4;
 }
 
 extern "C" int gmk_pack_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int cout, int cin, int ksize, int dtype,
@@ -827,9 +831,10 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
     const int64_t nbw = (int64_t)ksize * ksize * w_rows * (c0 + c1) * es;
     // LDS-DMA kernel: problems with at least ~2 tiles of 256 pixels per CU, buffers addressable with 32-bit offsets
     const int64_t nbo = (int64_t)p.M * out_cstride * es;
-    const int64_t lim = 0xFFFFFF00ll;      // kBadOff / kBadPix * bytes-per-pixel must lie beyond every buffer
+    // kBadOff and (kBadPix * bytes-per-pixel) mod 2^32 (>= 0xFFFFF000 for pixels of up to 4 KiB) must lie beyond every buffer
+    const int64_t lim = 0xFFFF0000ll;
     const bool fits = nb0 < lim && nb1 < lim && nbw < lim && nbo < lim && (int64_t)B * hs * ws < 0x00FFFFFF &&
-                      (int64_t)0x00FFFFFF * c0 * es >= nb0 && (c1 == 0 || (int64_t)0x00FFFFFF * c1 * es >= nb1);
+                      (int64_t)c0 * es <= 4096 && (int64_t)c1 * es <= 4096;
     const bool dma = fits && (force == 2 || (force != 1 && p.M >= 256 * 512));
     if (dma) {
         p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1; p.nbw = (unsigned)nbw; p.nbo = (unsigned)nbo;
@@ -862,6 +867,20 @@ extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, 
     GMK_REQUIRE(make_gather(mode, ksize, hs, ws, ho, wo, &p.g), "gmk_conv_wgrad: mode %d inconsistent with %dx%d -> %dx%d",
                 mode, hs, ws, ho, wo);
     const int taps = ksize * ksize;
+    // kernel choice: 0 = automatic, 1 = im2col split-K, 2 = padded-slot correlation (3x3 s1 bf16)
+    static const int wforce = getenv("GMK_WGRAD_KERNEL") ? atoi(getenv("GMK_WGRAD_KERNEL")) : 0;
+    if (wforce != 1 && dtype == GMK_BF16 && mode == GMK_CONV_NORMAL && ksize == 3) {
+        const int ns2 = gmk_conv_wgrad_slots_try(dy, dy_cstride, src0, src1, c0, c1, B, hs, ws, cout, (float*)workspace,
+                                                 workspace_bytes, wforce == 2, gmk_stream(stream));
+        if (ns2 > 0) {
+            int rc2 = gmk_check_launch("gmk_conv_wgrad(slots)");
+            if (rc2) return rc2;
+            const int64_t per2 = (int64_t)taps * cout * (c0 + c1);
+            wgrad_reduce_kernel<<<(int)((per2 + 255) / 256), 256, 0, gmk_stream(stream)>>>((const float*)workspace, dw, ns2, taps,
+                                                                                            cout, c0 + c1);
+            return gmk_check_launch("gmk_conv_wgrad(reduce)");
+        }
+    }
     p.dy = dy; p.dy_cstride = dy_cstride; p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.ktot = c0 + c1;
     p.cout = cout; p.M = B * ho * wo;
     const int ns = wgrad_nsplit(p.M, taps, cout, p.ktot, &p.chunk);

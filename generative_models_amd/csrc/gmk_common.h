@@ -32,6 +32,11 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
                          int n0, int cout, const float* bias, const float* emb, int emb_stride, const void* residual,
                          void* out, int out_cstride, int min_tiles, hipStream_t stream);
 
+// conv_wgrad_slots.hip: 3x3 stride-1 bf16 weight gradient over padded slots; returns the number of slabs written or 0
+int gmk_wgrad_slots_nsplit(int cout, int ktot);
+int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B, int H,
+                             int W, int cout, float* slab, int64_t slab_bytes, int forced, hipStream_t stream);
+
 static inline hipStream_t gmk_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int gmk_esize(int dtype) { return dtype == GMK_BF16 ? 2 : 4; }
 
