@@ -148,18 +148,26 @@ def main():
         for name, s, e, f in prof:
             d = by.setdefault(name, [0.0, 0.0, 0])
             d[0] += s.elapsed_time(e); d[1] += f; d[2] += 1
-        ms, fl, n = by["conv_igemm"]
+        dom = max(by, key=lambda k: by[k][0])          # dominant kernel = largest total HIP-event time
+        desc = {"conv3x3_halo_kernel": "3x3 stride-1 bf16 convolution, LDS-resident halo (forward + data gradients)",
+                "conv_igemm_dma_kernel": "im2col LDS-DMA convolution (1x1, strided, upsampled, fp32)",
+                "conv_igemm_kernel": "im2col register-staged convolution (small problems)",
+                "conv_wgrad_slots_kernel": "3x3 weight gradient over padded slots (+ slab reduce)",
+                "conv_wgrad_kernel": "im2col split-K weight gradient (+ slab reduce)"}
+        ms, fl, n = by[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        roofline = {"kernel": "conv_igemm_kernel (3x3/1x1 implicit GEMM, forward + data-gradient launches)",
-                    "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")     # PMC FETCH/WRITE_SIZE of the same command (rocprofv3)
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
+        roofline = {"kernel": dom, "what": desc.get(dom, ""), "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "launches_per_step": n // a.steps, "avg_launch_us": round(ms * 1e3 / n, 2),
-                    "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
-        if "conv_wgrad" in by:
-            ms2, fl2, n2 = by["conv_wgrad"]
-            roofline["wgrad"] = {"achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2), "avg_launch_us": round(ms2 * 1e3 / n2, 2),
-                                 "launches_per_step": n2 // a.steps, "share_of_step_time": round(ms2 * 1e-3 / elapsed, 3),
-                                 "note": "split-K kernel + slab reduce"}
+                    "share_of_step_time": round(ms * 1e-3 / elapsed, 3),
+                    "other_kernels": {k: {"achieved": round(v[1] / (v[0] * 1e-3) / 1e12, 2), "avg_launch_us": round(v[0] * 1e3 / v[2], 2),
+                                          "launches_per_step": v[2] // a.steps,
+                                          "share_of_step_time": round(v[0] * 1e-3 / elapsed, 3)}
+                                      for k, v in by.items() if k != dom}}
 
     # ---- reverse-diffusion steps/s: DDIM, guidance off (the `evaluate` path), trajectories not recorded
     from functools import partial

@@ -824,7 +824,10 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
     if ((force == 0 || force == 3) && dtype == GMK_BF16 && mode == GMK_CONV_NORMAL && ksize == 3) {
         const int rc = gmk_conv3x3_halo_try(src0, src1, c0, c1, B, hs, ws, w, w_rows, n0, cout, bias, emb, emb_stride, residual,
                                             out, out_cstride, force == 3 ? 1 : 256, gmk_stream(stream));
-        if (rc == 1) return gmk_check_launch("gmk_conv_igemm(halo)");
+        if (rc == 1) {
+            gmk_note_kernel(3);
+            return gmk_check_launch("gmk_conv_igemm(halo)");
+        }
     }
     const int es = gmk_esize(dtype);
     const int64_t nb0 = (int64_t)B * hs * ws * c0 * es, nb1 = (int64_t)B * hs * ws * c1 * es;
@@ -836,6 +839,7 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
     const bool fits = nb0 < lim && nb1 < lim && nbw < lim && nbo < lim && (int64_t)B * hs * ws < 0x00FFFFFF &&
                       (int64_t)c0 * es <= 4096 && (int64_t)c1 * es <= 4096;
     const bool dma = fits && (force == 2 || (force != 1 && p.M >= 256 * 512));
+    gmk_note_kernel(dma ? 2 : 1);
     if (dma) {
         p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1; p.nbw = (unsigned)nbw; p.nbo = (unsigned)nbo;
         int ncu = 256;
@@ -873,6 +877,7 @@ extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, 
         const int ns2 = gmk_conv_wgrad_slots_try(dy, dy_cstride, src0, src1, c0, c1, B, hs, ws, cout, (float*)workspace,
                                                  workspace_bytes, wforce == 2, gmk_stream(stream));
         if (ns2 > 0) {
+            gmk_note_kernel(12);
             int rc2 = gmk_check_launch("gmk_conv_wgrad(slots)");
             if (rc2) return rc2;
             const int64_t per2 = (int64_t)taps * cout * (c0 + c1);
@@ -888,6 +893,7 @@ extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, 
     GMK_REQUIRE(workspace_bytes >= need, "gmk_conv_wgrad: workspace %lld < %lld bytes", (long long)workspace_bytes,
                 (long long)need);
     p.slab = (float*)workspace;
+    gmk_note_kernel(11);
     dim3 grid(ns, taps, (cout / 128) * (p.ktot / 128));
     if (dtype == GMK_BF16) conv_wgrad_kernel<bf16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
     else conv_wgrad_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(p);

@@ -18,6 +18,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // ---- host-side error plumbing (no exceptions cross the C ABI) -------------------------------
 void gmk_set_error(const char* fmt, ...);
 int gmk_check_launch(const char* what);   // returns 0 or the positive hipError_t of the launch
+void gmk_note_kernel(int id);             // 1 conv_igemm_kernel, 2 conv_igemm_dma_kernel, 3 conv3x3_halo_kernel,
+                                          // 11 conv_wgrad_kernel, 12 conv_wgrad_slots_kernel
 
 #define GMK_REQUIRE(cond, ...)                 \
     do {                                       \

@@ -24,3 +24,8 @@ int gmk_check_launch(const char* what) {
 
 extern "C" int gmk_version(void) { return 1; }
 extern "C" const char* gmk_last_error(void) { return g_err; }
+
+// which kernel the last gmk_conv_igemm / gmk_conv_wgrad call of this thread launched (profiling aid, see bench.py)
+static thread_local int g_last_kernel = 0;
+void gmk_note_kernel(int id) { g_last_kernel = id; }
+extern "C" int gmk_last_kernel(void) { return g_last_kernel; }

@@ -18,6 +18,10 @@ NORMAL, STRIDE2, UPSAMPLE2, TRANSPOSED2 = 0, 1, 2, 3
 PROFILE = None
 
 
+KERNEL_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_dma_kernel", 3: "conv3x3_halo_kernel", 11: "conv_wgrad_kernel",
+                12: "conv_wgrad_slots_kernel"}
+
+
 class _Timed:
     def __init__(self, name, flops):
         self.on = PROFILE is not None
@@ -33,7 +37,7 @@ class _Timed:
     def __exit__(self, *exc):
         if self.on:
             self.e.record()
-            PROFILE.append((self.name, self.s, self.e, self.flops))
+            PROFILE.append((KERNEL_NAMES.get(lib.gmk_last_kernel(), self.name), self.s, self.e, self.flops))
 
 
 def dt_code(dtype):

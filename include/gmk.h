@@ -32,6 +32,9 @@ extern "C" {
 
 int gmk_version(void);
 const char* gmk_last_error(void);
+/* profiling aid: which kernel the calling thread's last gmk_conv_igemm / gmk_conv_wgrad launched
+ * (1 conv_igemm_kernel, 2 conv_igemm_dma_kernel, 3 conv3x3_halo_kernel, 11 conv_wgrad_kernel, 12 conv_wgrad_slots_kernel) */
+int gmk_last_kernel(void);
 /* number of bytes of scratch gmk_conv_wgrad needs for the given problem (split-K slabs) */
 int64_t gmk_conv_wgrad_workspace_bytes(int64_t n_pixels, int taps, int cout, int ktot);
 
