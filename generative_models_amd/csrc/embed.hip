@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                       const float* __restrict__ Bm, int64_t sb0, int64_t sb1,
                                                       float* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                       const float* __restrict__ bias, const float* __restrict__ rowscale,
-                                                      int silu, int accumulate) {
+                                                      int silu, int accumulate, float* __restrict__ ws, int kchunk) {
     __shared__ float As[TK][TM + 4];
     __shared__ float Bs[TK][TN + 4];
     const int tid = threadIdx.x;
@@ -44,7 +44,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += TK) {
+    // split-K: slice blockIdx.z covers k in [z*kchunk, (z+1)*kchunk) and, when there is more than one slice, writes its
+    // raw partial sums to ws[z][M][N]; gemm_splitk_reduce_kernel then applies bias / rowscale / accumulate
+    const int kbeg = blockIdx.z * kchunk;
+    if (gridDim.z > 1) K = min(K, kbeg + kchunk);
+    for (int k0 = kbeg; k0 < K; k0 += TK) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = tid + e * 256;              // 1024 elements per tile
@@ -82,6 +86,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
         __syncthreads();
     }
+    if (gridDim.z > 1) {
+        float* w = ws + (int64_t)blockIdx.z * M * N;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int i = i0 + ty * 4 + x;
+            if (i >= M) continue;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const int j = j0 + tx * 4 + y;
+                if (j < N) w[(int64_t)i * N + j] = acc[x][y];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
         const int i = i0 + ty * 4 + x;
@@ -96,6 +114,55 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             float* c = C + (int64_t)i * ldc + j;
             *c = accumulate ? *c + v : v;
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc,
+                                                               int M, int N, int nz, const float* __restrict__ bias,
+                                                               const float* __restrict__ rowscale, int accumulate) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
+    float s = 0.f;
+    for (int z = 0; z < nz; ++z) s += ws[(int64_t)z * M * N + idx];
+    float v = (s + (bias ? bias[j] : 0.f)) * (rowscale ? rowscale[i] : 1.f);
+    float* c = C + (int64_t)i * ldc + j;
+    *c = accumulate ? *c + v : v;
+}
+
+// up to 16 independent column sums per launch: out_k[c] = sum_r part_k[r*stride_k + c]
+struct ColsumTable {
+    const float* part[16]; long long stride[16]; float* out[16]; int R[16]; int C[16];
+};
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const ColsumTable t) {
+    __shared__ float red[8][33];
+    const int k = blockIdx.y;
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int R = t.R[k], C = t.C[k];
+    if (blockIdx.x * 32 >= C) return;
+    const float* part = t.part[k];
+    const long long stride = t.stride[k];
+    float s = 0.f;
+    if (c < C) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int r = rl;
+        for (; r + 24 < R; r += 32) {
+            s0 += part[(long long)r * stride + c];
+            s1 += part[(long long)(r + 8) * stride + c];
+            s2 += part[(long long)(r + 16) * stride + c];
+            s3 += part[(long long)(r + 24) * stride + c];
+        }
+        for (; r < R; r += 8) s0 += part[(long long)r * stride + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v += red[i][cl];
+        t.out[k][c] = v;
     }
 }
 
@@ -132,16 +199,60 @@ extern "C" int gmk_guide_onehot(const int64_t* guide, float* onehot, float* keep
     return gmk_check_launch("gmk_guide_onehot");
 }
 
+static int gemm_ksplit(int M, int N, int K, int* kchunk) {
+    const int tiles = ((N + TN - 1) / TN) * ((M + TM - 1) / TM);
+    int nz = 1;
+    if (tiles < 128 && K >= 256) {
+        nz = (256 + tiles - 1) / tiles;
+        if (nz > K / 64) nz = K / 64;
+        if (nz > 32) nz = 32;
+        if (nz < 1) nz = 1;
+    }
+    int kc = (K + nz - 1) / nz;
+    kc = (kc + TK - 1) / TK * TK;
+    nz = (K + kc - 1) / kc;
+    *kchunk = kc;
+    return nz;
+}
+
+extern "C" int64_t gmk_gemm_f32_workspace_bytes(int M, int N, int K) {
+    int kc;
+    const int nz = gemm_ksplit(M, N, K, &kc);
+    return nz > 1 ? (int64_t)nz * M * N * 4 : 0;
+}
+
 extern "C" int gmk_gemm_f32(const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1, float* C,
                             int64_t ldc, int M, int N, int K, const float* bias, const float* rowscale, int silu,
-                            int accumulate, void* stream) {
+                            int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
     GMK_REQUIRE(A && B && C, "gmk_gemm_f32: null pointer");
     GMK_REQUIRE(M > 0 && N > 0 && K > 0 && ldc >= N, "gmk_gemm_f32: bad shape M=%d N=%d K=%d ldc=%lld", M, N, K,
                 (long long)ldc);
-    dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM);
+    int kc;
+    int nz = gemm_ksplit(M, N, K, &kc);
+    if (nz > 1 && (!workspace || workspace_bytes < (int64_t)nz * M * N * 4)) { nz = 1; kc = K; }
+    dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM, nz);
     gemm_f32_kernel<<<grid, 256, 0, gmk_stream(stream)>>>(A, sa0, sa1, B, sb0, sb1, C, ldc, M, N, K, bias, rowscale, silu,
-                                                          accumulate);
-    return gmk_check_launch("gmk_gemm_f32");
+                                                          accumulate, (float*)workspace, kc);
+    int rc = gmk_check_launch("gmk_gemm_f32");
+    if (rc || nz == 1) return rc;
+    const int64_t n = (int64_t)M * N;
+    gemm_splitk_reduce_kernel<<<(int)((n + 255) / 256), 256, 0, gmk_stream(stream)>>>((const float*)workspace, C, ldc, M, N, nz,
+                                                                                       bias, rowscale, accumulate);
+    return gmk_check_launch("gmk_gemm_f32(reduce)");
+}
+
+extern "C" int gmk_colsum_multi(int n, const float* const* part, const int64_t* stride, float* const* out, const int* R,
+                                const int* C, void* stream) {
+    GMK_REQUIRE(n >= 1 && n <= 16 && part && stride && out && R && C, "gmk_colsum_multi: bad arguments (1 <= n <= 16)");
+    ColsumTable t;
+    int cmax = 0;
+    for (int k = 0; k < n; ++k) {
+        GMK_REQUIRE(part[k] && out[k] && R[k] > 0 && C[k] > 0 && stride[k] >= C[k], "gmk_colsum_multi: bad problem %d", k);
+        t.part[k] = part[k]; t.stride[k] = stride[k]; t.out[k] = out[k]; t.R[k] = R[k]; t.C[k] = C[k];
+        if (C[k] > cmax) cmax = C[k];
+    }
+    colsum_multi_kernel<<<dim3((cmax + 31) / 32, n), 256, 0, gmk_stream(stream)>>>(t);
+    return gmk_check_launch("gmk_colsum_multi");
 }
 
 extern "C" int gmk_silu_bwd(const float* dpost, const float* pre, const float* rowscale, float* dpre, int64_t n, int ncols,

@@ -105,13 +105,13 @@ class GaussianDiffusion:
             eps = self.rng.normal(x.shape, x.device)          # :83
         if u is None:
             u = self.rng.uniform((x.shape[0],), x.device)     # :94 continuous time
-        return u.contiguous().float(), eps.contiguous().float()
+        return ops.aligned(u.float()), ops.aligned(eps.float())
 
     def training_losses(self, *, net, x, u=None, eps=None):
         """Reference call shape (:81).  Differentiable through torch.autograd when grad mode is on."""
         assert x.dtype in [torch.float32, torch.float64]
         module, guide, cond_w = _unwrap(net)
-        x = x.contiguous().float()
+        x = ops.aligned(x.float())
         u, eps = self._draw(x, u, eps)
         logsnr, z_t = ops.q_sample(x, eps, u)
         v = module(z_t, logsnr, guide=guide, cond_w=cond_w)
@@ -125,7 +125,7 @@ class GaussianDiffusion:
         """Fused training pass used by DiffusionModel.train_step: forward, loss, dL/dv and the explicit backward
         schedule, leaving d(grad_scale * sum_b loss_b)/d(theta) in `module.flat_grads`.  No autograd graph."""
         module, guide, cond_w = _unwrap(net)
-        x = x.contiguous().float()
+        x = ops.aligned(x.float())
         u, eps = self._draw(x, u, eps)
         logsnr, z_t = ops.q_sample(x, eps, u)
         ctx = {}
@@ -152,14 +152,14 @@ class GaussianDiffusion:
             elif self.sample_cond_w is not None and float(self.sample_cond_w) != -1.0:
                 w = torch.full((B,), float(self.sample_cond_w), device=dev)
             else:
-                w = net_cond_w.contiguous().float()                   # :257
+                w = ops.aligned(net_cond_w.float())                   # :257
         else:
             w = None
         if self.sampler not in ("ddim", "noisy"):
             raise NotImplementedError(self.sampler)
         if w is not None and guide is None:
             raise ValueError("classifier-free guidance needs class labels (net must carry guide=)")
-        z_t = init_x.contiguous().float()
+        z_t = ops.aligned(init_x.float())
         zs, xs, es = [], [], []
         if w is not None:       # conditional + unconditional evaluations share one 2B-image forward (:176-177)
             guide2 = torch.cat([guide, -torch.ones_like(guide)])
@@ -176,7 +176,7 @@ class GaussianDiffusion:
                 v, vu = v2[:B], v2[B:]
             noise = None
             if self.sampler == "noisy":
-                noise = noises[i].contiguous() if noises is not None else self.rng.normal(z_t.shape, dev)   # :241
+                noise = ops.aligned(noises[i]) if noises is not None else self.rng.normal(z_t.shape, dev)   # :241
             z_t, xp, ep = ops.sampler_step(v, z_t, lt, ls, i == 0, v_uncond=vu, cond_w=w, noise=noise, want_pred=record)
             if record:
                 zs.append(z_t); xs.append(xp); es.append(ep)

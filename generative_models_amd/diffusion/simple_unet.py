@@ -223,11 +223,11 @@ class SimpleUnet(nn.Module):
         x, h1, rowscale = ctx[prefix]
         d = ops.scale_rows(demb, rowscale) if rowscale is not None else demb
         ops.gemm(d.t(), h1, out=G[f"{prefix}.2.weight"], silu_b=True)      # dW2 = d^T . silu(h1)
-        ops.colsum(d, G[f"{prefix}.2.bias"])
+        ops.colsum(d, G[f"{prefix}.2.bias"], defer=True)
         dsh = ops.gemm(d, P[f"{prefix}.2.weight"])
         dh1 = ops.silu_bwd(dsh, h1)
         ops.gemm(dh1.t(), x, out=G[f"{prefix}.0.weight"])
-        ops.colsum(dh1, G[f"{prefix}.0.bias"])
+        ops.colsum(dh1, G[f"{prefix}.0.bias"], defer=True)
 
     def _embed_fwd(self, logsnr, guide, cond_w, ctx):
         dev = logsnr.device
@@ -259,7 +259,7 @@ class SimpleUnet(nn.Module):
         gw = self.flat_grads[o0:o0 + 12 * C * 2 * C].view(12 * C, 2 * C)
         gb = self.flat_grads[b0:b0 + 12 * C]
         ops.gemm(demb_all.t(), emb, out=gw, silu_b=True)        # dWcat[n][k] = sum_b dE[b][n] * silu(emb)[b][k]
-        ops.colsum(demb_all, gb)
+        ops.colsum(demb_all, gb, defer=True)
         dsemb = ops.gemm(demb_all, wcat)
         demb = ops.silu_bwd(dsemb, emb)
         self._mlp_bwd("time_embed", ctx, demb)
@@ -303,19 +303,19 @@ class SimpleUnet(nn.Module):
         B, H, W, _ = dout.shape
         two = len(srcs) == 2
         # conv2 (out_layers.3)
-        ops.colsum(dout_sum, G[f"{name}.out_layers.3.bias"])
+        ops.colsum(dout_sum, G[f"{name}.out_layers.3.bias"], defer=True)
         ops.conv_wgrad(dout, [a2], 3, ops.NORMAL, G[f"{name}.out_layers.3.weight"])
         _, wd2 = self._packs[f"{name}.out_layers.3"]
         da2 = ops.conv_igemm([dout], wd2, C, 3, ops.NORMAL, (H, W))
         dh, dgp, dbp = ops.gn_silu_bwd(da2, h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], mean2,
                                        rstd2, dxsum=demb_all[:, blk * C:(blk + 1) * C])
-        ops.colsum(dgp, G[f"{name}.out_layers.0.weight"]); ops.colsum(dbp, G[f"{name}.out_layers.0.bias"])
+        ops.colsum(dgp, G[f"{name}.out_layers.0.weight"], defer=True); ops.colsum(dbp, G[f"{name}.out_layers.0.bias"], defer=True)
         # conv1 (in_layers.2): bias gradient = column sum of the embedding gradient slice (both are sum_hw dh)
-        ops.colsum(demb_all[:, blk * C:(blk + 1) * C], G[f"{name}.in_layers.2.bias"])
+        ops.colsum(demb_all[:, blk * C:(blk + 1) * C], G[f"{name}.in_layers.2.bias"], defer=True)
         ops.conv_wgrad(dh, a, 3, ops.NORMAL, G[f"{name}.in_layers.2.weight"])
         _, wd1 = self._packs[f"{name}.in_layers.2"]
         if two:
-            ops.colsum(dout_sum, G[f"{name}.skip_connection.bias"])
+            ops.colsum(dout_sum, G[f"{name}.skip_connection.bias"], defer=True)
             ops.conv_wgrad(dout, srcs, 1, ops.NORMAL, G[f"{name}.skip_connection.weight"])
             _, wds = self._packs[f"{name}.skip_connection"]
         outs = []
@@ -331,7 +331,7 @@ class SimpleUnet(nn.Module):
             ds, dgp, dbp = ops.gn_silu_bwd(da, s, P[f"{name}.in_layers.0.weight"][i * C:(i + 1) * C],
                                            P[f"{name}.in_layers.0.bias"][i * C:(i + 1) * C], stats1[i][0], stats1[i][1],
                                            dadd1=dskip, dadd2=add2, dxsum=ssum)
-            ops.colsum(dgp, gw[i * C:(i + 1) * C]); ops.colsum(dbp, gb[i * C:(i + 1) * C])
+            ops.colsum(dgp, gw[i * C:(i + 1) * C], defer=True); ops.colsum(dbp, gb[i * C:(i + 1) * C], defer=True)
             outs.append((ds, ssum))
         return outs
 
@@ -344,7 +344,8 @@ class SimpleUnet(nn.Module):
         B, cin, H, W = x.shape
         if cin != self.in_channels or H % 4 or W % 4:
             raise ValueError(f"input {tuple(x.shape)}: need {self.in_channels} channels and H, W divisible by 4")
-        x = x.contiguous().float()
+        x = ops.aligned(x.float())
+        logsnr, guide, cond_w = ops.aligned(logsnr), ops.aligned(guide), ops.aligned(cond_w)
         emb_all = self._embed_fwd(logsnr, guide, cond_w, ctx)
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         t0 = ops.stem_fwd(x, P["down.seq.0.conv.weight"], P["down.seq.0.conv.bias"], C, T)
@@ -404,7 +405,7 @@ class SimpleUnet(nn.Module):
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         x, t2, t5, u0r, u3r, u6, ao, mo, ro = ctx["net"]
         dev = dout.device
-        dout = dout.contiguous().float()
+        dout = ops.aligned(dout.float())
         demb_all = torch.empty((B, 12 * C), device=dev, dtype=torch.float32)
 
         # head: out.2 conv + out.0 GroupNorm/SiLU
@@ -415,14 +416,15 @@ class SimpleUnet(nn.Module):
         dao = ops.head_dgrad(dout, P["out.2.weight"], T)
         s6 = torch.empty((B, C), device=dev, dtype=torch.float32)
         du6, dgp, dbp = ops.gn_silu_bwd(dao, u6, P["out.0.weight"], P["out.0.bias"], mo, ro, dxsum=s6)
-        ops.colsum(dgp, G["out.0.weight"]); ops.colsum(dbp, G["out.0.bias"])
+        ops.colsum(dgp, G["out.0.weight"], defer=True); ops.colsum(dbp, G["out.0.bias"], defer=True)
 
         (du5, s5), (dt0a, _) = self._res_bwd("up.seq.6", ctx, du6, s6, demb_all, 11)
         (du4, s4), (dt1a, _) = self._res_bwd("up.seq.5", ctx, du5, s5, demb_all, 10)
         (du3, s3), (dt2a, _) = self._res_bwd("up.seq.4", ctx, du4, s4, demb_all, 9)
+        ops.flush_colsums()
         ready(0)
         # up.seq.3.1: nearest x2 + conv
-        ops.colsum(s3, G["up.seq.3.1.conv.bias"])
+        ops.colsum(s3, G["up.seq.3.1.conv.bias"], defer=True)
         ops.conv_wgrad(du3, [u3r], 3, ops.UPSAMPLE2, G["up.seq.3.1.conv.weight"])
         dU = ops.conv_igemm([du3], self._packs["up.seq.3.1.conv"][1], C, 3, ops.NORMAL, (H, W))
         du3r = ops.sumpool2x2(dU)
@@ -430,31 +432,34 @@ class SimpleUnet(nn.Module):
         (du2, s2), (dt3a, _) = self._res_bwd("up.seq.3.0", ctx, du3r, s3r, demb_all, 8)
         (du1, s1), (dt4a, _) = self._res_bwd("up.seq.2", ctx, du2, s2, demb_all, 7)
         (du0, s0), (dt5a, _) = self._res_bwd("up.seq.1", ctx, du1, s1, demb_all, 6)
-        ops.colsum(s0, G["up.seq.0.1.conv.bias"])
+        ops.colsum(s0, G["up.seq.0.1.conv.bias"], defer=True)
         ops.conv_wgrad(du0, [u0r], 3, ops.UPSAMPLE2, G["up.seq.0.1.conv.weight"])
         dU = ops.conv_igemm([du0], self._packs["up.seq.0.1.conv"][1], C, 3, ops.NORMAL, (H2, W2))
         du0r = ops.sumpool2x2(dU)
         s0r = ops.chansum(du0r)
         (dt7, s7), (dt6a, _) = self._res_bwd("up.seq.0.0", ctx, du0r, s0r, demb_all, 5)
+        ops.flush_colsums()
         ready(1)
         ((dt6, s6t),) = self._res_bwd("turn", ctx, dt7, s7, demb_all, 4, extra_add=[dt6a])
         # down.seq.6: stride-2 conv; its data gradient is the transposed gather
-        ops.colsum(s6t, G["down.seq.6.conv.bias"])
+        ops.colsum(s6t, G["down.seq.6.conv.bias"], defer=True)
         ops.conv_wgrad(dt6, [t5], 3, ops.STRIDE2, G["down.seq.6.conv.weight"])
         dt5 = ops.conv_igemm([dt6], self._packs["down.seq.6.conv"][1], C, 3, ops.TRANSPOSED2, (H2, W2), residual=dt5a)
         s5t = ops.chansum(dt5)
         ((dt4, s4t),) = self._res_bwd("down.seq.5", ctx, dt5, s5t, demb_all, 3, extra_add=[dt4a])
         ((dt3, s3t),) = self._res_bwd("down.seq.4", ctx, dt4, s4t, demb_all, 2, extra_add=[dt3a])
-        ops.colsum(s3t, G["down.seq.3.conv.bias"])
+        ops.colsum(s3t, G["down.seq.3.conv.bias"], defer=True)
         ops.conv_wgrad(dt3, [t2], 3, ops.STRIDE2, G["down.seq.3.conv.weight"])
         dt2 = ops.conv_igemm([dt3], self._packs["down.seq.3.conv"][1], C, 3, ops.TRANSPOSED2, (H, W), residual=dt2a)
         s2t = ops.chansum(dt2)
         ((dt1, s1t),) = self._res_bwd("down.seq.2", ctx, dt2, s2t, demb_all, 1, extra_add=[dt1a])
         ((dt0, s0t),) = self._res_bwd("down.seq.1", ctx, dt1, s1t, demb_all, 0, extra_add=[dt0a])
-        ops.colsum(s0t, G["down.seq.0.conv.bias"])
+        ops.colsum(s0t, G["down.seq.0.conv.bias"], defer=True)
         ops.stem_wgrad(x, dt0, G["down.seq.0.conv.weight"])
+        ops.flush_colsums()
         ready(2)
         self._embed_bwd(ctx, demb_all)
+        ops.flush_colsums()
         ready(3)
 
     def zero_grad_arena(self):

@@ -64,6 +64,14 @@ def _chk(t, dtype=None, name="tensor"):
     return t
 
 
+def aligned(t):
+    """Contiguous, 16-byte aligned version of a caller-supplied tensor (a slice of a batch may start anywhere)."""
+    if t is None:
+        return None
+    t = t.contiguous()
+    return t.clone() if t.data_ptr() % 16 else t
+
+
 def _f32(t, name):
     return _chk(t, torch.float32, name)
 
@@ -125,12 +133,37 @@ def chansum(x, out=None):
     return out
 
 
-def colsum(part, out, accumulate=False):
-    """out[c] (+)= sum_r part[r, c]; part fp32 [R, C] with unit column stride, out fp32 [C] (any contiguous view)."""
+_PENDING_COLSUMS = []      # (part, out) pairs deferred into gmk_colsum_multi launches of up to 16
+
+
+def colsum(part, out, accumulate=False, defer=False):
+    """out[c] (+)= sum_r part[r, c]; part fp32 [R, C] with unit column stride, out fp32 [C] (any contiguous view).
+    defer=True queues the reduction (same stream order) until flush_colsums(); `part` is kept alive until then."""
     assert part.dtype == torch.float32 and part.dim() == 2 and part.stride(1) == 1 and part.is_cuda
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == part.shape[1]
+    if defer and not accumulate:
+        _PENDING_COLSUMS.append((part, out))
+        if len(_PENDING_COLSUMS) >= 16:
+            flush_colsums()
+        return out
     check(lib.gmk_colsum(_p(part), part.stride(0), _p(out), part.shape[0], part.shape[1], int(accumulate), _s()), "colsum")
     return out
+
+
+def flush_colsums():
+    import ctypes
+    while _PENDING_COLSUMS:
+        batch = _PENDING_COLSUMS[:16]
+        del _PENDING_COLSUMS[:16]
+        n = len(batch)
+        parts = (ctypes.c_void_p * n)(*[b[0].data_ptr() for b in batch])
+        outs = (ctypes.c_void_p * n)(*[b[1].data_ptr() for b in batch])
+        strides = (ctypes.c_int64 * n)(*[b[0].stride(0) for b in batch])
+        Rs = (ctypes.c_int * n)(*[b[0].shape[0] for b in batch])
+        Cs = (ctypes.c_int * n)(*[b[0].shape[1] for b in batch])
+        check(lib.gmk_colsum_multi(n, ctypes.cast(parts, ctypes.c_void_p), ctypes.cast(strides, ctypes.c_void_p),
+                                   ctypes.cast(outs, ctypes.c_void_p), ctypes.cast(Rs, ctypes.c_void_p),
+                                   ctypes.cast(Cs, ctypes.c_void_p), _s()), "colsum_multi")
 
 
 def sumpool2x2(x):
@@ -186,8 +219,8 @@ def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, 
 _WS = {}
 
 
-def _workspace(nbytes, device):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+def _workspace(nbytes, device, tag="conv"):
+    key = (tag, device.index, torch.cuda.current_stream().cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
@@ -303,8 +336,11 @@ def gemm(A, B, out=None, bias=None, rowscale=None, silu_a=False, silu_b=False, a
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     if rowscale is not None:
         assert rowscale.dtype == torch.float32 and rowscale.numel() == M and rowscale.is_contiguous()
+    need = lib.gmk_gemm_f32_workspace_bytes(M, N, K)
+    wsb = _workspace(need, A.device, "gemm") if need else None
     check(lib.gmk_gemm_f32(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(out), out.stride(0), M, N, K,
-                           _p(bias), _p(rowscale), int(silu_a) | (int(silu_b) << 1), int(accumulate), _s()), "gemm_f32")
+                           _p(bias), _p(rowscale), int(silu_a) | (int(silu_b) << 1), int(accumulate), _p(wsb), need, _s()),
+          "gemm_f32")
     return out
 
 

@@ -62,6 +62,9 @@ int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma, const flo
 int gmk_chansum(const void* x, float* out, int out_stride, int B, int HW, int C, int dtype, void* stream);
 /* out[c] (+)= sum_r part[r*stride + c], r < R, c < C  (fp32) */
 int gmk_colsum(const float* part, int64_t stride, float* out, int R, int C, int accumulate, void* stream);
+/* up to 16 independent gmk_colsum problems in one launch (host arrays of length n) */
+int gmk_colsum_multi(int n, const float* const* part, const int64_t* stride, float* const* out, const int* R,
+                     const int* C, void* stream);
 /* 2x2 sum-pool NHWC [B][2H][2W][C] -> [B][H][W][C]: backward of F.interpolate(nearest, x2), simple_unet.py:120 */
 int gmk_sumpool2x2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 
@@ -116,7 +119,9 @@ int gmk_guide_onehot(const int64_t* guide, float* onehot, float* keep, int B, vo
  * of the embedding path. */
 int gmk_gemm_f32(const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1, float* C,
                  int64_t ldc, int M, int N, int K, const float* bias, const float* rowscale, int silu,
-                 int accumulate, void* stream);
+                 int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+/* scratch the GEMM wants for its deterministic split-K (few output tiles, long K); 0 if none */
+int64_t gmk_gemm_f32_workspace_bytes(int M, int N, int K);
 /* dpre[i] = dpost[i] * SiLU'(pre[i]) * (rowscale ? rowscale[i / ncols] : 1) */
 int gmk_silu_bwd(const float* dpost, const float* pre, const float* rowscale, float* dpre, int64_t n, int ncols,
                  void* stream);

@@ -195,6 +195,16 @@ def test_embedding_path(ops, golden):
     assert rel_err(out2, ref + A @ Bm) < 1e-5
     out3 = ops.gemm(A.cuda().t(), A.cuda(), silu_b=True)
     assert rel_err(out3, A.t() @ F.silu(A)) < 1e-5
+    # long-K shapes take the deterministic split-K path; batched deferred column sums
+    A2, B2 = rnd(1024, 200, seed=56), rnd(1024, 70, seed=57)
+    assert rel_err(ops.gemm(A2.cuda().t(), B2.cuda(), silu_b=True), A2.t() @ F.silu(B2)) < 1e-5
+    parts = [rnd(300 + 7 * k, 40 + 11 * k, seed=60 + k).cuda() for k in range(19)]
+    outs = [torch.empty(p_.shape[1], device="cuda") for p_ in parts]
+    for p_, o_ in zip(parts, outs):
+        ops.colsum(p_, o_, defer=True)
+    ops.flush_colsums()
+    for p_, o_ in zip(parts, outs):
+        assert rel_err(o_, p_.sum(0)) < 1e-5
     pre = rnd(9, 33, seed=54).requires_grad_(True)
     d = rnd(9, 33, seed=55)
     F.silu(pre).backward(d)
