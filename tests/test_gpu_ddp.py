@@ -38,6 +38,7 @@ def make():
 # single-rank reference on the whole batch
 ref = make(); dref = GaussianDiffusion(mean_type="v", num_steps=4); oref = FusedAdam(ref)
 dref.train_forward_backward(net=partial(ref, guide=y), x=x, grad_scale=1.0 / B, u=u, eps=eps)
+gref = ref.flat_grads.clone()
 oref.step()
 # sharded
 net = make(); sync = parallel.GradSync(net); sync.broadcast_params(0)
@@ -46,10 +47,14 @@ sl = slice(r * B // w, (r + 1) * B // w)
 d.train_forward_backward(net=partial(net, guide=y[sl]), x=x[sl], grad_scale=1.0 / (B // w), u=u[sl], eps=eps[sl],
                          on_grads_ready=sync.hook)
 sync.finish()
+# mean over ranks of the per-shard mean gradients == gradient of the whole-batch mean (equal shards)
+gdiff = float((net.flat_grads / w - gref).abs().max()) / float(gref.abs().max())
+assert gdiff < 1e-4, gdiff
 opt.step(grad_scale=1.0 / w)
 gerr = float((net.flat_params - ref.flat_params).abs().max())
 delta = float((ref.flat_params - make().flat_params).abs().max())
-assert delta > 1e-5 and gerr < 2e-3 * delta + 1e-7, (gerr, delta)
+# the first Adam step is ~ lr * sign(g): elements whose gradient is rounding noise may differ by a fraction of lr
+assert delta > 1e-5 and gerr < 0.1 * delta, (gerr, delta)
 dist.destroy_process_group()
 print("rank", r, "ok", gerr, delta)
 """

@@ -91,8 +91,8 @@ def test_unet_forward_backward_vs_oracle(dtype, in_channels, S):
             continue
         err = float((net.grad(name).cpu() - v.grad).abs().max())
         scale = max(float(v.grad.abs().max()), 1e-3 * gmax)
-        # gradients compound the forward and the backward rounding: 3x the forward bar at fp32, 5x at bf16
-        if err > (3 if dtype == torch.float32 else 5) * TOL[dtype] * scale:
+        # gradients compound the forward and the backward rounding: 3x the forward bar at fp32, 6x at bf16
+        if err > (3 if dtype == torch.float32 else 6) * TOL[dtype] * scale:
             bad.append((name, err, scale))
     assert not bad, bad[:8]
 

@@ -52,14 +52,15 @@ def main():
         t2 = timed(lambda: ops.conv_wgrad(dy, srcs, ks, ops.NORMAL, dw), a.iters)
         print(f"{name:22s} fwd {t * 1e6:8.1f} us {flops / t / 1e12:7.1f} TF/s | wgrad {t2 * 1e6:8.1f} us {flops / t2 / 1e12:7.1f} TF/s",
               flush=True)
-    x = torch.randn((B, 28, 28, C), device="cuda").to(T)
-    g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
-    t = timed(lambda: ops.gn_silu_fwd(x, g, b, 32), a.iters)
-    nbytes = x.numel() * x.element_size()
-    print(f"gn_silu_fwd @28 {t * 1e6:8.1f} us  {3 * nbytes / t / 1e12:.2f} TB/s (2 reads + 1 write)")
-    y, mean, rstd = ops.gn_silu_fwd(x, g, b, 32)
-    t = timed(lambda: ops.gn_silu_bwd(x, x, g, b, mean, rstd), a.iters)
-    print(f"gn_silu_bwd @28 {t * 1e6:8.1f} us  {5 * nbytes / t / 1e12:.2f} TB/s (4 reads + 1 write)")
+    for S in (28, 14, 7):
+        x = torch.randn((B, S, S, C), device="cuda").to(T)
+        g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
+        t = timed(lambda: ops.gn_silu_fwd(x, g, b, 32), a.iters)
+        nbytes = x.numel() * x.element_size()
+        print(f"gn_silu_fwd @{S} {t * 1e6:8.1f} us  {2 * nbytes / t / 1e12:.2f} TB/s of (1 read + 1 write)")
+        y, mean, rstd = ops.gn_silu_fwd(x, g, b, 32)
+        t = timed(lambda: ops.gn_silu_bwd(x, x, g, b, mean, rstd), a.iters)
+        print(f"gn_silu_bwd @{S} {t * 1e6:8.1f} us  {3 * nbytes / t / 1e12:.2f} TB/s of (2 reads + 1 write)")
 
 
 if __name__ == "__main__":
