@@ -40,6 +40,7 @@ struct HaloParams {
     const void* src0; const void* src1;
     int c0, c1, ktot;
     int B, H, W, WE, R, TP, ntiles, rows_total;
+    int shift;                                 // 1: the source is the half-resolution tensor (nearest x2 upsample folded in)
     const void* w; unsigned w_tap_stride_b; int n0;
     const float* bias; const float* emb; int emb_stride;
     const void* residual; void* out; int out_cstride; int M;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
             const int x = xe - 1;
             const int b = b0 + k;
             const bool ok = exists && y >= 0 && y < H && x >= 0 && x < W && b < p.B;
-            hpix[j] = ok ? (unsigned)((b * H + y) * W + x) : kBadPix;
+            hpix[j] = ok ? (unsigned)((b * (H >> p.shift) + (y >> p.shift)) * (W >> p.shift) + (x >> p.shift)) : kBadPix;
             er += f_der; xe += f_dxe;
             if (xe >= WE) { xe -= WE; ++er; }
         }
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
 // Returns 1 if the halo kernel was launched, 0 if the problem is not eligible (caller falls back), <0 / >0 on error.
 int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int B, int H, int W, const void* w, int w_rows,
                          int n0, int cout, const float* bias, const float* emb, int emb_stride, const void* residual,
-                         void* out, int out_cstride, int min_tiles, hipStream_t stream) {
+                         void* out, int out_cstride, int min_tiles, int upsample, hipStream_t stream) {
     if (c0 % 64 || c1 % 64 || cout % 128) return 0;
     if (W < 4 || W > 254 || H < 2) return 0;
     const int R = 256 / W;
@@ -323,7 +324,9 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     if (ner * (W + 2) > kHaloSlots) return 0;
     const int64_t rows_total = (int64_t)B * H;
     const int64_t M = rows_total * W;
-    const int64_t nb0 = M * c0 * 2, nb1 = M * c1 * 2;
+    if (upsample && ((H | W) & 1)) return 0;
+    const int64_t Msrc = upsample ? M / 4 : M;
+    const int64_t nb0 = Msrc * c0 * 2, nb1 = Msrc * c1 * 2;
     const int64_t nbw = (int64_t)9 * w_rows * (c0 + c1) * 2, nbo = M * out_cstride * 2;
     const int64_t lim = 0xFFFF0000ll;     // below (kBadPix * bytes-per-pixel) mod 2^32 for pixels of up to 4 KiB
     if (nb0 >= lim || nb1 >= lim || nbw >= lim || nbo >= lim || M >= 0x00FFFFFF || c0 > 2048 || c1 > 2048) return 0;
@@ -331,6 +334,7 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     if (ntiles < min_tiles) return 0;                         // not enough tiles to fill the chip: im2col kernels
     HaloParams p;
     p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.ktot = c0 + c1;
+    p.shift = upsample ? 1 : 0;
     p.B = B; p.H = H; p.W = W; p.WE = W + 2; p.R = R; p.TP = TP; p.ntiles = (int)ntiles; p.rows_total = (int)rows_total;
     p.w = w; p.w_tap_stride_b = (unsigned)w_rows * (unsigned)(c0 + c1) * 2u; p.n0 = n0;
     p.bias = bias; p.emb = emb; p.emb_stride = emb_stride; p.residual = residual; p.out = out; p.out_cstride = out_cstride;

@@ -820,10 +820,11 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
     p.bias = bias; p.emb = emb; p.emb_stride = emb_stride; p.residual = residual; p.out = out;
     p.out_cstride = out_cstride; p.M = B * ho * wo;
     // kernel choice: 0 = automatic, 1 = register-staged 128x128, 2 = LDS-DMA im2col 256x128, 3 = LDS halo (3x3 s1 bf16)
-    static const int force = getenv("GMK_CONV_KERNEL") ? atoi(getenv("GMK_CONV_KERNEL")) : 0;
-    if ((force == 0 || force == 3) && dtype == GMK_BF16 && mode == GMK_CONV_NORMAL && ksize == 3) {
-        const int rc = gmk_conv3x3_halo_try(src0, src1, c0, c1, B, hs, ws, w, w_rows, n0, cout, bias, emb, emb_stride, residual,
-                                            out, out_cstride, force == 3 ? 1 : 256, gmk_stream(stream));
+    const int force = gmk_kernel_choice(0, "GMK_CONV_KERNEL");
+    if ((force == 0 || force == 3) && dtype == GMK_BF16 && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2) && ksize == 3) {
+        const int rc = gmk_conv3x3_halo_try(src0, src1, c0, c1, B, ho, wo, w, w_rows, n0, cout, bias, emb, emb_stride, residual,
+                                            out, out_cstride, force == 3 ? 1 : 256, mode == GMK_CONV_UPSAMPLE2,
+                                            gmk_stream(stream));
         if (rc == 1) {
             gmk_note_kernel(3);
             return gmk_check_launch("gmk_conv_igemm(halo)");
@@ -872,10 +873,10 @@ extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, 
                 mode, hs, ws, ho, wo);
     const int taps = ksize * ksize;
     // kernel choice: 0 = automatic, 1 = im2col split-K, 2 = padded-slot correlation (3x3 s1 bf16)
-    static const int wforce = getenv("GMK_WGRAD_KERNEL") ? atoi(getenv("GMK_WGRAD_KERNEL")) : 0;
-    if (wforce != 1 && dtype == GMK_BF16 && mode == GMK_CONV_NORMAL && ksize == 3) {
-        const int ns2 = gmk_conv_wgrad_slots_try(dy, dy_cstride, src0, src1, c0, c1, B, hs, ws, cout, (float*)workspace,
-                                                 workspace_bytes, wforce == 2, gmk_stream(stream));
+    const int wforce = gmk_kernel_choice(1, "GMK_WGRAD_KERNEL");
+    if (wforce != 1 && dtype == GMK_BF16 && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2) && ksize == 3) {
+        const int ns2 = gmk_conv_wgrad_slots_try(dy, dy_cstride, src0, src1, c0, c1, B, ho, wo, cout, (float*)workspace,
+                                                 workspace_bytes, wforce == 2, mode == GMK_CONV_UPSAMPLE2, gmk_stream(stream));
         if (ns2 > 0) {
             gmk_note_kernel(12);
             int rc2 = gmk_check_launch("gmk_conv_wgrad(slots)");

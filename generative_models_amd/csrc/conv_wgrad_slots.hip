@@ -33,6 +33,7 @@ struct SlotParams {
     const void* src0; const void* src1;
     int c0, c1, ktot, cout;
     int B, H, W, WE;
+    int xshift;                  // 1: X is the half-resolution tensor (nearest x2 upsample folded into the gather)
     float* slab;                 // [nsplit][9][cout][ktot]
     int nchunks, chunks_per_split;
     unsigned nbdy, nb0, nb1;
@@ -89,6 +90,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_kernel(const SlotPara
         const bool ok = s.b >= 0 && s.b < p.B && s.ye >= 1 && s.ye <= H && s.xe >= 1 && s.xe <= W;
         return ok ? (unsigned)((s.b * H + s.ye - 1) * W + s.xe - 1) : kBadPix;
     };
+    auto xpix_of = [&](const SlotPos& s) -> unsigned {
+        const bool ok = s.b >= 0 && s.b < p.B && s.ye >= 1 && s.ye <= H && s.xe >= 1 && s.xe <= W;
+        const int sh = p.xshift;
+        return ok ? (unsigned)((s.b * (H >> sh) + ((s.ye - 1) >> sh)) * (W >> sh) + ((s.xe - 1) >> sh)) : kBadPix;
+    };
 
     // trackers: slot of this lane in the next X chunk / dY chunk to be issued
     int xc = c_begin - 1;                         // next X chunk index to issue
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_kernel(const SlotPara
     auto issue_x = [&]() {
         unsigned pix = kBadPix;
         if (xc >= 0) {
-            pix = pix_of(xpos);
+            pix = xpix_of(xpos);
             slot_advance(xpos, dxe64, dye64, H, WE);
         }
         const unsigned voff = __umul24(pix, xs_b) + xoff_b + x_lc;
@@ -204,7 +210,7 @@ int gmk_wgrad_slots_nsplit(int cout, int ktot) {
 
 // Returns the number of splits written (>= 1) if the slot kernel was launched, 0 if the problem is not eligible.
 int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B, int H,
-                             int W, int cout, float* slab, int64_t slab_bytes, int forced, hipStream_t stream) {
+                             int W, int cout, float* slab, int64_t slab_bytes, int forced, int upsample, hipStream_t stream) {
     if (c0 % 64 || c1 % 64 || cout % 128) return 0;
     const int WE = W + 2;
     if (WE + 1 > 64 || W < 4 || H < 2) return 0;
@@ -212,7 +218,9 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
     const int64_t M = (int64_t)B * H * W;
     const int64_t total = (int64_t)B * (H + 2) * WE;
     if (M >= 0x00FFFFFF || total >= (1ll << 30)) return 0;
-    const int64_t nbdy = M * dy_cstride * 2, nb0 = M * c0 * 2, nb1 = M * c1 * 2;
+    if (upsample && ((H | W) & 1)) return 0;
+    const int64_t Msrc = upsample ? M / 4 : M;
+    const int64_t nbdy = M * dy_cstride * 2, nb0 = Msrc * c0 * 2, nb1 = Msrc * c1 * 2;
     const int64_t lim = 0xFFFF0000ll;     // below (kBadPix * bytes-per-pixel) mod 2^32 for pixels of up to 4 KiB
     if (nbdy >= lim || nb0 >= lim || nb1 >= lim || c0 > 2048 || c1 > 2048 || dy_cstride > 2048) return 0;
     const int ktot = c0 + c1;
@@ -227,6 +235,7 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
     if ((int64_t)ns * 9 * cout * ktot * 4 > slab_bytes) return 0;
     SlotParams p;
     p.dy = dy; p.dy_cstride = dy_cstride; p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.ktot = ktot; p.cout = cout;
+    p.xshift = upsample ? 1 : 0;
     p.B = B; p.H = H; p.W = W; p.WE = WE; p.slab = slab; p.nchunks = nchunks; p.chunks_per_split = cps;
     p.nbdy = (unsigned)nbdy; p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1;
     dim3 grid(ns, ktot / 64, cout / 128);

@@ -18,6 +18,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // ---- host-side error plumbing (no exceptions cross the C ABI) -------------------------------
 void gmk_set_error(const char* fmt, ...);
 int gmk_check_launch(const char* what);   // returns 0 or the positive hipError_t of the launch
+int gmk_kernel_choice(int which, const char* env);   // 0 conv (GMK_CONV_KERNEL), 1 wgrad (GMK_WGRAD_KERNEL), 2 GN
 void gmk_note_kernel(int id);             // 1 conv_igemm_kernel, 2 conv_igemm_dma_kernel, 3 conv3x3_halo_kernel,
                                           // 11 conv_wgrad_kernel, 12 conv_wgrad_slots_kernel
 
@@ -32,12 +33,12 @@ void gmk_note_kernel(int id);             // 1 conv_igemm_kernel, 2 conv_igemm_d
 // conv_halo.hip: 3x3 stride-1 bf16 convolution with an LDS-resident halo; returns 1 if launched, 0 if not eligible
 int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int B, int H, int W, const void* w, int w_rows,
                          int n0, int cout, const float* bias, const float* emb, int emb_stride, const void* residual,
-                         void* out, int out_cstride, int min_tiles, hipStream_t stream);
+                         void* out, int out_cstride, int min_tiles, int upsample, hipStream_t stream);
 
 // conv_wgrad_slots.hip: 3x3 stride-1 bf16 weight gradient over padded slots; returns the number of slabs written or 0
 int gmk_wgrad_slots_nsplit(int cout, int ktot);
 int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B, int H,
-                             int W, int cout, float* slab, int64_t slab_bytes, int forced, hipStream_t stream);
+                             int W, int cout, float* slab, int64_t slab_bytes, int forced, int upsample, hipStream_t stream);
 
 static inline hipStream_t gmk_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int gmk_esize(int dtype) { return dtype == GMK_BF16 ? 2 : 4; }

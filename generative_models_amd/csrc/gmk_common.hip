@@ -1,6 +1,7 @@
 // Error plumbing of the C ABI (include/gmk.h): per-thread message, no exceptions.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "gmk_common.h"
 
@@ -29,3 +30,15 @@ extern "C" const char* gmk_last_error(void) { return g_err; }
 static thread_local int g_last_kernel = 0;
 void gmk_note_kernel(int id) { g_last_kernel = id; }
 extern "C" int gmk_last_kernel(void) { return g_last_kernel; }
+
+// kernel-selection overrides (development / A-B measurement): -1 = unset (environment variable, then automatic)
+static int g_choice[3] = {-1, -1, -1};
+extern "C" int gmk_set_kernel_choice(int conv, int wgrad, int gn) {
+    g_choice[0] = conv; g_choice[1] = wgrad; g_choice[2] = gn;
+    return 0;
+}
+int gmk_kernel_choice(int which, const char* env) {
+    if (g_choice[which] >= 0) return g_choice[which];
+    const char* v = getenv(env);
+    return v ? atoi(v) : 0;
+}

@@ -496,7 +496,7 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
     // GMK_GN_KERNEL=2 selects the LDS-resident single-read kernels (kept for experiments: measured on MI355X they are
     // 0-50 % SLOWER than the streaming kernels at 28x28 / 14x14 / 7x7 — one or few resident workgroups per CU serialise their
     // load / compute / store phases, while the streaming kernels' second sweep is served from L2 / Infinity Cache)
-    static const int gn_mode = getenv("GMK_GN_KERNEL") ? atoi(getenv("GMK_GN_KERNEL")) : 0;
+    const int gn_mode = gmk_kernel_choice(2, "GMK_GN_KERNEL");
     const int lds_ok = gn_mode == 2;
     const int lds_max_hw = 1024;
     const int64_t nbytes = (int64_t)B * HW * C * 2;
@@ -531,7 +531,7 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
     // GMK_GN_KERNEL=2 selects the LDS-resident single-read kernels (kept for experiments: measured on MI355X they are
     // 0-50 % SLOWER than the streaming kernels at 28x28 / 14x14 / 7x7 — one or few resident workgroups per CU serialise their
     // load / compute / store phases, while the streaming kernels' second sweep is served from L2 / Infinity Cache)
-    static const int gn_mode = getenv("GMK_GN_KERNEL") ? atoi(getenv("GMK_GN_KERNEL")) : 0;
+    const int gn_mode = gmk_kernel_choice(2, "GMK_GN_KERNEL");
     const int lds_ok = gn_mode == 2;
     const int lds_max_hw = 1024;
     const int64_t nbytes = (int64_t)B * HW * C * 2;

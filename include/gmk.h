@@ -35,6 +35,8 @@ const char* gmk_last_error(void);
 /* profiling aid: which kernel the calling thread's last gmk_conv_igemm / gmk_conv_wgrad launched
  * (1 conv_igemm_kernel, 2 conv_igemm_dma_kernel, 3 conv3x3_halo_kernel, 11 conv_wgrad_kernel, 12 conv_wgrad_slots_kernel) */
 int gmk_last_kernel(void);
+/* development aid: force kernel variants (0 = automatic; see GMK_CONV_KERNEL / GMK_WGRAD_KERNEL / GMK_GN_KERNEL); -1 = unset */
+int gmk_set_kernel_choice(int conv, int wgrad, int gn);
 /* number of bytes of scratch gmk_conv_wgrad needs for the given problem (split-K slabs) */
 int64_t gmk_conv_wgrad_workspace_bytes(int64_t n_pixels, int taps, int cout, int ktot);
 
