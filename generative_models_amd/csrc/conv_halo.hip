@@ -45,8 +45,20 @@ struct HaloParams {
     const float* bias; const float* emb; int emb_stride;
     const void* residual; void* out; int out_cstride; int M;
     unsigned nb0, nb1, nbw, nbo;
+    float* stats;                              // optional GroupNorm partial sums [ntiles][8][2][Cout/4][2] (see gmk.h)
+    int stats_groups;                          // Cout/4
     float inv_hp2, inv_h, inv_we, inv_w;       // reciprocals for exact small-integer division
 };
+
+// sum over the 32 lanes of a half-wave with DPP; lanes 16..31 (and 48..63) end up holding the half's total
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, true));   // row_bcast15 into rows 1 and 3
+    return v;
+}
 
 __device__ __forceinline__ int div_small(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
 
@@ -71,6 +83,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.nbo, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(
+        p.stats ? (void*)p.stats : p.out, 0, p.stats ? p.ntiles * 8 * 2 * p.stats_groups * 2 * 4 : 0, 0x00020000);
 
     // ---- per-lane constants -------------------------------------------------------------------------------
     const int lrow = lane >> 3, lch = lane & 7;
@@ -192,9 +206,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
             const bool live = ml < p.TP && m < p.M;
             const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
             const float* embp = nullptr;
-            if (p.emb) {
-                const int b = (live ? m : 0) / (H * W);
-                embp = p.emb + (int64_t)b * p.emb_stride;
+            int bsamp = 0;
+            if (p.emb || p.stats) bsamp = (live ? m : 0) / (H * W);
+            if (p.emb) embp = p.emb + (int64_t)bsamp * p.emb_stride;
+            // GroupNorm statistics: this 32-pixel group may straddle two samples (never three: 32 < H*W)
+            int b_first = 0;
+            bool hi_seg = false, straddle = false;
+            if (p.stats) {
+                b_first = __builtin_amdgcn_readfirstlane(bsamp);          // lane 0 = first pixel of the group
+                hi_seg = live && bsamp != b_first;
+                straddle = __any(hi_seg);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -237,6 +258,41 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                     const auto u = __builtin_bit_cast(u32x2_t, t);
                     pk[q4][0] = u[0]; pk[q4][1] = u[1];
                 }
+                if (p.stats) {
+                    // per-lane sum / sum of squares of the ROUNDED values of each 4-channel unit, reduced over the group's
+                    // pixels per sample segment; lanes 16..31 / 48..63 then write 16 floats each with ONE store
+                    float lo[4][2], hi[4][2];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const bf16x4 t = __builtin_bit_cast(bf16x4, (u32x2_t){pk[q4][0], pk[q4][1]});
+                        const float a0 = (float)t[0], a1 = (float)t[1], a2 = (float)t[2], a3 = (float)t[3];
+                        const float sm = live ? (a0 + a1) + (a2 + a3) : 0.f;
+                        const float sq = live ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.f;
+                        lo[q4][0] = half_wave_sum(hi_seg ? 0.f : sm);
+                        lo[q4][1] = half_wave_sum(hi_seg ? 0.f : sq);
+                        hi[q4][0] = 0.f; hi[q4][1] = 0.f;
+                        if (straddle) {
+                            hi[q4][0] = half_wave_sum(hi_seg ? sm : 0.f);
+                            hi[q4][1] = half_wave_sum(hi_seg ? sq : 0.f);
+                        }
+                    }
+                    const int idx = r - 16;                       // writer lanes: slot = idx>>3, q4 = (idx>>1)&3, comp = idx&1
+                    float val = 0.f;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                        for (int cpt = 0; cpt < 2; ++cpt) {
+                            if (idx == q4 * 2 + cpt) val = lo[q4][cpt];
+                            if (idx == 8 + q4 * 2 + cpt) val = hi[q4][cpt];
+                        }
+                    const int pg = wm * 2 + i;
+                    const int slot = idx >> 3, q4w = (idx >> 1) & 3, cpt = idx & 1;
+                    const int grp = (cb >> 2) + 2 * q4w + h;
+                    const unsigned soff = idx >= 0
+                        ? (unsigned)(((((tile * 8 + pg) * 2 + slot) * p.stats_groups) + grp) * 2 + cpt) * 4u
+                        : kBadOff;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rss, soff, 0, 0);
+                }
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4 += 2) {
                     const auto s0 = __builtin_amdgcn_permlane32_swap(pk[q4][0], pk[q4 + 1][0], false, false);
@@ -278,11 +334,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
             for (int tap = 0; tap < 9; ++tap) {
                 // ---- wait: retire everything but the ops issued in the previous step (+ the epilogue's stores)
                 if (tap == 0) {
-                    if (fresh > 0) { --fresh; asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    if (fresh > 0) {            // 8 output stores (+ 4 statistics stores) are younger than this step's data
+                        --fresh;
+                        if (p.stats) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                    } else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 } else if (tap == 1) {
-                    if (fresh > 0) { --fresh; asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
-                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    if (fresh > 0) {
+                        --fresh;
+                        if (p.stats) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+                    } else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 } else if (tap == 8) {
                     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 } else {
@@ -313,7 +375,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
 // Returns 1 if the halo kernel was launched, 0 if the problem is not eligible (caller falls back), <0 / >0 on error.
 int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int B, int H, int W, const void* w, int w_rows,
                          int n0, int cout, const float* bias, const float* emb, int emb_stride, const void* residual,
-                         void* out, int out_cstride, int min_tiles, int upsample, hipStream_t stream) {
+                         void* out, int out_cstride, int min_tiles, int upsample, float* stats, int64_t stats_bytes,
+                         hipStream_t stream) {
     if (c0 % 64 || c1 % 64 || cout % 128) return 0;
     if (W < 4 || W > 254 || H < 2) return 0;
     const int R = 256 / W;
@@ -340,6 +403,8 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     p.bias = bias; p.emb = emb; p.emb_stride = emb_stride; p.residual = residual; p.out = out; p.out_cstride = out_cstride;
     p.M = (int)M;
     p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1; p.nbw = (unsigned)nbw; p.nbo = (unsigned)nbo;
+    p.stats = nullptr; p.stats_groups = out_cstride / 4;
+    if (stats && cout == out_cstride && stats_bytes >= ntiles * 8 * 2 * (int64_t)(out_cstride / 4) * 2 * 4 && H * W >= 32) p.stats = stats;
     p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 2); p.inv_w = 1.0f / (float)W;
     dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256), cout / 128);
     conv3x3_halo_kernel<<<grid, 512, 0, stream>>>(p);

@@ -801,7 +801,7 @@ extern "C" int gmk_pack_conv_weight(const float* w, void* w_fwd, void* w_dgrad, 
 extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1, int B, int hs, int ws, int ho, int wo,
                               int ksize, int mode, const void* w, int w_rows, int n0, int cout, const float* bias,
                               const float* emb, int emb_stride, const void* residual, void* out, int out_cstride,
-                              int dtype, void* stream) {
+                              float* gn_stats, int64_t gn_stats_bytes, int dtype, void* stream) {
     GMK_REQUIRE(src0 && w && out, "gmk_conv_igemm: null pointer");
     GMK_REQUIRE(dtype == GMK_BF16 || dtype == GMK_F32, "gmk_conv_igemm: bad dtype %d", dtype);
     GMK_REQUIRE(ksize == 1 || ksize == 3, "gmk_conv_igemm: ksize %d", ksize);
@@ -823,8 +823,8 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
     const int force = gmk_kernel_choice(0, "GMK_CONV_KERNEL");
     if ((force == 0 || force == 3) && dtype == GMK_BF16 && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2) && ksize == 3) {
         const int rc = gmk_conv3x3_halo_try(src0, src1, c0, c1, B, ho, wo, w, w_rows, n0, cout, bias, emb, emb_stride, residual,
-                                            out, out_cstride, force == 3 ? 1 : 256, mode == GMK_CONV_UPSAMPLE2,
-                                            gmk_stream(stream));
+                                            out, out_cstride, force == 3 ? 1 : 256, mode == GMK_CONV_UPSAMPLE2, gn_stats,
+                                            gn_stats_bytes, gmk_stream(stream));
         if (rc == 1) {
             gmk_note_kernel(3);
             return gmk_check_launch("gmk_conv_igemm(halo)");

@@ -17,7 +17,8 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
                                                               float* __restrict__ mean, float* __restrict__ rstd,
-                                                              int HW, int C, int G, float eps) {
+                                                              int HW, int C, int G, float eps,
+                                                              const float* __restrict__ part, int TP, int ntiles) {
     __shared__ float red[kThreads * 4];
     __shared__ float smean[64], srstd[64];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -27,6 +28,31 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
     const T* xb = x + (size_t)b * HW * C + vec * 8;
     T* yb = y + (size_t)b * HW * C + vec * 8;
 
+    if (part) {
+        // statistics from the producer's partial sums: [tile][8 pixel groups][2 sample slots][C/4 units][sum, sumsq],
+        // added in a fixed order (deterministic)
+        if (tid < G) {
+            const int units = cpg >> 2, G4 = C >> 2;
+            const int m_beg = b * HW, m_end = m_beg + HW;
+            const int t0 = m_beg / TP, t1 = min((m_end - 1) / TP, ntiles - 1);
+            float s = 0.f, q = 0.f;
+            for (int t = t0; t <= t1; ++t)
+                for (int pg = 0; pg < 8; ++pg) {
+                    const int g_beg = t * TP + pg * 32;
+                    const int g_end = min(g_beg + 32, t * TP + TP);
+                    if (g_beg >= g_end || g_end <= m_beg || g_beg >= m_end) continue;
+                    const int slot = b - g_beg / HW;              // 0, or 1 when the group started in the previous sample
+                    const float* pp = part + ((size_t)((t * 8 + pg) * 2 + slot) * G4 + tid * units) * 2;
+                    for (int u = 0; u < units; ++u) { s += pp[2 * u]; q += pp[2 * u + 1]; }
+                }
+            const float n = (float)cpg * (float)HW;
+            const float m = s / n;
+            const float var = fmaxf(q / n - m * m, 0.f);
+            const float r = 1.0f / sqrtf(var + eps);
+            smean[tid] = m; srstd[tid] = r;
+            mean[b * G + tid] = m; rstd[b * G + tid] = r;
+        }
+    } else {
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
     for (int p = pl; p < HW; p += planes) {
         float v[8];
@@ -54,6 +80,7 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
         const float r = 1.0f / sqrtf(var + eps);
         smean[tid] = m; srstd[tid] = r;
         mean[b * G + tid] = m; rstd[b * G + tid] = r;
+    }
     }
     __syncthreads();
     float sc[8], sh[8];
@@ -489,7 +516,10 @@ bool gn_shape_ok(int C, int G) {
 }  // namespace
 
 extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
-                               int B, int HW, int C, int groups, float eps, int dtype, void* stream) {
+                               int B, int HW, int C, int groups, float eps, const float* stats_part, int tile_pixels,
+                               int ntiles, int dtype, void* stream) {
+    GMK_REQUIRE(!stats_part || (tile_pixels >= 32 && ntiles > 0 && HW >= 32 && C % 4 == 0),
+                "gmk_gn_silu_fwd: bad statistics geometry");
     GMK_REQUIRE(x && y && gamma && beta && mean && rstd, "gmk_gn_silu_fwd: null pointer");
     GMK_REQUIRE(B > 0 && HW > 0 && gn_shape_ok(C, groups), "gmk_gn_silu_fwd: unsupported shape B=%d HW=%d C=%d G=%d", B,
                 HW, C, groups);
@@ -500,7 +530,7 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
     const int lds_ok = gn_mode == 2;
     const int lds_max_hw = 1024;
     const int64_t nbytes = (int64_t)B * HW * C * 2;
-    if (dtype == GMK_BF16 && lds_ok && C % 64 == 0 && HW <= lds_max_hw && nbytes < 0xFFFF0000ll) {
+    if (dtype == GMK_BF16 && lds_ok && !stats_part && C % 64 == 0 && HW <= lds_max_hw && nbytes < 0xFFFF0000ll) {
         dim3 grid(B, C / 64);
         if (HW <= 256)
             gn_silu_fwd_lds_kernel<256><<<grid, kThreads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, mean,
@@ -510,10 +540,12 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
                                                                                  mean, rstd, HW, C, groups, eps, (unsigned)nbytes);
     } else if (dtype == GMK_BF16)
         gn_silu_fwd_kernel<bf16_t><<<B, kThreads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta,
-                                                                            mean, rstd, HW, C, groups, eps);
+                                                                            mean, rstd, HW, C, groups, eps, stats_part,
+                                                                            tile_pixels, ntiles);
     else if (dtype == GMK_F32)
         gn_silu_fwd_kernel<float><<<B, kThreads, 0, gmk_stream(stream)>>>((const float*)x, (float*)y, gamma, beta,
-                                                                          mean, rstd, HW, C, groups, eps);
+                                                                          mean, rstd, HW, C, groups, eps, stats_part,
+                                                                          tile_pixels, ntiles);
     else
         GMK_REQUIRE(false, "gmk_gn_silu_fwd: bad dtype %d", dtype);
     return gmk_check_launch("gmk_gn_silu_fwd");

@@ -281,7 +281,7 @@ class SimpleUnet(nn.Module):
             a.append(y); stats1.append((mean, rstd))
         wf1, _ = self._packs[f"{name}.in_layers.2"]
         h = ops.conv_igemm(a, wf1, C, 3, ops.NORMAL, (H, W), bias=P[f"{name}.in_layers.2.bias"],
-                           emb=emb_all[:, blk * C:(blk + 1) * C])
+                           emb=emb_all[:, blk * C:(blk + 1) * C], gn_stats=True)
         a2, mean2, rstd2 = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], 32)
         if len(srcs) == 2:
             wfs, _ = self._packs[f"{name}.skip_connection"]
@@ -289,7 +289,8 @@ class SimpleUnet(nn.Module):
         else:
             res = srcs[0]
         wf2, _ = self._packs[f"{name}.out_layers.3"]
-        out = ops.conv_igemm([a2], wf2, C, 3, ops.NORMAL, (H, W), bias=P[f"{name}.out_layers.3.bias"], residual=res)
+        out = ops.conv_igemm([a2], wf2, C, 3, ops.NORMAL, (H, W), bias=P[f"{name}.out_layers.3.bias"], residual=res,
+                             gn_stats=True)
         if ctx is not None:
             ctx[name] = (srcs, a, stats1, h, a2, (mean2, rstd2))
         return out
@@ -360,12 +361,12 @@ class SimpleUnet(nn.Module):
         t7 = self._res_fwd("turn", [t6], emb_all, 4, ctx)
         u0r = self._res_fwd("up.seq.0.0", [t7, t6], emb_all, 5, ctx)
         u0 = ops.conv_igemm([u0r], self._packs["up.seq.0.1.conv"][0], C, 3, ops.UPSAMPLE2, (H2, W2),
-                            bias=P["up.seq.0.1.conv.bias"])
+                            bias=P["up.seq.0.1.conv.bias"], gn_stats=True)
         u1 = self._res_fwd("up.seq.1", [u0, t5], emb_all, 6, ctx)
         u2 = self._res_fwd("up.seq.2", [u1, t4], emb_all, 7, ctx)
         u3r = self._res_fwd("up.seq.3.0", [u2, t3], emb_all, 8, ctx)
         u3 = ops.conv_igemm([u3r], self._packs["up.seq.3.1.conv"][0], C, 3, ops.UPSAMPLE2, (H, W),
-                            bias=P["up.seq.3.1.conv.bias"])
+                            bias=P["up.seq.3.1.conv.bias"], gn_stats=True)
         u4 = self._res_fwd("up.seq.4", [u3, t2], emb_all, 9, ctx)
         u5 = self._res_fwd("up.seq.5", [u4, t1], emb_all, 10, ctx)
         u6 = self._res_fwd("up.seq.6", [u5, t0], emb_all, 11, ctx)

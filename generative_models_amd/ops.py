@@ -89,15 +89,24 @@ def pack_conv_weight(w, w_fwd, w_dgrad):
 
 
 # ---- GroupNorm + SiLU ------------------------------------------------------------------------------------
+# Let producing convolutions emit GroupNorm statistics from their epilogue (gmk_conv_igemm gn_stats).  OFF by default:
+# measured on MI355X the DPP reductions in the conv epilogue cost as much as the statistics pass they save (27.25 vs
+# 27.19 ms/step), and with it a sample's result depends (in the last bits) on which tile neighbours it had.
+GN_STATS = False
+
+
 def gn_silu_fwd(x, gamma, beta, groups, eps=1e-5):
-    """x NHWC [B,H,W,C] -> (y, mean[B,G], rstd[B,G])"""
+    """x NHWC [B,H,W,C] -> (y, mean[B,G], rstd[B,G]).  If the convolution that produced x attached its partial
+    GroupNorm statistics (x._gn_stats), the statistics pass over x is skipped."""
     _chk(x, name="x"); _f32(gamma, "gamma"); _f32(beta, "beta")
     B, H, W, C = x.shape
     assert gamma.numel() == C and beta.numel() == C
     y = torch.empty_like(x)
     mean = torch.empty((B, groups), device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
-    check(lib.gmk_gn_silu_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), B, H * W, C, groups, eps,
+    st = getattr(x, "_gn_stats", None)
+    part, tp, nt = st if st is not None else (None, 0, 0)
+    check(lib.gmk_gn_silu_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), B, H * W, C, groups, eps, _p(part), tp, nt,
                               _DT[x.dtype], _s()), "gn_silu_fwd")
     return y, mean, rstd
 
@@ -186,7 +195,7 @@ def out_size(mode, hs, ws):
     raise ValueError(mode)
 
 
-def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, emb=None, residual=None):
+def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, emb=None, residual=None, gn_stats=False):
     """srcs: list of 1-2 NHWC tensors (same B,H,W); w: packed weights [taps][w_rows][sum C]; -> out NHWC [B,ho,wo,cout]."""
     s0 = _chk(srcs[0], name="src0")
     s1 = _chk(srcs[1], s0.dtype, "src1") if len(srcs) > 1 else None
@@ -209,10 +218,18 @@ def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, 
     if residual is not None:
         _chk(residual, s0.dtype, "residual"); assert residual.shape == out.shape
     mpix = B * hs * ws if mode == TRANSPOSED2 else B * ho * wo     # algorithmic work: that of the stride-2 conv
+    part, tp, nt = None, 0, 0
+    if gn_stats and GN_STATS and ksize == 3 and mode in (NORMAL, UPSAMPLE2) and s0.dtype == torch.bfloat16 and 4 <= wo <= 254:
+        r = 256 // wo
+        tp, nt = r * wo, (B * ho + r - 1) // r
+        part = torch.empty(nt * 8 * 2 * (cout // 4) * 2, device=s0.device, dtype=torch.float32)
     with _Timed("conv_igemm", 2.0 * mpix * cout * (c0 + c1) * ksize * ksize):
         check(lib.gmk_conv_igemm(_p(s0), _p(s1), c0, c1, B, hs, ws, ho, wo, ksize, mode, _p(w), w_rows, n0, cout,
-                                 _p(bias), _p(emb), emb_stride, _p(residual), _p(out), cout, _DT[s0.dtype], _s()),
+                                 _p(bias), _p(emb), emb_stride, _p(residual), _p(out), cout, _p(part),
+                                 part.numel() * 4 if part is not None else 0, _DT[s0.dtype], _s()),
               "conv_igemm")
+    if part is not None and lib.gmk_last_kernel() == 3 and ho * wo >= 32:
+        out._gn_stats = (part, tp, nt)     # consumed by gn_silu_fwd(out, ...)
     return out
 
 

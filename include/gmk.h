@@ -52,7 +52,10 @@ int gmk_pack_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int cout, i
  * x,y: NHWC [B][HW][C]; `groups` groups over these C channels (a 2C-channel concatenated input is handled as
  * two calls of 16 groups each, simple_unet.py:150,161); mean/rstd: fp32 [B][groups] (written). */
 int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
-                    int B, int HW, int C, int groups, float eps, int dtype, void* stream);
+                    int B, int HW, int C, int groups, float eps, const float* stats_part, int tile_pixels, int ntiles,
+                    int dtype, void* stream);
+/* stats_part (optional): partial sums emitted by the producing convolution (see gmk_conv_igemm gn_stats); when given,
+ * the statistics pass over x is skipped (x is read once). */
 /* backward of the above.  dx = d/dx + dadd1 + dadd2 (optional NHWC addends, e.g. the identity-skip gradient).
  * dgamma_part/dbeta_part: fp32 [B][C] per-sample partials (reduce with gmk_colsum); dxsum: optional fp32
  * [B][dxsum_stride] per-sample channel sums of the final dx (bias / embedding gradients). */
@@ -77,11 +80,17 @@ int gmk_sumpool2x2(const void* x, void* y, int B, int H, int W, int C, int dtype
  * torch.cat([x, skip], 1) (simple_unet.py:150) is never materialised.  (hs, ws): source spatial size;
  * (ho, wo): output spatial size; `mode` one of GMK_CONV_*.  w: packed rows `[tap][w_rows][c0+c1]` of
  * `dtype`; output channels n0 .. n0+cout-1 use rows n0.. of each tap (cout % 128 == 0).  bias/emb/residual
- * may be NULL.  Forward convolutions pass a w_fwd pack; data gradients pass a w_dgrad pack. */
+ * may be NULL.  Forward convolutions pass a w_fwd pack; data gradients pass a w_dgrad pack.
+ * gn_stats (optional, may be NULL): the convolution that PRODUCES a GroupNorm input can emit that GroupNorm's
+ * statistics from its epilogue, saving the consumer one full read of the tensor.  Only conv3x3_halo_kernel
+ * (gmk_last_kernel() == 3) fills it: fp32 [ntiles][8][2][cout/4][2] = for every 32-pixel group of every tile
+ * (tile = 256/wo whole rows of the global row list b*ho + y) and each of the <= 2 samples the group touches, the sum
+ * and the sum of squares of the stored (rounded) outputs of every 4-channel unit.  Pass the same buffer to
+ * gmk_gn_silu_fwd together with tile_pixels = (256/wo)*wo and ntiles = ceil(B*ho / (256/wo)). */
 int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1, int B, int hs, int ws, int ho, int wo,
                    int ksize, int mode, const void* w, int w_rows, int n0, int cout, const float* bias,
                    const float* emb, int emb_stride, const void* residual, void* out, int out_cstride,
-                   int dtype, void* stream);
+                   float* gn_stats, int64_t gn_stats_bytes, int dtype, void* stream);
 /* weight gradient: dw[n][k][tap] (reference layout `[Cout][Cin][k][k]`, fp32, overwritten or accumulated) =
  *   sum_pixels dy[b][oy][ox][n0_dy + n] * srcK[b][sy][sx][k],  same gather as the forward of `mode`.
  * workspace: gmk_conv_wgrad_workspace_bytes(B*ho*wo, ksize*ksize, cout, c0+c1) bytes. */

@@ -292,3 +292,30 @@ def test_rng_and_adam(ops):
         p.grad = g.clone(); opt.step()
         ops.adam_step(pd, (g * 8).cuda(), m, v, 3e-4, 0.9, 0.999, 1e-8, step, grad_scale=0.125)
         assert float((pd.cpu() - p.detach()).abs().max()) < 1e-6 * step + 1e-7
+
+
+@pytest.mark.parametrize("S,B,G", [(28, 3, 32), (14, 5, 32), (14, 5, 16), (8, 37, 32), (7, 9, 32)])
+def test_conv_emits_groupnorm_statistics(ops, S, B, G):
+    """The halo convolution's epilogue statistics == statistics of the tensor it stored (tiles spanning samples,
+    32-pixel groups straddling two samples, partial last tile)."""
+    from generative_models_amd._lib import lib
+    C, dtype = 128, torch.bfloat16
+    x = nhwc(q(rnd(B, C, S, S, seed=90), dtype), dtype)
+    w = q(rnd(C, C, 3, 3, seed=91) / math.sqrt(9 * C), dtype)
+    wf = torch.empty(w.numel(), device="cuda", dtype=dtype)
+    ops.pack_conv_weight(w.cuda(), wf, None)
+    res = nhwc(q(rnd(B, C, S, S, seed=92) * 3, dtype), dtype)
+    lib.gmk_set_kernel_choice(3, -1, -1)
+    ops.GN_STATS = True
+    try:
+        out = ops.conv_igemm([x], wf, C, 3, 0, (S, S), bias=(0.5 * rnd(C, seed=93)).cuda(), residual=res, gn_stats=True)
+    finally:
+        lib.gmk_set_kernel_choice(-1, -1, -1)
+        ops.GN_STATS = False
+    assert getattr(out, "_gn_stats", None) is not None
+    gamma, beta = (1 + 0.1 * rnd(C, seed=94)).cuda(), (0.1 * rnd(C, seed=95)).cuda()
+    y1, m1, r1 = ops.gn_silu_fwd(out, gamma, beta, G)
+    plain = out.clone()                                   # same values, no attached statistics -> 3-pass kernel
+    y2, m2, r2 = ops.gn_silu_fwd(plain, gamma, beta, G)
+    assert rel_err(m1, m2) < 1e-4 and rel_err(r1, r2) < 1e-4
+    assert rel_err(y1.float(), y2.float()) < 1e-2

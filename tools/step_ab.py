@@ -2,7 +2,7 @@
     python tools/step_ab.py "0,0,0" "2,0,0" ...      (conv,wgrad,gn choices; see include/gmk.h)"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from generative_models_amd import common
+from generative_models_amd import common, ops
 from generative_models_amd._lib import lib
 import bench
 variants = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(0, 0, 0)]
@@ -13,7 +13,8 @@ x, y = bench.synthetic_batch(1024, 1, 28, "cuda", 1000)
 res = {v: [] for v in variants}
 for rnd in range(4):
     for v in variants:
-        lib.gmk_set_kernel_choice(*v)
+        lib.gmk_set_kernel_choice(*v[:3])
+        ops.GN_STATS = (v[3] != 0) if len(v) > 3 else True
         for _ in range(2):
             model.train_step(x, y.clone())
         torch.cuda.synchronize(); t0 = time.perf_counter()
