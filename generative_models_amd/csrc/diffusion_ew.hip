@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void v_loss_kernel(const float* __restrict__ v
                                                     const float* __restrict__ x, const float* __restrict__ eps,
                                                     const float* __restrict__ logsnr, float* __restrict__ loss_b,
                                                     float* __restrict__ x_mse_o, float* __restrict__ eps_mse_o,
-                                                    float* __restrict__ dv, float grad_scale, int64_t n) {
+                                                    float* __restrict__ dv, float grad_scale, int64_t n, int loss_type) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     const LogsnrCoef c = logsnr_coef(logsnr[b]);
@@ -91,13 +91,13 @@ __global__ __launch_bounds__(256) void v_loss_kernel(const float* __restrict__ v
     se = block_sum(se, red);
     const float xm = sx / (float)n, em = se / (float)n;
     if (threadIdx.x == 0) {
-        loss_b[b] = fmaxf(xm, em);                                         // :169 'snr_trunc'
+        loss_b[b] = loss_type == 1 ? em : fmaxf(xm, em);                   // :171 'snr' (distillation step1) / :169 'snr_trunc'
         if (x_mse_o) x_mse_o[b] = xm;
         if (eps_mse_o) eps_mse_o[b] = em;
     }
     if (!dv) return;
     // torch.maximum routes the gradient to the larger branch, ties split evenly; torch.clip passes it inside [-1, 1]
-    const float gx = xm > em ? 1.f : (xm == em ? 0.5f : 0.f);
+    const float gx = loss_type == 1 ? 0.f : (xm > em ? 1.f : (xm == em ? 0.5f : 0.f));
     const float ge = 1.f - gx;
     const float kx = grad_scale * gx * 2.f / (float)n;
     const float ke = grad_scale * ge * 2.f / (float)n * (-c.c1 * c.c2);
@@ -116,8 +116,10 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const float* __restri
                                                           const float* __restrict__ cond_w, const float* __restrict__ z,
                                                           const float* __restrict__ noise, float lt, float ls, int is_last,
                                                           float* __restrict__ z_next, float* __restrict__ x_pred,
-                                                          float* __restrict__ eps_pred, int64_t n) {
+                                                          float* __restrict__ eps_pred, int64_t n,
+                                                          const float* __restrict__ lt_vec, const float* __restrict__ ls_vec) {
     const int b = blockIdx.y;
+    if (lt_vec) { lt = lt_vec[b]; ls = ls_vec[b]; }      // per-sample times (teacher steps of the distillation loss)
     const LogsnrCoef c = logsnr_coef(lt);
     const float alpha_s = sqrtf(1.0f / (1.0f + expf(-ls)));
     const float sigma_s = sqrtf(1.0f / (1.0f + expf(ls)));
@@ -256,11 +258,12 @@ extern "C" int gmk_q_sample(const float* x, const float* eps, const float* u, fl
 }
 
 extern "C" int gmk_v_loss(const float* v, const float* z, const float* x, const float* eps, const float* logsnr,
-                          float* loss_b, float* x_mse, float* eps_mse, float* dv, float grad_scale, int B, int64_t n,
-                          void* stream) {
+                          float* loss_b, float* x_mse, float* eps_mse, float* dv, float grad_scale, int loss_type, int B,
+                          int64_t n, void* stream) {
     GMK_REQUIRE(v && z && x && eps && logsnr && loss_b, "gmk_v_loss: null pointer");
     GMK_REQUIRE(B > 0 && n > 0, "gmk_v_loss: bad shape");
-    v_loss_kernel<<<B, 256, 0, gmk_stream(stream)>>>(v, z, x, eps, logsnr, loss_b, x_mse, eps_mse, dv, grad_scale, n);
+    GMK_REQUIRE(loss_type == 0 || loss_type == 1, "gmk_v_loss: loss_type must be 0 (snr_trunc) or 1 (snr)");
+    v_loss_kernel<<<B, 256, 0, gmk_stream(stream)>>>(v, z, x, eps, logsnr, loss_b, x_mse, eps_mse, dv, grad_scale, n, loss_type);
     return gmk_check_launch("gmk_v_loss");
 }
 
@@ -273,8 +276,83 @@ extern "C" int gmk_sampler_step(const float* v, const float* v_uncond, const flo
     int gx = (int)((n + 255) / 256);
     if (gx > 64) gx = 64;
     sampler_step_kernel<<<dim3(gx, B), 256, 0, gmk_stream(stream)>>>(v, v_uncond, cond_w, z, noise, logsnr_t, logsnr_s,
-                                                                     is_last, z_next, x_pred, eps_pred, n);
+                                                                     is_last, z_next, x_pred, eps_pred, n, nullptr, nullptr);
     return gmk_check_launch("gmk_sampler_step");
+}
+
+extern "C" int gmk_ddim_step_vec(const float* v, const float* v_uncond, const float* cond_w, const float* z,
+                                 const float* logsnr_t, const float* logsnr_s, float* z_next, float* x_pred, float* eps_pred,
+                                 int B, int64_t n, void* stream) {
+    GMK_REQUIRE(v && z && z_next && logsnr_t && logsnr_s, "gmk_ddim_step_vec: null pointer");
+    GMK_REQUIRE((v_uncond == nullptr) == (cond_w == nullptr), "gmk_ddim_step_vec: v_uncond and cond_w go together");
+    GMK_REQUIRE(B > 0 && B < 65536 && n > 0, "gmk_ddim_step_vec: bad shape");
+    int gx = (int)((n + 255) / 256);
+    if (gx > 64) gx = 64;
+    sampler_step_kernel<<<dim3(gx, B), 256, 0, gmk_stream(stream)>>>(v, v_uncond, cond_w, z, nullptr, 0.f, 0.f, 0, z_next, x_pred,
+                                                                     eps_pred, n, logsnr_t, logsnr_s);
+    return gmk_check_launch("gmk_ddim_step_vec");
+}
+
+namespace {
+// u -> logsnr (diffusion_utils.py:198-201); optionally u = (i + 1) / T - shift from integer times (gaussian_diffusion.py:90-91)
+__global__ void schedule_kernel(const float* __restrict__ u, const int64_t* __restrict__ ti, float inv_T_num, float T,
+                                float shift, float* __restrict__ u_out, float* __restrict__ logsnr, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float uu = ti ? __fdiv_rn((float)(ti[b] + 1), T) : u[b];
+    (void)inv_T_num;
+    uu = __fsub_rn(uu, shift);
+    if (u_out) u_out[b] = uu;
+    const float t = __fadd_rn(__fmul_rn(kSchedA, uu), kSchedB);
+    logsnr[b] = -2.0f * logf(tanf(t));
+}
+
+// gaussian_diffusion.py:147-154: x-target implied by two teacher DDIM steps, its i == 0 select, and the eps-target
+__global__ __launch_bounds__(256) void distill_target_kernel(const float* __restrict__ z_teacher, const float* __restrict__ z_t,
+                                                            const float* __restrict__ x_pred_teacher,
+                                                            const float* __restrict__ logsnr, const float* __restrict__ logsnr_s,
+                                                            const int64_t* __restrict__ ti, float* __restrict__ x_target,
+                                                            float* __restrict__ eps_target, int64_t n) {
+    const int b = blockIdx.y;
+    const float l = logsnr[b], ls = logsnr_s[b];
+    const float alpha_s = sqrtf(1.0f / (1.0f + expf(-ls)));
+    const float alpha_t = sqrtf(1.0f / (1.0f + expf(-l)));
+    // F.softplus(x) = log1p(exp(x)) (x <= 20), x beyond the threshold
+    const float sp_t = l > 20.f ? l : log1pf(expf(l));
+    const float sp_s = ls > 20.f ? ls : log1pf(expf(ls));
+    const float frac = expf(0.5f * (sp_t - sp_s));
+    const float denom = alpha_s - frac * alpha_t;
+    const float c1 = sqrtf(1.0f + expf(l)), c2 = 1.0f / sqrtf(1.0f + expf(-l));
+    const bool first = ti[b] == 0;
+    const int64_t base = (int64_t)b * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float zt = z_t[base + i];
+        const float xt = first ? x_pred_teacher[base + i] : (z_teacher[base + i] - frac * zt) / denom;
+        x_target[base + i] = xt;
+        eps_target[base + i] = c1 * (zt - xt * c2);
+    }
+}
+}  // namespace
+
+extern "C" int gmk_logsnr_schedule(const float* u, const int64_t* i_times, int num_steps, float shift, float* u_out,
+                                   float* logsnr, int B, void* stream) {
+    GMK_REQUIRE((u != nullptr) != (i_times != nullptr) && logsnr && B > 0, "gmk_logsnr_schedule: give exactly one of u / i_times");
+    GMK_REQUIRE(!i_times || num_steps >= 1, "gmk_logsnr_schedule: num_steps");
+    schedule_kernel<<<(B + 255) / 256, 256, 0, gmk_stream(stream)>>>(u, i_times, 0.f, (float)num_steps, shift, u_out, logsnr, B);
+    return gmk_check_launch("gmk_logsnr_schedule");
+}
+
+extern "C" int gmk_distill_target(const float* z_teacher, const float* z_t, const float* x_pred_teacher, const float* logsnr,
+                                  const float* logsnr_s, const int64_t* i_times, float* x_target, float* eps_target, int B,
+                                  int64_t n, void* stream) {
+    GMK_REQUIRE(z_teacher && z_t && x_pred_teacher && logsnr && logsnr_s && i_times && x_target && eps_target,
+                "gmk_distill_target: null pointer");
+    GMK_REQUIRE(B > 0 && B < 65536 && n > 0, "gmk_distill_target: bad shape");
+    int gx = (int)((n + 255) / 256);
+    if (gx > 64) gx = 64;
+    distill_target_kernel<<<dim3(gx, B), 256, 0, gmk_stream(stream)>>>(z_teacher, z_t, x_pred_teacher, logsnr, logsnr_s, i_times,
+                                                                       x_target, eps_target, n);
+    return gmk_check_launch("gmk_distill_target");
 }
 
 extern "C" int gmk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

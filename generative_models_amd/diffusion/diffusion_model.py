@@ -50,14 +50,23 @@ def make_plugin(GMBase, AttrDict):
         def __init__(self, G):
             super().__init__(G)
             get = lambda k: G[k] if k in G else self.DG[k]
-            if Path(get("teacher_path")) != Path("."):
-                raise NotImplementedError("progressive distillation (--teacher_path) is not on the HIP path yet")
             self.net = SimpleUnet(get("hidden_size"), get("dropout"), in_channels=get("in_channels"),
                                   compute_dtype=_DTYPES[get("compute_dtype")])
-            self.teacher_net = None
+            weights_from = Path(G["weights_from"]) if "weights_from" in G else Path(".")
+            if Path(get("teacher_path")) != Path(".") and weights_from == Path("."):      # diffusion_model.py:34-43
+                print("Loading teacher model")
+                self.load_state_dict(torch.load(get("teacher_path"), map_location="cpu"), strict=False)
+                self.teacher_net = SimpleUnet(get("hidden_size"), get("dropout"), in_channels=get("in_channels"),
+                                              compute_dtype=_DTYPES[get("compute_dtype")])
+                self.teacher_net.load_state_dict(self.net.state_dict())
+                self.teacher_net.eval()
+                for param in self.teacher_net.parameters():
+                    param.requires_grad = False
+            else:
+                self.teacher_net = None
             seed = int(get("seed")) * 1000 + parallel.rank()
             self.diffusion = GaussianDiffusion(mean_type=get("mean_type"), num_steps=int(get("timesteps")),
-                                               sampler=get("sampler"), teacher_net=None,
+                                               sampler=get("sampler"), teacher_net=self.teacher_net,
                                                teacher_mode=get("teacher_mode"), sample_cond_w=get("sample_cond_w"),
                                                seed=seed)
             self.optimizer = FusedAdam(self.net, lr=G.lr if "lr" in G else 3e-4)

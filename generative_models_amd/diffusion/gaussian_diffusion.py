@@ -9,8 +9,9 @@ as the reference passes it (diffusion_model.py:77,85).  All arithmetic is in lib
 * DDIM / ancestral / guidance update   gmk_sampler_step (:174-243,:292)
 * RNG                                   counter-based Philox streams (gmk_rng_*), keyed (seed, rank, draw index)
 
-Only `mean_type='v'` (the reference default, diffusion_model.py:21) is implemented on the HIP path; the progressive
-distillation branches (:105-154, teacher_net) are SURVEY §8f "next" and raise NotImplementedError.
+Only `mean_type='v'` (the reference default, diffusion_model.py:21) is implemented on the HIP path.  Progressive
+distillation (:87-91,:105-154) is supported: `teacher_net` is a frozen HIP `SimpleUnet`; teacher DDIM
+steps run through gmk_ddim_step_vec / gmk_distill_target, the student is conditioned on the guidance weight.
 """
 from functools import partial
 
@@ -71,8 +72,8 @@ class _VLoss(torch.autograd.Function):
     """loss_b = max(mse_x, mse_eps) of the clipped v-parameterised prediction, differentiable w.r.t. v."""
 
     @staticmethod
-    def forward(ctx, v, z, x, eps, logsnr):
-        loss_b, _, _, dv = ops.v_loss(v.contiguous(), z, x, eps, logsnr, grad_scale=1.0)
+    def forward(ctx, v, z, x, eps, logsnr, loss_type=0):
+        loss_b, _, _, dv = ops.v_loss(v.contiguous(), z, x, eps, logsnr, grad_scale=1.0, loss_type=loss_type)
         ctx.save_for_backward(dv)
         return loss_b
 
@@ -81,7 +82,7 @@ class _VLoss(torch.autograd.Function):
         (dv,) = ctx.saved_tensors
         B = dv.shape[0]
         out = ops.scale_rows(dv.view(B, -1), g.contiguous().float()).view_as(dv)
-        return out, None, None, None, None
+        return out, None, None, None, None, None
 
 
 class GaussianDiffusion:
@@ -89,48 +90,89 @@ class GaussianDiffusion:
                  seed=0):
         if mean_type != "v":
             raise NotImplementedError(f"HIP path implements mean_type='v' (reference default); got {mean_type!r}")
-        if teacher_net is not None:
-            raise NotImplementedError("progressive distillation (teacher_net) is not on the HIP path yet")
         self.mean_type = mean_type
         self.num_steps = num_steps
-        self.teacher_net = None
+        self.teacher_net = teacher_net
         self.sampler = sampler
         self.sample_cond_w = sample_cond_w
         self.loss_weight_type = "snr_trunc"
+        if self.teacher_net is not None:                      # :39-43
+            assert teacher_mode in ["step1", "step2"]
+            self.teacher_mode = teacher_mode
+            if self.teacher_mode == "step1":
+                self.loss_weight_type = "snr"
         self.rng = PhiloxStream(seed)
 
     # ---- training ----------------------------------------------------------------------------------------
-    def _draw(self, x, u, eps):
-        if eps is None:
-            eps = self.rng.normal(x.shape, x.device)          # :83
-        if u is None:
-            u = self.rng.uniform((x.shape[0],), x.device)     # :94 continuous time
-        return ops.aligned(u.float()), ops.aligned(eps.float())
+    def _teacher_eval(self, z, logsnr, guide, cond_w_net, guided):
+        """Teacher forward (no grad).  guided: also the unconditional evaluation, batched as one 2B forward (:176-177)."""
+        t = self.teacher_net
+        if not guided:
+            return t.forward_hip(z, logsnr, guide, cond_w_net), None
+        B = z.shape[0]
+        v2 = t.forward_hip(torch.cat([z, z]), torch.cat([logsnr, logsnr]), torch.cat([guide, -torch.ones_like(guide)]), None)
+        return v2[:B], v2[B:]
 
-    def training_losses(self, *, net, x, u=None, eps=None):
+    def _prepare(self, net, x, u, eps, i_times=None, cond_w=None):
+        """Everything ahead of the student's forward pass: draws, q_sample and (distillation) the teacher's targets.
+        -> (module, guide, student cond_w, z_t, logsnr, x_target, eps_target, loss_type)"""
+        module, guide, _ = _unwrap(net)
+        x = ops.aligned(x.float())
+        B, dev = x.shape[0], x.device
+        distill = self.teacher_net is not None
+        if eps is None:
+            eps = self.rng.normal(x.shape, dev)                                   # :83
+        eps = ops.aligned(eps.float())
+        if distill and self.teacher_mode == "step2":                              # :87-91 discrete time
+            if i_times is None:
+                i_times = (self.rng.uniform((B,), dev) * self.num_steps).long().clamp_(max=self.num_steps - 1)
+            i_times = ops.aligned(i_times.long())
+            _, u = ops.logsnr_schedule(B, dev, i_times=i_times, num_steps=self.num_steps, want_u=True)
+        else:
+            if u is None:
+                u = self.rng.uniform((B,), dev)                                   # :94 continuous time
+            u = ops.aligned(u.float())
+        logsnr, z_t = ops.q_sample(x, eps, u)                                     # :95-100
+        if not distill:
+            return module, guide, None, z_t, logsnr, x, eps, 0
+        if cond_w is None:
+            cond_w = 4.0 * self.rng.uniform((B,), dev)                            # :107
+        cond_w = ops.aligned(cond_w.float())
+        with torch.no_grad():
+            logsnr_s = ops.logsnr_schedule(B, dev, u=u, shift=1.0 / self.num_steps)           # :118-119
+            if self.teacher_mode == "step1":                                      # :121-126 one guided teacher step
+                v, vu = self._teacher_eval(z_t, logsnr, guide, None, guided=True)
+                _, x_target, eps_target = ops.ddim_step_vec(v, z_t, logsnr, logsnr_s, v_uncond=vu, cond_w=cond_w)
+                loss_type = 1
+            else:                                                                 # :128-154 two w-conditioned teacher steps
+                logsnr_mid = ops.logsnr_schedule(B, dev, u=u, shift=0.5 / self.num_steps)
+                v1, _ = self._teacher_eval(z_t, logsnr, guide, cond_w, guided=False)
+                z_mid, _, _ = ops.ddim_step_vec(v1, z_t, logsnr, logsnr_mid)
+                v2, _ = self._teacher_eval(z_mid, logsnr_mid, guide, cond_w, guided=False)
+                z_teacher, x_pred_teacher, _ = ops.ddim_step_vec(v2, z_mid, logsnr_mid, logsnr_s)
+                x_target, eps_target = ops.distill_target(z_teacher, z_t, x_pred_teacher, logsnr, logsnr_s, i_times)
+                loss_type = 0
+        return module, guide, cond_w, z_t, logsnr, x_target, eps_target, loss_type
+
+    def training_losses(self, *, net, x, u=None, eps=None, i_times=None, cond_w=None):
         """Reference call shape (:81).  Differentiable through torch.autograd when grad mode is on."""
         assert x.dtype in [torch.float32, torch.float64]
-        module, guide, cond_w = _unwrap(net)
-        x = ops.aligned(x.float())
-        u, eps = self._draw(x, u, eps)
-        logsnr, z_t = ops.q_sample(x, eps, u)
-        v = module(z_t, logsnr, guide=guide, cond_w=cond_w)
+        module, guide, w, z_t, logsnr, x_t, eps_t, loss_type = self._prepare(net, x, u, eps, i_times, cond_w)
+        v = module(z_t, logsnr, guide=guide, cond_w=w)
         if torch.is_grad_enabled() and v.requires_grad:
-            loss = _VLoss.apply(v, z_t, x, eps, logsnr)
+            loss = _VLoss.apply(v, z_t, x_t, eps_t, logsnr, loss_type)
         else:
-            loss = ops.v_loss(v, z_t, x, eps, logsnr)[0]
+            loss = ops.v_loss(v, z_t, x_t, eps_t, logsnr, loss_type=loss_type)[0]
         return {"loss": loss}
 
-    def train_forward_backward(self, *, net, x, grad_scale, u=None, eps=None, on_grads_ready=None):
+    def train_forward_backward(self, *, net, x, grad_scale, u=None, eps=None, i_times=None, cond_w=None,
+                               on_grads_ready=None):
         """Fused training pass used by DiffusionModel.train_step: forward, loss, dL/dv and the explicit backward
         schedule, leaving d(grad_scale * sum_b loss_b)/d(theta) in `module.flat_grads`.  No autograd graph."""
-        module, guide, cond_w = _unwrap(net)
-        x = ops.aligned(x.float())
-        u, eps = self._draw(x, u, eps)
-        logsnr, z_t = ops.q_sample(x, eps, u)
+        module, guide, w, z_t, logsnr, x_t, eps_t, loss_type = self._prepare(net, x, u, eps, i_times, cond_w)
         ctx = {}
-        v = module.forward_hip(z_t, logsnr, guide, cond_w, ctx=ctx)
-        loss_b, x_mse, eps_mse, dv = ops.v_loss(v, z_t, x, eps, logsnr, grad_scale=grad_scale)
+        v = module.forward_hip(z_t, logsnr, guide, w, ctx=ctx)
+        loss_b, x_mse, eps_mse, dv = ops.v_loss(v, z_t, x_t, eps_t, logsnr, grad_scale=grad_scale, loss_type=loss_type)
         module.backward_hip(ctx, dv, on_grads_ready=on_grads_ready)
         return {"loss": loss_b, "x_mse": x_mse, "eps_mse": eps_mse, "logsnr": logsnr}
 
@@ -141,12 +183,26 @@ class GaussianDiffusion:
         with record=False only the final z is produced and returned as a 1-tuple-compatible triple
         (z[None], None, None) — the 3*T*B*C*H*W*4-byte trajectory is the dominant cost at large T*B otherwise.
         `noises` ([T, ...], indexed by step i) / `net_cond_w` inject the random draws (tests)."""
-        module, guide, _ = _unwrap(net)
+        module, guide, kw_cond_w = _unwrap(net)
         B = init_x.shape[0]
         dev = init_x.device
-        if cond_w is not None:
-            if net_cond_w is None:
-                net_cond_w = 4.0 * self.rng.uniform((B,), dev)       # :247-251
+        student_w = None
+        if cond_w is not None and net_cond_w is None:
+            net_cond_w = 4.0 * self.rng.uniform((B,), dev)           # :247-251
+        if self.teacher_net is not None and self.sampler != "teacher_test":
+            # :252-255 during distillation the student is conditioned on w instead of doing classifier-free guidance
+            student_w = ops.aligned(net_cond_w.float()) if net_cond_w is not None else None
+            cond_w = None
+        teacher_w = None
+        if self.sampler == "teacher_test":                            # :271-278 guided teacher with the student's w
+            module = self.teacher_net
+            teacher_w = kw_cond_w if kw_cond_w is not None else net_cond_w
+            if teacher_w is None:
+                raise ValueError("sampler='teacher_test' needs a guidance weight (cond_w)")
+            cond_w = 0.5
+        if teacher_w is not None:
+            w = ops.aligned(teacher_w.float())
+        elif cond_w is not None:
             if isinstance(self.sample_cond_w, torch.Tensor):
                 w = self.sample_cond_w.to(dev).float().expand(B).contiguous()
             elif self.sample_cond_w is not None and float(self.sample_cond_w) != -1.0:
@@ -155,7 +211,7 @@ class GaussianDiffusion:
                 w = ops.aligned(net_cond_w.float())                   # :257
         else:
             w = None
-        if self.sampler not in ("ddim", "noisy"):
+        if self.sampler not in ("ddim", "noisy", "teacher_test"):
             raise NotImplementedError(self.sampler)
         if w is not None and guide is None:
             raise ValueError("classifier-free guidance needs class labels (net must carry guide=)")
@@ -168,7 +224,7 @@ class GaussianDiffusion:
             lt, ls = logsnr_schedule_cosine_host(u_t), logsnr_schedule_cosine_host(u_s)
             if w is None:
                 lvec = torch.full((B,), float(lt), device=dev)
-                v = module.forward_hip(z_t, lvec, guide, None)
+                v = module.forward_hip(z_t, lvec, guide, student_w)
                 vu = None
             else:
                 lvec = torch.full((2 * B,), float(lt), device=dev)

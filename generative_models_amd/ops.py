@@ -400,8 +400,8 @@ def q_sample(x, eps, u):
     return logsnr, z
 
 
-def v_loss(v, z, x, eps, logsnr, grad_scale=None):
-    """-> (loss_b, x_mse, eps_mse, dv or None)."""
+def v_loss(v, z, x, eps, logsnr, grad_scale=None, loss_type=0):
+    """-> (loss_b, x_mse, eps_mse, dv or None).  loss_type 0 'snr_trunc', 1 'snr'."""
     for t, nm in ((v, "v"), (z, "z"), (x, "x"), (eps, "eps"), (logsnr, "logsnr")):
         _f32(t, nm)
     B = x.shape[0]
@@ -411,7 +411,7 @@ def v_loss(v, z, x, eps, logsnr, grad_scale=None):
     xm = torch.empty_like(loss_b); em = torch.empty_like(loss_b)
     dv = torch.empty_like(v) if grad_scale is not None else None
     check(lib.gmk_v_loss(_p(v), _p(z), _p(x), _p(eps), _p(logsnr), _p(loss_b), _p(xm), _p(em), _p(dv),
-                         float(grad_scale or 0.0), B, n, _s()), "v_loss")
+                         float(grad_scale or 0.0), loss_type, B, n, _s()), "v_loss")
     return loss_b, xm, em, dv
 
 
@@ -431,6 +431,43 @@ def sampler_step(v, z, logsnr_t, logsnr_s, is_last, v_uncond=None, cond_w=None, 
     check(lib.gmk_sampler_step(_p(v), _p(v_uncond), _p(cond_w), _p(z), _p(noise), float(logsnr_t), float(logsnr_s),
                                int(is_last), _p(z_next), _p(xp), _p(ep), B, n, _s()), "sampler_step")
     return z_next, xp, ep
+
+
+def logsnr_schedule(B, device, u=None, i_times=None, num_steps=1, shift=0.0, want_u=False):
+    """logsnr = schedule(u - shift), u given or (i_times + 1) / num_steps.  -> logsnr (, u_shifted)"""
+    if u is not None:
+        _f32(u, "u")
+    if i_times is not None:
+        _chk(i_times, torch.int64, "i_times")
+    logsnr = torch.empty((B,), device=device, dtype=torch.float32)
+    uo = torch.empty((B,), device=device, dtype=torch.float32) if want_u else None
+    check(lib.gmk_logsnr_schedule(_p(u), _p(i_times), int(num_steps), float(shift), _p(uo), _p(logsnr), B, _s()),
+          "logsnr_schedule")
+    return (logsnr, uo) if want_u else logsnr
+
+
+def ddim_step_vec(v, z, logsnr_t, logsnr_s, v_uncond=None, cond_w=None):
+    """Teacher DDIM step with per-sample times.  -> (z_s, x_pred, eps_pred)"""
+    for t, nm in ((v, "v"), (z, "z"), (logsnr_t, "logsnr_t"), (logsnr_s, "logsnr_s")):
+        _f32(t, nm)
+    B = z.shape[0]
+    n = z.numel() // B
+    zs, xp, ep = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+    check(lib.gmk_ddim_step_vec(_p(v), _p(v_uncond), _p(cond_w), _p(z), _p(logsnr_t), _p(logsnr_s), _p(zs), _p(xp), _p(ep), B, n,
+                                _s()), "ddim_step_vec")
+    return zs, xp, ep
+
+
+def distill_target(z_teacher, z_t, x_pred_teacher, logsnr, logsnr_s, i_times):
+    for t, nm in ((z_teacher, "z_teacher"), (z_t, "z_t"), (x_pred_teacher, "x_pred"), (logsnr, "logsnr"), (logsnr_s, "logsnr_s")):
+        _f32(t, nm)
+    _chk(i_times, torch.int64, "i_times")
+    B = z_t.shape[0]
+    n = z_t.numel() // B
+    xt, et = torch.empty_like(z_t), torch.empty_like(z_t)
+    check(lib.gmk_distill_target(_p(z_teacher), _p(z_t), _p(x_pred_teacher), _p(logsnr), _p(logsnr_s), _p(i_times), _p(xt), _p(et),
+                                 B, n, _s()), "distill_target")
+    return xt, et
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):

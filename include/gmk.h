@@ -151,7 +151,9 @@ int gmk_q_sample(const float* x, const float* eps, const float* u, float* logsnr
  * x_hat = clip(alpha z - sigma v); eps_hat = eps_from_x; loss_b = max(mean (x_hat-x)^2, mean (eps_hat-eps)^2);
  * dv (optional) = d(grad_scale * sum_b loss_b)/dv.  loss_b/x_mse/eps_mse: fp32 [B]. */
 int gmk_v_loss(const float* v, const float* z, const float* x, const float* eps, const float* logsnr, float* loss_b,
-               float* x_mse, float* eps_mse, float* dv, float grad_scale, int B, int64_t n, void* stream);
+               float* x_mse, float* eps_mse, float* dv, float grad_scale, int loss_type, int B, int64_t n, void* stream);
+/* loss_type 0 = 'snr_trunc' (max of the two MSEs, :168-169), 1 = 'snr' (eps MSE only, :170-171, distillation step1);
+ * x / eps are the denoising targets (x0, eps) or the teacher's (x_target, eps_target). */
 /* one reverse step on a batch (gaussian_diffusion.py:189-243,174-187,292):
  *   v: conditional net output; v_uncond/cond_w: NULL or the unconditional output + per-sample guidance weight;
  *   noise: NULL -> DDIM update, else ancestral ('noisy') update with that noise; is_last: the i == 0 select.
@@ -159,6 +161,20 @@ int gmk_v_loss(const float* v, const float* z, const float* x, const float* eps,
 int gmk_sampler_step(const float* v, const float* v_uncond, const float* cond_w, const float* z, const float* noise,
                      float logsnr_t, float logsnr_s, int is_last, float* z_next, float* x_pred, float* eps_pred,
                      int B, int64_t n, void* stream);
+
+/* ---- progressive distillation (gaussian_diffusion.py:87-91,105-154) ------------------------------------------ */
+/* logsnr[b] = schedule(u[b] - shift) with u given, or u = fp32(i_times[b] + 1) / num_steps (discrete time, :90-91);
+ * u_out (optional) receives the shifted u */
+int gmk_logsnr_schedule(const float* u, const int64_t* i_times, int num_steps, float shift, float* u_out, float* logsnr,
+                        int B, void* stream);
+/* one DDIM step with per-sample times logsnr_t[b] -> logsnr_s[b] (teacher steps inside the loss, :116,:129-144) */
+int gmk_ddim_step_vec(const float* v, const float* v_uncond, const float* cond_w, const float* z, const float* logsnr_t,
+                      const float* logsnr_s, float* z_next, float* x_pred, float* eps_pred, int B, int64_t n, void* stream);
+/* x_target = (z_teacher - f z_t) / (alpha_s - f alpha_t), f = exp((softplus(l) - softplus(l_s)) / 2); the i == 0 rows
+ * take x_pred_teacher; eps_target = eps_from_x(z_t, x_target, l)  (:147-154) */
+int gmk_distill_target(const float* z_teacher, const float* z_t, const float* x_pred_teacher, const float* logsnr,
+                       const float* logsnr_s, const int64_t* i_times, float* x_target, float* eps_target, int B, int64_t n,
+                       void* stream);
 
 /* ---- optimiser (torch.optim.Adam defaults as diffusion_model.py:56 uses it), flat fp32 arena ------------- */
 int gmk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

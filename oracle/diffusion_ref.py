@@ -168,6 +168,52 @@ def sample(params, init_x, guide, num_steps, sampler="ddim", cond_w=None, noises
     return z_t
 
 
+def ddim_step_vec(params, logsnr_t, logsnr_s, z_t, guide=None, net_cond_w=None, cf_w=None, mean_type="v"):
+    """gaussian_diffusion.py:189-213 with per-sample [B] times (the teacher steps inside the distillation loss).
+    net_cond_w conditions the net on w (cond_w_embed); cf_w applies classifier-free guidance with weight w."""
+    out = model_outputs(unet_ref.unet_forward(params, z_t, logsnr_t, guide=guide, cond_w=net_cond_w), z_t, logsnr_t, mean_type)
+    x_pred, eps_pred = out["model_x"], out["model_eps"]
+    if cf_w is not None:
+        unc = model_outputs(unet_ref.unet_forward(params, z_t, logsnr_t, guide=-torch.ones_like(guide), cond_w=net_cond_w),
+                            z_t, logsnr_t, mean_type)
+        w = bcast(cf_w, z_t.shape)
+        eps = (1 + w) * eps_pred + (-w) * unc["model_eps"]
+        x_pred = torch.clip(predict_x_from_eps(z_t, eps, logsnr_t), -1.0, 1.0)
+        eps_pred = predict_eps_from_x(z_t, x_pred, logsnr_t)
+    ls = bcast(logsnr_s, z_t.shape)
+    z_s = torch.sqrt(torch.sigmoid(ls)) * x_pred + torch.sqrt(torch.sigmoid(-ls)) * eps_pred
+    return z_s, x_pred, eps_pred
+
+
+def distill_losses(student, teacher, x, y, eps, cond_w, num_steps, mode, u=None, i_times=None):
+    """gaussian_diffusion.py:81-172, teacher branches (:87-91,:105-154), draws injected.
+    mode 'step1': u given; 'step2': integer i_times given (u = (i+1)/T)."""
+    if mode == "step2":
+        u = (i_times + 1).to(x.dtype) / num_steps
+    logsnr = logsnr_schedule_cosine(u)
+    z_t = q_sample(x, logsnr, eps)
+    u_s = u - 1.0 / num_steps
+    logsnr_s = logsnr_schedule_cosine(u_s)
+    with torch.no_grad():
+        if mode == "step1":
+            _, x_target, eps_target = ddim_step_vec(teacher, logsnr, logsnr_s, z_t, guide=y, cf_w=cond_w)
+        else:
+            logsnr_mid = logsnr_schedule_cosine(u - 0.5 / num_steps)
+            z_mid, _, _ = ddim_step_vec(teacher, logsnr, logsnr_mid, z_t, guide=y, net_cond_w=cond_w)
+            z_teacher, x_pred_teacher, _ = ddim_step_vec(teacher, logsnr_mid, logsnr_s, z_mid, guide=y, net_cond_w=cond_w)
+            alpha_s = bcast(torch.sqrt(torch.sigmoid(logsnr_s)), x.shape)
+            alpha_t = bcast(torch.sqrt(torch.sigmoid(logsnr)), x.shape)
+            frac = bcast(torch.exp(0.5 * (torch.nn.functional.softplus(logsnr) - torch.nn.functional.softplus(logsnr_s))), x.shape)
+            x_target = (z_teacher - frac * z_t) / (alpha_s - frac * alpha_t)
+            x_target = torch.where(bcast(i_times == 0, x.shape), x_pred_teacher, x_target)
+            eps_target = predict_eps_from_x(z_t, x_target, logsnr)
+    out = run_model(student, z_t, logsnr, guide=y, cond_w=cond_w)
+    x_mse = torch.square(out["model_x"] - x_target).flatten(1).mean(1)
+    eps_mse = torch.square(out["model_eps"] - eps_target).flatten(1).mean(1)
+    loss = eps_mse if mode == "step1" else torch.maximum(x_mse, eps_mse)
+    return {"loss": loss, "x_target": x_target, "eps_target": eps_target, "logsnr": logsnr, "z_t": z_t}
+
+
 def adam_step(p, g, m, v, step, lr=3e-4, b1=0.9, b2=0.999, eps=1e-8):
     """torch.optim.Adam defaults as diffusion_model.py:56 uses them (no weight decay, no amsgrad).
     `step` is the 1-based step count AFTER incrementing.  Returns (p, m, v)."""

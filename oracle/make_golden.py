@@ -180,6 +180,57 @@ def gen_sample(C, S, B, T, seed, name):
     save(name, **out)
 
 
+def gen_distill(C, S, B, T, seed, name):
+    """Progressive-distillation losses (gaussian_diffusion.py:105-154): frozen teacher = closed-form fill, student =
+    0.9 x the same fill.  Draw order replayed: eps (randn), i or u, cond_w = 4*rand_like(u)."""
+    teacher = ref_net(C)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    x0, y = inputs(B, S, seed)
+    y = y.clone(); y[0] = 3
+    out = {"x0": x0, "y": y}
+    for mode in ("step1", "step2"):
+        student = ref_net(C).train()
+        with torch.no_grad():
+            for p in student.parameters():
+                p.mul_(0.9)
+        diff = R_gd.GaussianDiffusion(mean_type="v", num_steps=T, teacher_net=teacher, teacher_mode=mode, sampler="ddim",
+                                      sample_cond_w=-1.0)
+        torch.manual_seed(seed)
+        eps = torch.randn(x0.shape)
+        if mode == "step2":
+            i = torch.randint(T, (B,)); i[1] = 0              # exercise the i == 0 select (:153)
+            u = (i + 1).to(x0.dtype) / T
+        else:
+            i = None
+            u = torch.rand(size=(B,))
+        w_raw = torch.rand_like(u)
+        w = 4.0 * w_raw                                       # :107 (the reference multiplies the draw by 4 itself)
+        # feed exactly these draws: patch the generator calls by re-seeding is not enough once i is edited, so monkeypatch
+        draws = {"randn": [eps], "randint": [i], "rand": [u], "rand_like": [w_raw]}
+        orig = (torch.randn, torch.randint, torch.rand, torch.rand_like)
+        torch.randn = lambda *a, **k: draws["randn"].pop(0)
+        torch.randint = lambda *a, **k: draws["randint"].pop(0)
+        torch.rand = lambda *a, **k: draws["rand"].pop(0)
+        torch.rand_like = lambda *a, **k: draws["rand_like"].pop(0)
+        try:
+            losses = diff.training_losses(net=partial(student, guide=y), x=x0)["loss"]
+        finally:
+            torch.randn, torch.randint, torch.rand, torch.rand_like = orig
+        losses.mean().backward()
+        out[f"{mode}_eps"] = eps; out[f"{mode}_cond_w"] = w
+        out[f"{mode}_u"] = u
+        if i is not None:
+            out[f"{mode}_i"] = i
+        out[f"{mode}_loss_b"] = losses.detach()
+        names = [k for k, _ in student.named_parameters()]
+        out["grad_names"] = np.array(names)
+        out[f"{mode}_grad_norms"] = torch.stack([p.grad.norm() if p.grad is not None else torch.tensor(0.0)
+                                                 for _, p in student.named_parameters()])
+        out[f"{mode}_grad_cond_w_embed"] = student.cond_w_embed[2].weight.grad.detach().clone()
+    save(name, **out)
+
+
 def main():
     torch.set_num_threads(4)
     gen_schedule()
@@ -196,6 +247,8 @@ def main():
     gen_train(128, 28, 2, 22, "train_c128_s28.npz")
     gen_sample(32, 8, 3, 4, 30, "sample_c32_s8_T4.npz")
     gen_sample(32, 12, 2, 8, 31, "sample_c32_s12_T8.npz")
+    gen_distill(64, 8, 3, 8, 40, "distill_c64_s8.npz")
+    gen_distill(128, 8, 3, 8, 41, "distill_c128_s8.npz")
 
 
 if __name__ == "__main__":

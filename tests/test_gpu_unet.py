@@ -215,3 +215,37 @@ def test_diffusion_model_methods():
     assert s2.shape == (4, 1, 28, 28)
     model.evaluate(common.NullWriter(), x, y, 0)
     assert model.last_eval["samples"].dtype == torch.uint8 and model.last_eval["sampling_process"].shape[0] == 3
+
+
+@pytest.mark.parametrize("mode", ["step1", "step2"])
+def test_distillation_vs_golden(golden, mode):
+    """teacher branches of the loss on the HIP path (fp32 mode) vs the reference's own numbers."""
+    from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    from generative_models_amd.diffusion.simple_unet import SimpleUnet
+    from oracle import unet_ref as U
+    g = golden("distill_c128_s8.npz")
+    params = U.closed_form_params(128)
+    teacher = SimpleUnet(128, 0.0, compute_dtype=torch.float32); teacher.load_state_dict(params); teacher = teacher.cuda().eval()
+    student = SimpleUnet(128, 0.0, compute_dtype=torch.float32)
+    student.load_state_dict({k: 0.9 * v for k, v in params.items()}); student = student.cuda()
+    diff = GaussianDiffusion(mean_type="v", num_steps=8, teacher_net=teacher, teacher_mode=mode)
+    x0, y = T(g["x0"]).cuda(), T(g["y"]).cuda()
+    kw = dict(u=T(g[f"{mode}_u"]).cuda()) if mode == "step1" else dict(i_times=T(g[f"{mode}_i"]).cuda())
+    B = x0.shape[0]
+    out = diff.train_forward_backward(net=partial(student, guide=y), x=x0, grad_scale=1.0 / B, eps=T(g[f"{mode}_eps"]).cuda(),
+                                      cond_w=T(g[f"{mode}_cond_w"]).cuda(), **kw)
+    assert rel_err(out["loss"], T(g[f"{mode}_loss_b"])) < 1e-3
+    names = [str(n) for n in g["grad_names"]]
+    norms = torch.stack([student.grad(n).norm() for n in names]).cpu()
+    ref = T(g[f"{mode}_grad_norms"])
+    ok = (norms - ref).abs() <= 3e-3 * ref.abs() + 1e-5 * ref.abs().max()
+    assert bool(ok.all()), [(names[i], float(norms[i]), float(ref[i])) for i in (~ok).nonzero().flatten()[:8]]
+    assert rel_err(student.grad("cond_w_embed.2.weight"), T(g[f"{mode}_grad_cond_w_embed"])) < 3e-3
+    # the same loss through the autograd bridge
+    with torch.no_grad():
+        l2 = diff.training_losses(net=partial(student, guide=y), x=x0, eps=T(g[f"{mode}_eps"]).cuda(),
+                                  cond_w=T(g[f"{mode}_cond_w"]).cuda(), **kw)["loss"]
+    assert rel_err(l2, T(g[f"{mode}_loss_b"])) < 1e-3
+    # sampling a distilled student: conditioned on w, no second (unconditional) evaluation
+    zs, xs, _ = diff.sample(net=partial(student, guide=y), init_x=T(g[f"{mode}_eps"]).cuda(), cond_w=0.5)
+    assert zs.shape[0] == 8 and torch.equal(zs[-1], xs[-1])

@@ -140,3 +140,21 @@ def test_samplers(golden, name, C, steps):
         close(zs, g["anc_zs"], 1e-4); close(xs, g["anc_xs"], 1e-4)
         # final-step select (gaussian_diffusion.py:292): last z equals last x_pred
         assert torch.equal(zs[-1], xs[-1])
+
+
+@pytest.mark.parametrize("name,C", [("distill_c64_s8.npz", 64), ("distill_c128_s8.npz", 128)])
+@pytest.mark.parametrize("mode", ["step1", "step2"])
+def test_distillation_losses(golden, name, C, mode):
+    """Teacher branches of training_losses (gaussian_diffusion.py:87-91,105-154), incl. the integer time path (I3)."""
+    g = golden(name)
+    teacher = U.closed_form_params(C)
+    student = {k: (0.9 * v).clone().requires_grad_(True) for k, v in teacher.items()}
+    kw = dict(u=T(g[f"{mode}_u"])) if mode == "step1" else dict(i_times=T(g[f"{mode}_i"]))
+    out = D.distill_losses(student, teacher, T(g["x0"]), T(g["y"]), T(g[f"{mode}_eps"]), T(g[f"{mode}_cond_w"]), 8, mode, **kw)
+    close(out["loss"], g[f"{mode}_loss_b"], 5e-5)
+    out["loss"].mean().backward()
+    names = [str(n) for n in g["grad_names"]]
+    norms = torch.stack([student[n].grad.norm() if student[n].grad is not None else torch.tensor(0.0) for n in names])
+    ref = T(g[f"{mode}_grad_norms"])
+    assert bool(((norms - ref).abs() <= 2e-3 * ref.abs() + 1e-5 * ref.abs().max()).all())
+    close(student["cond_w_embed.2.weight"].grad, g[f"{mode}_grad_cond_w_embed"], 5e-4)
