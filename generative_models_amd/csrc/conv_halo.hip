@@ -198,6 +198,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
         }
     };
 
+    // residual tile of this lane (same layout as its accumulators), prefetched three K-steps before the epilogue so its
+    // HBM latency hides under the last MFMA steps instead of stalling the epilogue (and draining the next tile's DMA)
+    u32x2_t resv[2][2][4];
+    auto prefetch_residual = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ml = wm * 64 + i * 32 + r;
+            const int m = tile * p.TP + ml;
+            const bool live = ml < p.TP && m < p.M;
+            const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cb = nblk + wn * 64 + j * 32;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const unsigned off = live ? row_b + (unsigned)(cb + 8 * q4 + 4 * h) * ES : kBadOff;
+                    resv[i][j][q4] = __builtin_amdgcn_raw_buffer_load_b64(rsr, off, 0, 0);
+                }
+            }
+        }
+    };
+
     auto epilogue = [&](int tile) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -244,9 +266,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                 if (p.residual) {
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-                        const unsigned off = live ? row_b + (unsigned)(cb + 8 * q4 + 4 * h) * ES : kBadOff;
-                        const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rsr, off, 0, 0);
-                        const bf16x4 rb = __builtin_bit_cast(bf16x4, raw);
+                        const bf16x4 rb = __builtin_bit_cast(bf16x4, resv[i][j][q4]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[4 * q4 + e] += (float)rb[e];
                     }
@@ -345,8 +365,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                         if (p.stats) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
                     } else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                } else if (tap == 7) {      // the 16 residual loads issued behind tap 6's DMA are younger than this step's data
+                    if (last_ph && p.residual) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 } else if (tap == 8) {
-                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    if (last_ph && p.residual) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 }
@@ -355,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                 if (tap < 7) issue_w(sq, tap + 2, ph);
                 else issue_w(sq, tap - 7, ph_next);
                 if (tap < 7) issue_fill(hbuf ^ 1, ph_next, tap);
+                if (tap == 6 && last_ph && p.residual) prefetch_residual(tile);
                 // ---- compute
                 compute(hbuf, st, (tap / 3 - 1) * WE + (tap % 3 - 1));
                 st = st == 2 ? 0 : st + 1;
