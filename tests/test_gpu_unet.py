@@ -249,3 +249,28 @@ def test_distillation_vs_golden(golden, mode):
     # sampling a distilled student: conditioned on w, no second (unconditional) evaluation
     zs, xs, _ = diff.sample(net=partial(student, guide=y), init_x=T(g[f"{mode}_eps"]).cuda(), cond_w=0.5)
     assert zs.shape[0] == 8 and torch.equal(zs[-1], xs[-1])
+
+
+@pytest.mark.parametrize("B,S", [(1, 28), (5, 32), (7, 28)])
+def test_odd_batches_and_sizes_bf16_vs_fp32_vs_oracle(B, S):
+    """Ragged shapes: single image, batch sizes that leave partial tiles in every kernel, the pad32 size."""
+    from oracle import unet_ref as U
+    net32, params = make_net(torch.float32, closed_form=False)
+    net16, _ = make_net(torch.bfloat16, closed_form=False)
+    g = torch.Generator().manual_seed(B * 100 + S)
+    z = torch.randn((B, 1, S, S), generator=g)
+    l = torch.rand((B,), generator=g) * 30 - 15
+    y = torch.randint(-1, 10, (B,), generator=g)
+    dout = torch.randn((B, 1, S, S), generator=g)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = U.unet_forward(p, z, l, guide=y)
+    ref.backward(dout)
+    for net, tol in ((net32, 1e-3), (net16, 1e-2)):
+        ctx = {}
+        out = net.forward_hip(z.cuda(), l.cuda(), y.cuda(), None, ctx=ctx)
+        assert rel_err(out, ref) < tol
+        net.backward_hip(ctx, dout.cuda())
+        for name in ("down.seq.1.in_layers.2.weight", "up.seq.3.1.conv.weight", "down.seq.6.conv.weight",
+                     "up.seq.5.skip_connection.weight", "out.2.weight", "time_embed.0.weight", "turn.out_layers.0.bias"):
+            gr = p[name].grad
+            assert rel_err(net.grad(name), gr) < 6 * tol, name
