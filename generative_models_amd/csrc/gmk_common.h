@@ -89,8 +89,10 @@ __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
     *reinterpret_cast<bf16x4*>(p) = a;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float siluf_(float x) { return x / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE `1.0f / d` costs ~12 VALU issue slots more per element (div_scale / fma chain /
+// div_fmas / div_fixup plus hazard nops), which made the GroupNorm kernels VALU-bound instead of HBM-bound
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // 64-lane wave sum (butterfly; every lane ends with the total)
 __device__ __forceinline__ float wave_sum(float v) {

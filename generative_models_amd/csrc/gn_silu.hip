@@ -12,21 +12,40 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// A workgroup handles one (sample, channel slab).  Slabs narrower than the sample keep the set of lines the resident
+// workgroups of an XCD are sweeping (32 CUs x a few workgroups x HW*CS*2 B) inside that XCD's 4 MiB L2, so the second
+// sweep of the two-sweep kernels below is an L2 hit instead of a second trip to HBM.  Workgroup ids round-robin over the 8
+// XCDs, so the slabs of one sample are given ids 8 apart: they run on the same XCD at about the same time and share
+// the 128-B lines that straddle two slabs.
+__device__ __forceinline__ void slab_of_block(int idx, int nslab, int B, int& b, int& slab) {
+    if ((B & 7) == 0) {
+        const int xcd = idx & 7, j = idx >> 3;
+        slab = j % nslab;
+        b = (j / nslab) * 8 + xcd;
+    } else {
+        b = idx / nslab;
+        slab = idx % nslab;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
                                                               float* __restrict__ mean, float* __restrict__ rstd,
                                                               int HW, int C, int G, float eps,
-                                                              const float* __restrict__ part, int TP, int ntiles) {
+                                                              const float* __restrict__ part, int TP, int ntiles,
+                                                              int CS, int B) {
     __shared__ float red[kThreads * 4];
     __shared__ float smean[64], srstd[64];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int nvec = C >> 3, planes = kThreads / nvec;
+    const int tid = threadIdx.x;
+    int b, slab;
+    slab_of_block(blockIdx.x, C / CS, B, b, slab);
+    const int nvec = CS >> 3, planes = kThreads / nvec;
     const int vec = tid % nvec, pl = tid / nvec;
-    const int cpg = C / G;
-    const T* xb = x + (size_t)b * HW * C + vec * 8;
-    T* yb = y + (size_t)b * HW * C + vec * 8;
+    const int cpg = C / G, c0 = slab * CS, g0 = c0 / cpg, gps = CS / cpg;
+    const T* xb = x + (size_t)b * HW * C + c0 + vec * 8;
+    T* yb = y + (size_t)b * HW * C + c0 + vec * 8;
 
     if (part) {
         // statistics from the producer's partial sums: [tile][8 pixel groups][2 sample slots][C/4 units][sum, sumsq],
@@ -54,6 +73,7 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
         }
     } else {
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll 4
     for (int p = pl; p < HW; p += planes) {
         float v[8];
         load8(xb + (size_t)p * C, v);
@@ -64,7 +84,7 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
     }
     red[tid * 4 + 0] = s0; red[tid * 4 + 1] = q0; red[tid * 4 + 2] = s1; red[tid * 4 + 3] = q1;
     __syncthreads();
-    if (tid < G) {
+    if (tid < gps) {
         const int hv_per_g = cpg >> 2;   // 4-channel half-vectors per group
         float s = 0.f, q = 0.f;
         for (int j = 0; j < hv_per_g; ++j) {
@@ -79,17 +99,18 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
         const float var = fmaxf(q / n - m * m, 0.f);
         const float r = 1.0f / sqrtf(var + eps);
         smean[tid] = m; srstd[tid] = r;
-        mean[b * G + tid] = m; rstd[b * G + tid] = r;
+        mean[b * G + g0 + tid] = m; rstd[b * G + g0 + tid] = r;
     }
     }
     __syncthreads();
     float sc[8], sh[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int c = vec * 8 + i, g = c / cpg;
+        const int cl = vec * 8 + i, g = cl / cpg, c = c0 + cl;
         sc[i] = srstd[g] * gamma[c];
         sh[i] = beta[c] - smean[g] * sc[i];
     }
+#pragma unroll 4
     for (int p = pl; p < HW; p += planes) {
         float v[8];
         load8(xb + (size_t)p * C, v);
@@ -104,28 +125,31 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd, const T* __restrict__ dadd1,
     const T* __restrict__ dadd2, T* __restrict__ dx, float* __restrict__ dgp, float* __restrict__ dbp,
-    float* __restrict__ dxsum, int dxsum_stride, int HW, int C, int G) {
+    float* __restrict__ dxsum, int dxsum_stride, int HW, int C, int G, int CS, int B) {
     __shared__ float red[kThreads * 16];
     __shared__ float chg[256], chb[256];
     __shared__ float sA[64], sB[64];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int nvec = C >> 3, planes = kThreads / nvec;
+    const int tid = threadIdx.x;
+    int b, slab;
+    slab_of_block(blockIdx.x, C / CS, B, b, slab);
+    const int nvec = CS >> 3, planes = kThreads / nvec;
     const int vec = tid % nvec, pl = tid / nvec;
-    const int cpg = C / G;
-    const size_t base = (size_t)b * HW * C + vec * 8;
+    const int cpg = C / G, c0 = slab * CS, g0 = c0 / cpg, gps = CS / cpg;
+    const size_t base = (size_t)b * HW * C + c0 + vec * 8;
 
     float gam[8], bet[8], mu[8], rs[8];
     int grp[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int c = vec * 8 + i;
-        grp[i] = c / cpg;
+        const int cl = vec * 8 + i, c = c0 + cl;
+        grp[i] = cl / cpg;
         gam[i] = gamma[c]; bet[i] = beta[c];
-        mu[i] = mean[b * G + grp[i]]; rs[i] = rstd[b * G + grp[i]];
+        mu[i] = mean[b * G + g0 + grp[i]]; rs[i] = rstd[b * G + g0 + grp[i]];
     }
     float ag[8], ab[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+#pragma unroll 2
     for (int p = pl; p < HW; p += planes) {
         float xv[8], dv[8];
         load8(x + base + (size_t)p * C, xv);
@@ -143,7 +167,7 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) { red[tid * 16 + i] = ag[i]; red[tid * 16 + 8 + i] = ab[i]; }
     __syncthreads();
-    if (tid < C) {
+    if (tid < CS) {
         const int vv = tid >> 3, i = tid & 7;
         float a = 0.f, bb = 0.f;
         for (int p = 0; p < planes; ++p) {
@@ -151,16 +175,16 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
             bb += red[(p * nvec + vv) * 16 + 8 + i];
         }
         chg[tid] = a; chb[tid] = bb;
-        dgp[(size_t)b * C + tid] = a;
-        dbp[(size_t)b * C + tid] = bb;
+        dgp[(size_t)b * C + c0 + tid] = a;
+        dbp[(size_t)b * C + c0 + tid] = bb;
     }
     __syncthreads();
-    if (tid < G) {
+    if (tid < gps) {
         float A = 0.f, Bq = 0.f;
         for (int j = 0; j < cpg; ++j) {
-            const int c = tid * cpg + j;
-            A = fmaf(gamma[c], chb[c], A);
-            Bq = fmaf(gamma[c], chg[c], Bq);
+            const int cl = tid * cpg + j;
+            A = fmaf(gamma[c0 + cl], chb[cl], A);
+            Bq = fmaf(gamma[c0 + cl], chg[cl], Bq);
         }
         const float inv_n = 1.f / ((float)cpg * (float)HW);
         sA[tid] = A * inv_n; sB[tid] = Bq * inv_n;
@@ -169,6 +193,7 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
     float cA[8], cB[8], xs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { cA[i] = sA[grp[i]]; cB[i] = sB[grp[i]]; xs[i] = 0.f; }
+#pragma unroll 2
     for (int p = pl; p < HW; p += planes) {
         float xv[8], dv[8], o[8];
         load8(x + base + (size_t)p * C, xv);
@@ -202,11 +227,11 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < 8; ++i) red[tid * 16 + i] = xs[i];
         __syncthreads();
-        if (tid < C) {
+        if (tid < CS) {
             const int vv = tid >> 3, i = tid & 7;
             float a = 0.f;
             for (int p = 0; p < planes; ++p) a += red[(p * nvec + vv) * 16 + i];
-            dxsum[(size_t)b * dxsum_stride + tid] = a;
+            dxsum[(size_t)b * dxsum_stride + c0 + tid] = a;
         }
     }
 }
@@ -513,6 +538,18 @@ bool gn_shape_ok(int C, int G) {
     return cpg == 4 || cpg == 8 || cpg == 16;
 }
 
+// Channel slab width of one workgroup: GMK_GN_KERNEL / gmk_set_kernel_choice(gn) 1 = whole sample, 3 = 32 channels,
+// 4 = 64 channels, otherwise automatic.
+int gn_slab_channels(int mode, int C, int G, int HW, int elem_bytes, bool backward) {
+    const int cpg = C / G;
+    int CS = C;
+    if (mode == 3) CS = 32;
+    else if (mode == 4) CS = 64;
+    else if (mode != 1) CS = backward && (int64_t)HW * C * elem_bytes > 65536 ? 32 : C;   // measured: tools/gn_bench.py
+    if (CS > C || C % CS || CS % cpg || (CS & 7) || kThreads % (CS >> 3)) CS = C;
+    return CS;
+}
+
 }  // namespace
 
 extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
@@ -538,14 +575,15 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
         else
             gn_silu_fwd_lds_kernel<1024><<<grid, kThreads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta,
                                                                                  mean, rstd, HW, C, groups, eps, (unsigned)nbytes);
-    } else if (dtype == GMK_BF16)
-        gn_silu_fwd_kernel<bf16_t><<<B, kThreads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta,
-                                                                            mean, rstd, HW, C, groups, eps, stats_part,
-                                                                            tile_pixels, ntiles);
-    else if (dtype == GMK_F32)
-        gn_silu_fwd_kernel<float><<<B, kThreads, 0, gmk_stream(stream)>>>((const float*)x, (float*)y, gamma, beta,
-                                                                          mean, rstd, HW, C, groups, eps, stats_part,
-                                                                          tile_pixels, ntiles);
+    } else if (dtype == GMK_BF16) {
+        const int CS = stats_part ? C : gn_slab_channels(gn_mode, C, groups, HW, 2, false);
+        gn_silu_fwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
+            (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, HW, C, groups, eps, stats_part, tile_pixels, ntiles, CS, B);
+    } else if (dtype == GMK_F32) {
+        const int CS = stats_part ? C : gn_slab_channels(gn_mode, C, groups, HW, 4, false);
+        gn_silu_fwd_kernel<float><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
+            (const float*)x, (float*)y, gamma, beta, mean, rstd, HW, C, groups, eps, stats_part, tile_pixels, ntiles, CS, B);
+    }
     else
         GMK_REQUIRE(false, "gmk_gn_silu_fwd: bad dtype %d", dtype);
     return gmk_check_launch("gmk_gn_silu_fwd");
@@ -577,14 +615,17 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
             gn_silu_bwd_lds_kernel<1024><<<grid, kThreads, 0, gmk_stream(stream)>>>(
                 (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2,
                 (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, (unsigned)nbytes);
-    } else if (dtype == GMK_BF16)
-        gn_silu_bwd_kernel<bf16_t><<<B, kThreads, 0, gmk_stream(stream)>>>(
+    } else if (dtype == GMK_BF16) {
+        const int CS = gn_slab_channels(gn_mode, C, groups, HW, 2, true);
+        gn_silu_bwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2,
-            (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups);
-    else if (dtype == GMK_F32)
-        gn_silu_bwd_kernel<float><<<B, kThreads, 0, gmk_stream(stream)>>>(
+            (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, CS, B);
+    } else if (dtype == GMK_F32) {
+        const int CS = gn_slab_channels(gn_mode, C, groups, HW, 4, true);
+        gn_silu_bwd_kernel<float><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const float*)dy, (const float*)x, gamma, beta, mean, rstd, (const float*)dadd1, (const float*)dadd2,
-            (float*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups);
+            (float*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, CS, B);
+    }
     else
         GMK_REQUIRE(false, "gmk_gn_silu_bwd: bad dtype %d", dtype);
     return gmk_check_launch("gmk_gn_silu_bwd");

@@ -2,249 +2,147 @@
 // Reference: gms/diffusion/simple_unet.py:92-94 (Downsample(1, channels, 1)) and :41 (Conv2d(channels, 1, 3, padding=1)).
 // Degenerate GEMM shapes (K = 9 or N = 1): HBM-bound streaming kernels, no MFMA.  Image-side tensors are NCHW
 // fp32 as the reference passes them; the network side is NHWC in `dtype`.
+//
+// All five kernels move the C-channel tensor exactly once (16 B per lane, a wave covers whole 256-B pixel rows) and
+// take the 1-channel image through L1/L2; a thread is (8-channel vector, pixel lane) and walks the flat pixel range of
+// its block with 32-bit counters (one division per thread, then increments — per-pixel 64-bit div/mod had made the
+// first version of these kernels 5x slower than their HBM time).  With one image channel the thread's 9x8 weights
+// live in registers; with more (CIFAR-shape configs) they are re-read from LDS.
 #include "gmk_common.h"
 
 namespace {
 
 constexpr int kMaxSmall = 4;   // max image channels handled (1 in the reference, 3 for the CIFAR-shape configs)
 
-// ---- stem forward: thread = (pixel, 8-channel vector) -----------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                      const float* __restrict__ bias, T* __restrict__ y, int B, int cin,
-                                                      int H, int W, int C) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [cin*9][C] then bias[C]
-    const int nw = cin * 9;
-    for (int i = threadIdx.x; i < nw * C; i += blockDim.x) {
-        const int co = i % C, k = i / C;                          // k = ci*9 + tap
-        wl[i] = w[(int64_t)co * nw + k];
+__device__ __forceinline__ int div_small(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
+
+// flat pixel g = b*HW + p, advanced by `step` (< HW or not) with increments only
+struct PixWalk {
+    int b, p;
+    __device__ __forceinline__ PixWalk(unsigned g, int HW) { b = (int)(g / (unsigned)HW); p = (int)(g - (unsigned)b * (unsigned)HW); }
+    __device__ __forceinline__ void advance(int step, int HW) {
+        p += step;
+        while (p >= HW) { p -= HW; ++b; }
     }
-    for (int i = threadIdx.x; i < C; i += blockDim.x) wl[nw * C + i] = bias[i];
-    __syncthreads();
-    const int nvec = C >> 3;
-    const int64_t total = (int64_t)B * H * W * nvec;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int vec = (int)(idx % nvec);
-        int64_t pix = idx / nvec;
-        const int ox = (int)(pix % W);
-        const int64_t t2 = pix / W;
-        const int oy = (int)(t2 % H);
-        const int64_t b = t2 / H;
-        float acc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = wl[nw * C + vec * 8 + i];
-        for (int ci = 0; ci < cin; ++ci) {
-            const float* xp = x + (b * cin + ci) * (int64_t)H * W;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = oy + ky - 1;
-                if (iy < 0 || iy >= H) continue;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = ox + kx - 1;
-                    if (ix < 0 || ix >= W) continue;
-                    const float xv = xp[iy * W + ix];
-                    const float* wp = wl + (ci * 9 + ky * 3 + kx) * C + vec * 8;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(xv, wp[i], acc[i]);
-                }
-            }
-        }
-        store8(y + pix * C + vec * 8, acc);
-    }
+};
+
+// sum over the 16 lanes of a DPP row; every lane of the row ends with the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
 }
 
-// ---- stem weight gradient: block = pixel range; thread = (pixel lane, 8-channel vector) ------------------
-template <typename T>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
-                                                        float* __restrict__ part, int64_t npix, int cin, int H, int W,
-                                                        int C, int64_t pix_per_blk) {
-    __shared__ float red[256 * 8];
+// ---- 1 -> C "expand" convolution: stem forward (FLIP = false) and head data gradient (FLIP = true) ---------
+//   stem:  y[b,p,c]  = bias[c] + sum_{s,t} x[b,s,p + off(t)]    * w[c][s][t]        w: [C][cs][3][3]
+//   head:  da[b,p,c] =           sum_{s,t} dout[b,s,p - off(t)] * w[s][c][t]        w: [cs][C][3][3]
+template <typename T, bool REGW, bool FLIP>
+__global__ __launch_bounds__(256) void expand3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, T* __restrict__ out, int cs, int H,
+                                                       int W, int C, float inv_w, unsigned npix, int ppb) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [cs][9][C] (only when !REGW)
     const int tid = threadIdx.x;
     const int nvec = C >> 3, planes = 256 / nvec;
     const int vec = tid % nvec, pl = tid / nvec;
-    const int64_t p0 = blockIdx.x * pix_per_blk;
-    const int64_t p1 = min(p0 + pix_per_blk, npix);
-    float* out = part + (int64_t)blockIdx.x * C * cin * 9;
-    for (int ci = 0; ci < cin; ++ci) {
-        float acc[9][8];
+    const int HW = H * W;
+    auto widx = [&](int c, int s, int t) { return FLIP ? (s * C + c) * 9 + t : (c * cs + s) * 9 + t; };
+    float wr[9][8], bs[8];
+    if (REGW) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
-        for (int64_t pix = p0 + pl; pix < p1; pix += planes) {
-            const int ox = (int)(pix % W);
-            const int64_t t2 = pix / W;
-            const int oy = (int)(t2 % H);
-            const int64_t b = t2 / H;
-            float d[8];
-            load8(dy + pix * C + vec * 8, d);
-            const float* xp = x + (b * cin + ci) * (int64_t)H * W;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = oy + ky - 1;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = ox + kx - 1;
-                    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                    const float xv = ok ? xp[iy * W + ix] : 0.f;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[ky * 3 + kx][i] = fmaf(xv, d[i], acc[ky * 3 + kx][i]);
-                }
-            }
+            for (int i = 0; i < 8; ++i) wr[t][i] = w[widx(vec * 8 + i, 0, t)];
+    } else {
+        for (int i = tid; i < cs * 9 * C; i += 256) {
+            const int c = i % C, t = (i / C) % 9, s = i / (9 * C);
+            wl[i] = w[widx(c, s, t)];
         }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 8; ++i) red[tid * 8 + i] = acc[t][i];
-            __syncthreads();
-            if (tid < C) {
-                const int vv = tid >> 3, i = tid & 7;
-                float s = 0.f;
-                for (int p = 0; p < planes; ++p) s += red[(p * nvec + vv) * 8 + i];
-                out[((int64_t)tid * cin + ci) * 9 + t] = s;     // reference layout [C][cin][3][3]
-            }
-        }
+        __syncthreads();
     }
-}
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bs[i] = bias ? bias[vec * 8 + i] : 0.f;
 
-// ---- head forward: nvec threads per pixel, each 8 channels x 9 taps, reduced with wave shuffles ----------
-template <typename T>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a, const float* __restrict__ w,
-                                                      const float* __restrict__ bias, float* __restrict__ out, int B,
-                                                      int cout, int H, int W, int C) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [cout][9][C]
-    for (int i = threadIdx.x; i < cout * 9 * C; i += blockDim.x) {
-        const int ci = i % C, t = (i / C) % 9, co = i / (9 * C);
-        wl[i] = w[((int64_t)co * C + ci) * 9 + t];
-    }
-    __syncthreads();
-    const int nvec = C >> 3;                 // 16 or 32: a power of two inside one wave
-    const int64_t npix = (int64_t)B * H * W;
-    const int64_t total = npix * nvec;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // every lane of a wave iterates the same number of times (total is a multiple of 64 when padded)
-    const int64_t total_pad = (total + 63) / 64 * 64;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total_pad; idx += stride) {
-        const bool live = idx < total;
-        const int vec = (int)(idx % nvec);
-        const int64_t pix = live ? idx / nvec : 0;
-        const int ox = (int)(pix % W);
-        const int64_t t2 = pix / W;
-        const int oy = (int)(t2 % H);
-        const int64_t b = t2 / H;
-        float acc[kMaxSmall] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy + ky - 1;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox + kx - 1;
-                if (!live || iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-                float v[8];
-                load8(a + (((b * H + iy) * W) + ix) * (int64_t)C + vec * 8, v);
-                for (int co = 0; co < cout; ++co) {
-                    const float* wp = wl + (co * 9 + ky * 3 + kx) * C + vec * 8;
-                    float s = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) s = fmaf(v[i], wp[i], s);
-                    acc[co] += s;
-                }
-            }
-        }
-        for (int co = 0; co < cout; ++co) {
-            float s = acc[co];
-            for (int off = nvec >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-            if (live && vec == 0) out[((b * cout + co) * H + oy) * (int64_t)W + ox] = s + bias[co];
-        }
-    }
-}
-
-// ---- head data gradient: thread = (pixel, 8-channel vector) ----------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ w,
-                                                        T* __restrict__ da, int B, int cout, int H, int W, int C) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [cout][9][C]
-    for (int i = threadIdx.x; i < cout * 9 * C; i += blockDim.x) {
-        const int ci = i % C, t = (i / C) % 9, co = i / (9 * C);
-        wl[i] = w[((int64_t)co * C + ci) * 9 + t];
-    }
-    __syncthreads();
-    const int nvec = C >> 3;
-    const int64_t total = (int64_t)B * H * W * nvec;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int vec = (int)(idx % nvec);
-        const int64_t pix = idx / nvec;
-        const int x0 = (int)(pix % W);
-        const int64_t t2 = pix / W;
-        const int y0 = (int)(t2 % H);
-        const int64_t b = t2 / H;
+    const unsigned g0 = blockIdx.x * (unsigned)ppb;
+    const unsigned g1 = min(g0 + (unsigned)ppb, npix);
+    if (g0 + pl >= g1) return;
+    PixWalk pw(g0 + pl, HW);
+    for (unsigned g = g0 + pl; g < g1; g += planes) {
+        const int oy = div_small(pw.p, inv_w), ox = pw.p - oy * W;
         float acc[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-        // out[oy][ox] used a[oy+ky-1][ox+kx-1]  =>  a[y0][x0] feeds out[y0-ky+1][x0-kx+1]
-        for (int co = 0; co < cout; ++co) {
-            const float* dp = dout + (b * cout + co) * (int64_t)H * W;
+        for (int i = 0; i < 8; ++i) acc[i] = bs[i];
+        for (int s = 0; s < (REGW ? 1 : cs); ++s) {
+            const float* ip = in + (size_t)(pw.b * cs + s) * HW;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const int oy = y0 - ky + 1;
-                if (oy < 0 || oy >= H) continue;
+                const int iy = FLIP ? oy + 1 - ky : oy + ky - 1;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int ox = x0 - kx + 1;
-                    if (ox < 0 || ox >= W) continue;
-                    const float d = dp[oy * W + ox];
-                    const float* wp = wl + (co * 9 + ky * 3 + kx) * C + vec * 8;
+                    const int ix = FLIP ? ox + 1 - kx : ox + kx - 1;
+                    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                    const float xv = ok ? ip[iy * W + ix] : 0.f;
+                    if (REGW) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(d, wp[i], acc[i]);
+                        for (int i = 0; i < 8; ++i) acc[i] = fmaf(xv, wr[ky * 3 + kx][i], acc[i]);
+                    } else {
+                        const float* wp = wl + (s * 9 + ky * 3 + kx) * C + vec * 8;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i] = fmaf(xv, wp[i], acc[i]);
+                    }
                 }
             }
         }
-        store8(da + pix * C + vec * 8, acc);
+        store8(out + (size_t)g * C + vec * 8, acc);
+        pw.advance(planes, HW);
     }
 }
 
-// ---- head weight (+bias) gradient: block = pixel range; thread = (pixel lane, 8-channel vector) ----------
-template <typename T>
-__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dout, const T* __restrict__ a,
-                                                        float* __restrict__ part, int64_t npix, int cout, int H, int W,
-                                                        int C, int64_t pix_per_blk) {
+// ---- weight gradients of both: the C-channel tensor is read once per image channel, the image through L1 --------
+//   stem (FLIP = false): dw[c][s][t] = sum_{b,p} x[b,s,p + off(t)]    * dy[b,p,c]
+//   head (FLIP = true):  dw[s][c][t] = sum_{b,p} dout[b,s,p - off(t)] * a[b,p,c];  db[s] = sum dout[b,s,p]
+// part: [nblk][cs*C*9 (+ cs bias sums when FLIP)] per-block partials in the reference's weight layout.
+template <typename T, bool FLIP>
+__global__ __launch_bounds__(256) void wgrad3x3_kernel(const float* __restrict__ small, const T* __restrict__ big,
+                                                      float* __restrict__ part, int cs, int H, int W, int C, float inv_w,
+                                                      unsigned npix, int ppb) {
     __shared__ float red[256 * 8];
     const int tid = threadIdx.x;
     const int nvec = C >> 3, planes = 256 / nvec;
     const int vec = tid % nvec, pl = tid / nvec;
-    const int64_t p0 = blockIdx.x * pix_per_blk;
-    const int64_t p1 = min(p0 + pix_per_blk, npix);
-    float* out = part + (int64_t)blockIdx.x * ((int64_t)cout * C * 9 + cout);
-    for (int co = 0; co < cout; ++co) {
+    const int HW = H * W;
+    const unsigned g0 = blockIdx.x * (unsigned)ppb;
+    const unsigned g1 = min(g0 + (unsigned)ppb, npix);
+    float* out = part + (size_t)blockIdx.x * ((size_t)cs * C * 9 + (FLIP ? cs : 0));
+    for (int s = 0; s < cs; ++s) {
         float acc[9][8];
         float bsum = 0.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
-        for (int64_t pix = p0 + pl; pix < p1; pix += planes) {
-            const int ox = (int)(pix % W);
-            const int64_t t2 = pix / W;
-            const int oy = (int)(t2 % H);
-            const int64_t b = t2 / H;
-            const float d = dout[((b * cout + co) * H + oy) * (int64_t)W + ox];
-            bsum += d;
+        if (g0 + pl < g1) {
+            PixWalk pw(g0 + pl, HW);
+            for (unsigned g = g0 + pl; g < g1; g += planes) {
+                const int oy = div_small(pw.p, inv_w), ox = pw.p - oy * W;
+                float v[8];
+                load8(big + (size_t)g * C + vec * 8, v);
+                const float* sp = small + (size_t)(pw.b * cs + s) * HW;
+                if (FLIP) bsum += sp[pw.p];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = oy + ky - 1;
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int iy = FLIP ? oy + 1 - ky : oy + ky - 1;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = ox + kx - 1;
-                    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-                    float v[8];
-                    load8(a + (((b * H + iy) * W) + ix) * (int64_t)C + vec * 8, v);
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int ix = FLIP ? ox + 1 - kx : ox + kx - 1;
+                        const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                        const float sv = ok ? sp[iy * W + ix] : 0.f;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[ky * 3 + kx][i] = fmaf(d, v[i], acc[ky * 3 + kx][i]);
+                        for (int i = 0; i < 8; ++i) acc[ky * 3 + kx][i] = fmaf(sv, v[i], acc[ky * 3 + kx][i]);
+                    }
                 }
+                pw.advance(planes, HW);
             }
         }
 #pragma unroll
@@ -255,37 +153,101 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
             __syncthreads();
             if (tid < C) {
                 const int vv = tid >> 3, i = tid & 7;
-                float s = 0.f;
-                for (int p = 0; p < planes; ++p) s += red[(p * nvec + vv) * 8 + i];
-                out[((int64_t)co * C + tid) * 9 + t] = s;        // reference layout [cout][C][3][3]
+                float sum = 0.f;
+                for (int q = 0; q < planes; ++q) sum += red[(q * nvec + vv) * 8 + i];
+                out[FLIP ? ((size_t)s * C + tid) * 9 + t : ((size_t)tid * cs + s) * 9 + t] = sum;
             }
         }
-        // bias partial: only vec == 0 lanes hold distinct pixels' d
-        __syncthreads();
-        red[tid] = vec == 0 ? bsum : 0.f;
-        __syncthreads();
-        if (tid == 0) {
-            float s = 0.f;
-            for (int i = 0; i < 256; ++i) s += red[i];
-            out[(int64_t)cout * C * 9 + co] = s;
+        if (FLIP) {     // bias partial: only vec == 0 lanes hold distinct pixels' dout
+            __syncthreads();
+            red[tid] = vec == 0 ? bsum : 0.f;
+            __syncthreads();
+            if (tid == 0) {
+                float sum = 0.f;
+                for (int i = 0; i < 256; ++i) sum += red[i];
+                out[(size_t)cs * C * 9 + s] = sum;
+            }
         }
     }
 }
 
+// ---- head forward (C -> cs): out[b,s,p] = bias[s] + sum_{t,c} a[b,p + off(t),c] * w[s][c][t] ----------------------------
+// One workgroup = one band of image rows.  Pass 1 reads every activation vector of the band (+1 row above/below) once and
+// leaves its 9 per-tap channel sums in LDS (tap[t][q] = sum_c a[q,c] w[s][c][t], reduced over the pixel's lanes with DPP);
+// pass 2 adds the 9 shifted planes per output pixel.  (A gather would read each activation 9 times through L1.)
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int cs,
+                                                      int H, int W, int C, float inv_w, int band, int nbands) {
+    extern __shared__ __attribute__((aligned(16))) float tapl[];   // [9][(band+2)*W]
+    const int tid = threadIdx.x;
+    const int nvec = C >> 3, planes = 256 / nvec;
+    const int vec = tid % nvec, pl = tid / nvec;
+    const int b = blockIdx.x / nbands, r0 = (blockIdx.x % nbands) * band;
+    const int rows = min(band, H - r0);
+    const int e0 = max(r0 - 1, 0), e1 = min(r0 + rows + 1, H);       // rows whose activations feed this band
+    const int next = (e1 - e0) * W, plane = (band + 2) * W;
+    const T* ab = a + ((size_t)b * H + e0) * W * C + vec * 8;
+    for (int s = 0; s < cs; ++s) {
+        float wr[9][8];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wr[t][i] = w[((size_t)s * C + vec * 8 + i) * 9 + t];
+        if (s) __syncthreads();
+        for (int q0 = 0; q0 < next; q0 += planes) {      // every lane of a wave runs the same trip count (DPP below)
+            const int q = q0 + pl;
+            float v[8];
+            if (q < next) load8(ab + (size_t)q * C, v);
+            else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = 0.f;
+            }
+            float mine = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) d = fmaf(v[i], wr[t][i], d);
+                d = row16_sum(d);
+                if (nvec == 32) d += __shfl_xor(d, 16, 64);
+                if (vec == t) mine = d;
+            }
+            if (vec < 9 && q < next) tapl[vec * plane + q] = mine;
+        }
+        __syncthreads();
+        const float bv = bias[s];
+        for (int o = tid; o < rows * W; o += 256) {
+            const int oyl = div_small(o, inv_w), ox = o - oyl * W;
+            const int oy = r0 + oyl;
+            float sum = bv;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy + ky - 1;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox + kx - 1;
+                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                        sum += tapl[(ky * 3 + kx) * plane + (iy - e0) * W + ix];
+                }
+            }
+            out[((size_t)(b * cs + s) * H + oy) * W + ox] = sum;
+        }
+    }
+}
+
+int small_ppb(int64_t npix) {          // pixels per workgroup of the streaming kernels
+    return npix > 4096 * 256 ? 1024 : 512;
+}
+
 int small_blocks(int64_t npix) {
-    int64_t nb = (npix + 1023) / 1024;
-    if (nb < 1) nb = 1;
-    if (nb > 1024) nb = 1024;
-    return (int)nb;
+    const int ppb = small_ppb(npix);
+    return (int)((npix + ppb - 1) / ppb);
 }
 
 bool small_shape_ok(int B, int cs, int H, int W, int C) {
-    return B > 0 && cs >= 1 && cs <= kMaxSmall && H > 0 && W > 0 && (C == 128 || C == 256);
-}
-
-int grid_for(int64_t total) {
-    int64_t g = (total + 255) / 256;
-    return (int)(g < 8192 ? g : 8192);
+    return B > 0 && cs >= 1 && cs <= kMaxSmall && H > 0 && W > 0 && (C == 128 || C == 256) && (int64_t)B * H * W < (1ll << 24) &&
+           H * W >= 32;
 }
 
 }  // namespace
@@ -293,81 +255,84 @@ int grid_for(int64_t total) {
 extern "C" int gmk_stem_wgrad_blocks(int64_t n_pixels) { return small_blocks(n_pixels); }
 extern "C" int gmk_head_wgrad_blocks(int64_t n_pixels) { return small_blocks(n_pixels); }
 
+template <typename T, bool FLIP>
+static void launch_expand(const float* in, const float* w, const float* bias, T* out, int B, int cs, int H, int W, int C,
+                          hipStream_t stream) {
+    const int64_t npix = (int64_t)B * H * W;
+    const int ppb = small_ppb(npix), nb = small_blocks(npix);
+    const float inv_w = 1.0f / (float)W;
+    if (cs == 1)
+        expand3x3_kernel<T, true, FLIP><<<nb, 256, 0, stream>>>(in, w, bias, out, cs, H, W, C, inv_w, (unsigned)npix, ppb);
+    else
+        expand3x3_kernel<T, false, FLIP><<<nb, 256, (size_t)cs * 9 * C * 4, stream>>>(in, w, bias, out, cs, H, W, C, inv_w,
+                                                                                      (unsigned)npix, ppb);
+}
+
 extern "C" int gmk_stem_fwd(const float* x, const float* w, const float* bias, void* y, int B, int cin, int H, int W, int C,
                             int dtype, void* stream) {
     GMK_REQUIRE(x && w && bias && y, "gmk_stem_fwd: null pointer");
     GMK_REQUIRE(small_shape_ok(B, cin, H, W, C), "gmk_stem_fwd: unsupported shape B=%d cin=%d %dx%d C=%d", B, cin, H, W, C);
-    const int64_t total = (int64_t)B * H * W * (C >> 3);
-    const size_t lds = (size_t)(cin * 9 * C + C) * 4;
-    if (dtype == GMK_BF16)
-        stem_fwd_kernel<bf16_t><<<grid_for(total), 256, lds, gmk_stream(stream)>>>(x, w, bias, (bf16_t*)y, B, cin, H, W, C);
-    else if (dtype == GMK_F32)
-        stem_fwd_kernel<float><<<grid_for(total), 256, lds, gmk_stream(stream)>>>(x, w, bias, (float*)y, B, cin, H, W, C);
-    else
-        GMK_REQUIRE(false, "gmk_stem_fwd: bad dtype %d", dtype);
+    if (dtype == GMK_BF16) launch_expand<bf16_t, false>(x, w, bias, (bf16_t*)y, B, cin, H, W, C, gmk_stream(stream));
+    else if (dtype == GMK_F32) launch_expand<float, false>(x, w, bias, (float*)y, B, cin, H, W, C, gmk_stream(stream));
+    else GMK_REQUIRE(false, "gmk_stem_fwd: bad dtype %d", dtype);
     return gmk_check_launch("gmk_stem_fwd");
-}
-
-extern "C" int gmk_stem_wgrad(const float* x, const void* dy, float* dw_part, int B, int cin, int H, int W, int C, int dtype,
-                              void* stream) {
-    GMK_REQUIRE(x && dy && dw_part, "gmk_stem_wgrad: null pointer");
-    GMK_REQUIRE(small_shape_ok(B, cin, H, W, C), "gmk_stem_wgrad: unsupported shape");
-    const int64_t npix = (int64_t)B * H * W;
-    const int nb = small_blocks(npix);
-    const int64_t ppb = (npix + nb - 1) / nb;
-    if (dtype == GMK_BF16)
-        stem_wgrad_kernel<bf16_t><<<nb, 256, 0, gmk_stream(stream)>>>(x, (const bf16_t*)dy, dw_part, npix, cin, H, W, C, ppb);
-    else if (dtype == GMK_F32)
-        stem_wgrad_kernel<float><<<nb, 256, 0, gmk_stream(stream)>>>(x, (const float*)dy, dw_part, npix, cin, H, W, C, ppb);
-    else
-        GMK_REQUIRE(false, "gmk_stem_wgrad: bad dtype %d", dtype);
-    return gmk_check_launch("gmk_stem_wgrad");
-}
-
-extern "C" int gmk_head_fwd(const void* a, const float* w, const float* bias, float* out, int B, int cout, int H, int W,
-                            int C, int dtype, void* stream) {
-    GMK_REQUIRE(a && w && bias && out, "gmk_head_fwd: null pointer");
-    GMK_REQUIRE(small_shape_ok(B, cout, H, W, C), "gmk_head_fwd: unsupported shape");
-    const int64_t total = (int64_t)B * H * W * (C >> 3);
-    const size_t lds = (size_t)cout * 9 * C * 4;
-    if (dtype == GMK_BF16)
-        head_fwd_kernel<bf16_t><<<grid_for(total), 256, lds, gmk_stream(stream)>>>((const bf16_t*)a, w, bias, out, B, cout, H,
-                                                                                    W, C);
-    else if (dtype == GMK_F32)
-        head_fwd_kernel<float><<<grid_for(total), 256, lds, gmk_stream(stream)>>>((const float*)a, w, bias, out, B, cout, H, W,
-                                                                                  C);
-    else
-        GMK_REQUIRE(false, "gmk_head_fwd: bad dtype %d", dtype);
-    return gmk_check_launch("gmk_head_fwd");
 }
 
 extern "C" int gmk_head_dgrad(const float* dout, const float* w, void* da, int B, int cout, int H, int W, int C, int dtype,
                               void* stream) {
     GMK_REQUIRE(dout && w && da, "gmk_head_dgrad: null pointer");
     GMK_REQUIRE(small_shape_ok(B, cout, H, W, C), "gmk_head_dgrad: unsupported shape");
-    const int64_t total = (int64_t)B * H * W * (C >> 3);
-    const size_t lds = (size_t)cout * 9 * C * 4;
-    if (dtype == GMK_BF16)
-        head_dgrad_kernel<bf16_t><<<grid_for(total), 256, lds, gmk_stream(stream)>>>(dout, w, (bf16_t*)da, B, cout, H, W, C);
-    else if (dtype == GMK_F32)
-        head_dgrad_kernel<float><<<grid_for(total), 256, lds, gmk_stream(stream)>>>(dout, w, (float*)da, B, cout, H, W, C);
-    else
-        GMK_REQUIRE(false, "gmk_head_dgrad: bad dtype %d", dtype);
+    if (dtype == GMK_BF16) launch_expand<bf16_t, true>(dout, w, nullptr, (bf16_t*)da, B, cout, H, W, C, gmk_stream(stream));
+    else if (dtype == GMK_F32) launch_expand<float, true>(dout, w, nullptr, (float*)da, B, cout, H, W, C, gmk_stream(stream));
+    else GMK_REQUIRE(false, "gmk_head_dgrad: bad dtype %d", dtype);
     return gmk_check_launch("gmk_head_dgrad");
+}
+
+template <typename T, bool FLIP>
+static void launch_wgrad(const float* small, const T* big, float* part, int B, int cs, int H, int W, int C, hipStream_t stream) {
+    const int64_t npix = (int64_t)B * H * W;
+    wgrad3x3_kernel<T, FLIP><<<small_blocks(npix), 256, 0, stream>>>(small, big, part, cs, H, W, C, 1.0f / (float)W,
+                                                                     (unsigned)npix, small_ppb(npix));
+}
+
+extern "C" int gmk_stem_wgrad(const float* x, const void* dy, float* dw_part, int B, int cin, int H, int W, int C, int dtype,
+                              void* stream) {
+    GMK_REQUIRE(x && dy && dw_part, "gmk_stem_wgrad: null pointer");
+    GMK_REQUIRE(small_shape_ok(B, cin, H, W, C), "gmk_stem_wgrad: unsupported shape");
+    if (dtype == GMK_BF16) launch_wgrad<bf16_t, false>(x, (const bf16_t*)dy, dw_part, B, cin, H, W, C, gmk_stream(stream));
+    else if (dtype == GMK_F32) launch_wgrad<float, false>(x, (const float*)dy, dw_part, B, cin, H, W, C, gmk_stream(stream));
+    else GMK_REQUIRE(false, "gmk_stem_wgrad: bad dtype %d", dtype);
+    return gmk_check_launch("gmk_stem_wgrad");
 }
 
 extern "C" int gmk_head_wgrad(const float* dout, const void* a, float* dw_part, int B, int cout, int H, int W, int C,
                               int dtype, void* stream) {
     GMK_REQUIRE(dout && a && dw_part, "gmk_head_wgrad: null pointer");
     GMK_REQUIRE(small_shape_ok(B, cout, H, W, C), "gmk_head_wgrad: unsupported shape");
-    const int64_t npix = (int64_t)B * H * W;
-    const int nb = small_blocks(npix);
-    const int64_t ppb = (npix + nb - 1) / nb;
-    if (dtype == GMK_BF16)
-        head_wgrad_kernel<bf16_t><<<nb, 256, 0, gmk_stream(stream)>>>(dout, (const bf16_t*)a, dw_part, npix, cout, H, W, C, ppb);
-    else if (dtype == GMK_F32)
-        head_wgrad_kernel<float><<<nb, 256, 0, gmk_stream(stream)>>>(dout, (const float*)a, dw_part, npix, cout, H, W, C, ppb);
-    else
-        GMK_REQUIRE(false, "gmk_head_wgrad: bad dtype %d", dtype);
+    if (dtype == GMK_BF16) launch_wgrad<bf16_t, true>(dout, (const bf16_t*)a, dw_part, B, cout, H, W, C, gmk_stream(stream));
+    else if (dtype == GMK_F32) launch_wgrad<float, true>(dout, (const float*)a, dw_part, B, cout, H, W, C, gmk_stream(stream));
+    else GMK_REQUIRE(false, "gmk_head_wgrad: bad dtype %d", dtype);
     return gmk_check_launch("gmk_head_wgrad");
+}
+
+extern "C" int gmk_head_fwd(const void* a, const float* w, const float* bias, float* out, int B, int cout, int H, int W,
+                            int C, int dtype, void* stream) {
+    GMK_REQUIRE(a && w && bias && out, "gmk_head_fwd: null pointer");
+    GMK_REQUIRE(small_shape_ok(B, cout, H, W, C), "gmk_head_fwd: unsupported shape");
+    // band of rows per workgroup: 9 fp32 planes of (band + 2) rows within 48 KiB of LDS, at least 4 workgroups per CU's worth of bands
+    int band = 49152 / (36 * W) - 2;
+    GMK_REQUIRE(band >= 1, "gmk_head_fwd: image too wide (W=%d)", W);
+    if (band > H) band = H;
+    const int nbands = (H + band - 1) / band;
+    const size_t lds = (size_t)9 * (band + 2) * W * 4;
+    const float inv_w = 1.0f / (float)W;
+    if (dtype == GMK_BF16)
+        head_fwd_kernel<bf16_t><<<B * nbands, 256, lds, gmk_stream(stream)>>>((const bf16_t*)a, w, bias, out, cout, H, W, C, inv_w,
+                                                                              band, nbands);
+    else if (dtype == GMK_F32)
+        head_fwd_kernel<float><<<B * nbands, 256, lds, gmk_stream(stream)>>>((const float*)a, w, bias, out, cout, H, W, C, inv_w,
+                                                                             band, nbands);
+    else
+        GMK_REQUIRE(false, "gmk_head_fwd: bad dtype %d", dtype);
+    return gmk_check_launch("gmk_head_fwd");
 }
