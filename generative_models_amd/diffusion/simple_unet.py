@@ -144,6 +144,7 @@ class SimpleUnet(nn.Module):
             self._pv[n] = p.data
             self._gv[n] = p.grad
         self._packs = None
+        self._side = None          # side stream of the weight gradients (backward_hip)
         self._packs_stale = True
         self._freqs = {}
 
@@ -295,6 +296,25 @@ class SimpleUnet(nn.Module):
             ctx[name] = (srcs, a, stats1, h, a2, (mean2, rstd2))
         return out
 
+    def _wgrad(self, dy, srcs, ksize, mode, dw):
+        """Weight gradient on the side stream (ops.WGRAD_STREAM): it depends only on dy and the saved activations, so it
+        runs beside the data-gradient chain and fills the CUs the persistent kernels' tails leave idle."""
+        if not ops.WGRAD_STREAM:
+            return ops.conv_wgrad(dy, srcs, ksize, mode, dw)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dy.device)
+        side = self._side
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.conv_wgrad(dy, srcs, ksize, mode, dw)
+        for t in (dy, *srcs):
+            t.record_stream(side)
+        return dw
+
+    def _join_side(self):
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
     def _res_bwd(self, name, ctx, dout, dout_sum, demb_all, blk, extra_add=None):
         """dout: gradient of the block output (NHWC); dout_sum: its per-sample channel sums [B, C].
         extra_add: per-source optional extra gradient tensors added into the returned source gradients.
@@ -305,7 +325,7 @@ class SimpleUnet(nn.Module):
         two = len(srcs) == 2
         # conv2 (out_layers.3)
         ops.colsum(dout_sum, G[f"{name}.out_layers.3.bias"], defer=True)
-        ops.conv_wgrad(dout, [a2], 3, ops.NORMAL, G[f"{name}.out_layers.3.weight"])
+        self._wgrad(dout, [a2], 3, ops.NORMAL, G[f"{name}.out_layers.3.weight"])
         _, wd2 = self._packs[f"{name}.out_layers.3"]
         da2 = ops.conv_igemm([dout], wd2, C, 3, ops.NORMAL, (H, W))
         dh, dgp, dbp = ops.gn_silu_bwd(da2, h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], mean2,
@@ -313,11 +333,11 @@ class SimpleUnet(nn.Module):
         ops.colsum(dgp, G[f"{name}.out_layers.0.weight"], defer=True); ops.colsum(dbp, G[f"{name}.out_layers.0.bias"], defer=True)
         # conv1 (in_layers.2): bias gradient = column sum of the embedding gradient slice (both are sum_hw dh)
         ops.colsum(demb_all[:, blk * C:(blk + 1) * C], G[f"{name}.in_layers.2.bias"], defer=True)
-        ops.conv_wgrad(dh, a, 3, ops.NORMAL, G[f"{name}.in_layers.2.weight"])
+        self._wgrad(dh, a, 3, ops.NORMAL, G[f"{name}.in_layers.2.weight"])
         _, wd1 = self._packs[f"{name}.in_layers.2"]
         if two:
             ops.colsum(dout_sum, G[f"{name}.skip_connection.bias"], defer=True)
-            ops.conv_wgrad(dout, srcs, 1, ops.NORMAL, G[f"{name}.skip_connection.weight"])
+            self._wgrad(dout, srcs, 1, ops.NORMAL, G[f"{name}.skip_connection.weight"])
             _, wds = self._packs[f"{name}.skip_connection"]
         outs = []
         gw, gb = G[f"{name}.in_layers.0.weight"], G[f"{name}.in_layers.0.bias"]
@@ -401,6 +421,8 @@ class SimpleUnet(nn.Module):
         """dout: NCHW fp32 gradient of the network output.  Fills `flat_grads` (overwrites every touched slice).
         on_grads_ready(k): called as soon as bucket k of grad_buckets() is final (overlapped gradient all-reduce)."""
         ready = on_grads_ready if on_grads_ready is not None else (lambda k: None)
+        # a bucket is final only when the side stream's weight gradients are: join before handing it to the all-reduce
+        join = self._join_side if on_grads_ready is not None else (lambda: None)
         P, G, C, T = self._pv, self._gv, self.channels, self.compute_dtype
         B, H, W = ctx["dims"]
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
@@ -422,11 +444,11 @@ class SimpleUnet(nn.Module):
         (du5, s5), (dt0a, _) = self._res_bwd("up.seq.6", ctx, du6, s6, demb_all, 11)
         (du4, s4), (dt1a, _) = self._res_bwd("up.seq.5", ctx, du5, s5, demb_all, 10)
         (du3, s3), (dt2a, _) = self._res_bwd("up.seq.4", ctx, du4, s4, demb_all, 9)
-        ops.flush_colsums()
+        ops.flush_colsums(); join()
         ready(0)
         # up.seq.3.1: nearest x2 + conv
         ops.colsum(s3, G["up.seq.3.1.conv.bias"], defer=True)
-        ops.conv_wgrad(du3, [u3r], 3, ops.UPSAMPLE2, G["up.seq.3.1.conv.weight"])
+        self._wgrad(du3, [u3r], 3, ops.UPSAMPLE2, G["up.seq.3.1.conv.weight"])
         dU = ops.conv_igemm([du3], self._packs["up.seq.3.1.conv"][1], C, 3, ops.NORMAL, (H, W))
         du3r = ops.sumpool2x2(dU)
         s3r = ops.chansum(du3r)
@@ -434,30 +456,30 @@ class SimpleUnet(nn.Module):
         (du1, s1), (dt4a, _) = self._res_bwd("up.seq.2", ctx, du2, s2, demb_all, 7)
         (du0, s0), (dt5a, _) = self._res_bwd("up.seq.1", ctx, du1, s1, demb_all, 6)
         ops.colsum(s0, G["up.seq.0.1.conv.bias"], defer=True)
-        ops.conv_wgrad(du0, [u0r], 3, ops.UPSAMPLE2, G["up.seq.0.1.conv.weight"])
+        self._wgrad(du0, [u0r], 3, ops.UPSAMPLE2, G["up.seq.0.1.conv.weight"])
         dU = ops.conv_igemm([du0], self._packs["up.seq.0.1.conv"][1], C, 3, ops.NORMAL, (H2, W2))
         du0r = ops.sumpool2x2(dU)
         s0r = ops.chansum(du0r)
         (dt7, s7), (dt6a, _) = self._res_bwd("up.seq.0.0", ctx, du0r, s0r, demb_all, 5)
-        ops.flush_colsums()
+        ops.flush_colsums(); join()
         ready(1)
         ((dt6, s6t),) = self._res_bwd("turn", ctx, dt7, s7, demb_all, 4, extra_add=[dt6a])
         # down.seq.6: stride-2 conv; its data gradient is the transposed gather
         ops.colsum(s6t, G["down.seq.6.conv.bias"], defer=True)
-        ops.conv_wgrad(dt6, [t5], 3, ops.STRIDE2, G["down.seq.6.conv.weight"])
+        self._wgrad(dt6, [t5], 3, ops.STRIDE2, G["down.seq.6.conv.weight"])
         dt5 = ops.conv_igemm([dt6], self._packs["down.seq.6.conv"][1], C, 3, ops.TRANSPOSED2, (H2, W2), residual=dt5a)
         s5t = ops.chansum(dt5)
         ((dt4, s4t),) = self._res_bwd("down.seq.5", ctx, dt5, s5t, demb_all, 3, extra_add=[dt4a])
         ((dt3, s3t),) = self._res_bwd("down.seq.4", ctx, dt4, s4t, demb_all, 2, extra_add=[dt3a])
         ops.colsum(s3t, G["down.seq.3.conv.bias"], defer=True)
-        ops.conv_wgrad(dt3, [t2], 3, ops.STRIDE2, G["down.seq.3.conv.weight"])
+        self._wgrad(dt3, [t2], 3, ops.STRIDE2, G["down.seq.3.conv.weight"])
         dt2 = ops.conv_igemm([dt3], self._packs["down.seq.3.conv"][1], C, 3, ops.TRANSPOSED2, (H, W), residual=dt2a)
         s2t = ops.chansum(dt2)
         ((dt1, s1t),) = self._res_bwd("down.seq.2", ctx, dt2, s2t, demb_all, 1, extra_add=[dt1a])
         ((dt0, s0t),) = self._res_bwd("down.seq.1", ctx, dt1, s1t, demb_all, 0, extra_add=[dt0a])
         ops.colsum(s0t, G["down.seq.0.conv.bias"], defer=True)
         ops.stem_wgrad(x, dt0, G["down.seq.0.conv.weight"])
-        ops.flush_colsums()
+        ops.flush_colsums(); self._join_side()
         ready(2)
         self._embed_bwd(ctx, demb_all)
         ops.flush_colsums()

@@ -93,6 +93,7 @@ def pack_conv_weight(w, w_fwd, w_dgrad):
 # measured on MI355X the DPP reductions in the conv epilogue cost as much as the statistics pass they save (27.25 vs
 # 27.19 ms/step), and with it a sample's result depends (in the last bits) on which tile neighbours it had.
 GN_STATS = False
+WGRAD_STREAM = True    # weight gradients on a side stream beside the data-gradient chain (simple_unet._wgrad)
 
 
 def gn_silu_fwd(x, gamma, beta, groups, eps=1e-5):

@@ -15,6 +15,7 @@ for rnd in range(4):
     for v in variants:
         lib.gmk_set_kernel_choice(*v[:3])
         ops.GN_STATS = (v[3] != 0) if len(v) > 3 else False
+        ops.WGRAD_STREAM = (v[4] != 0) if len(v) > 4 else True
         for _ in range(2):
             model.train_step(x, y.clone())
         torch.cuda.synchronize(); t0 = time.perf_counter()
