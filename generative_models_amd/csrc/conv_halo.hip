@@ -15,8 +15,11 @@
 // Slot s of a tile = ext-row * (W+2) + x + 1, ext rows = the tile's rows with a pad row above/below every image
 // segment; with E = ext-row + y0 (y0 = first row's position in its image) the layout is (H+2)-periodic:
 // image k = E / (H+2), y = E % (H+2) - 1.  Pad rows / columns and rows of non-existent images read a zero through the
-// buffer descriptor's range check.  Swizzle: physical chunk c of slot s holds logical chunk c ^ ((s>>1)&7) (applied
-// to the DMA source address and to the fragment reads), which keeps ds_read_b128 conflict-free for runs of pixels.
+// buffer descriptor's range check.  Swizzle: physical chunk c of slot s holds logical chunk c ^ ((n>>1)&7), n = s - 2*ext-row - 1
+// (the slot index with the two pad columns per row taken out; applied to the DMA source address and to the fragment reads).
+// For any tap the 16 pixels a ds_read_b128 lane group touches have CONSECUTIVE n even where they wrap to the next image
+// row (their slots jump by 3 there), so every group is conflict-free; keying the swizzle on s itself cost 29 % extra LDS
+// cycles at W = 28 (two 2-way conflicts in every group that contains a wrap).
 //
 // Schedule: K-step q = (phase, tap); each step every wave issues the 2 DMA instructions of weight tile q+2 and, for
 // taps 0..6, one 1-KiB piece (8 slots) of the next phase's halo.  The counts are static, so `s_waitcnt vmcnt(N)`
@@ -47,6 +50,8 @@ struct HaloParams {
     unsigned nb0, nb1, nbw, nbo;
     float* stats;                              // optional GroupNorm partial sums [ntiles][8][2][Cout/4][2] (see gmk.h)
     int stats_groups;                          // Cout/4
+    int variant;                               // GMK_DEV_VARIANT (experiments)
+    unsigned long long* stamps;                // diagnostic builds only (variant 99): s_memtime per tile, [wg][16 tiles][4]
     float inv_hp2, inv_h, inv_we, inv_w;       // reciprocals for exact small-integer division
 };
 
@@ -92,7 +97,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     const int fs0 = wave * 8 + lrow;
     const int f_er0 = div_small(fs0, p.inv_we), f_xe0 = fs0 - f_er0 * WE;
     const int f_der = div_small(64, p.inv_we), f_dxe = 64 - f_der * WE;
-    const unsigned f_ch = (unsigned)((lch ^ ((fs0 >> 1) & 7)) << 4);
+    unsigned f_swz = 0;      // (n>>1)&7 of this lane's slot in each of the 7 fill pieces, 3 bits per piece (tile independent)
+    {
+        int er = f_er0, xe = f_xe0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int n = p.variant == 1 ? er * WE + xe : er * WE + xe - 2 * er - 1;
+            f_swz |= (unsigned)((n >> 1) & 7) << (3 * j);
+            er += f_der; xe += f_dxe;
+            if (xe >= WE) { xe -= WE; ++er; }
+        }
+    }
     // weight tile rows: 16*wave + 8*i + lrow
     unsigned w_off[2];
 #pragma unroll
@@ -110,6 +125,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     }
     unsigned hpix[7];       // source pixel of this lane's slot in each fill piece (tile whose fills are being issued)
     int cslot[2];           // centre slot of this lane's two MFMA pixel rows (tile being computed)
+    int cn[2];              // ... and its pad-free index n = slot - 2*ext-row - 1 (the swizzle key)
 
     auto resolve_fill = [&](int tile) {
         const bool exists = tile < p.ntiles;
@@ -141,8 +157,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
             const int y = t - k * H;
             const int er = k * (H + 2) + y + 1 - y0;
             int s = er * WE + px_x[i] + 1;
-            if (s < WE + 1 || s >= kHaloSlots - WE - 1) s = WE + 1;     // dead rows (m_local >= TP): any in-range slot
+            int n = p.variant == 1 ? s : s - 2 * er - 1;
+            if (s < WE + 1 || s >= kHaloSlots - WE - 1) { s = WE + 1; n = WE - 2; }   // dead rows (m_local >= TP): any in-range slot
             cslot[i] = s;
+            cn[i] = n;
         }
     };
 
@@ -153,6 +171,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
         const unsigned cs_b = (unsigned)(second ? p.c1 : p.c0) * ES;
         const unsigned koff_b = (unsigned)(second ? kelem - p.c0 : kelem) * ES;
         GMK_LDS char* dst = (GMK_LDS char*)(smem + hbuf * kHB + j * 8192 + wave * 1024);
+        const unsigned f_ch = (unsigned)((lch ^ ((f_swz >> (3 * j)) & 7)) << 4);
         const unsigned voff = __umul24(hpix[j], cs_b) + koff_b + f_ch;
         if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (GMK_LDS void*)dst, 16, voff, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (GMK_LDS void*)dst, 16, voff, 0, 0, 0);
@@ -170,17 +189,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     const int swz = (r >> 1) & 7;
     const int b_off = kWOFF + (wn * 64 + r) * 128;
 
-    auto compute = [&](int hbuf, int st, int tapoff) {
+    auto compute = [&](int hbuf, int st, int tapoff, int tapoff_n) {
         const char* Hb = smem + hbuf * kHB;
         const char* Wb = smem + st * kWST + b_off;
         int rowb[2], sw[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int c = cslot[i];
-            asm volatile("" : "+v"(c));      // keep the per-tap addresses out of loop-invariant hoisting (72 VGPRs)
-            const int s = c + tapoff;
-            rowb[i] = s << 7;
-            sw[i] = (s >> 1) & 7;
+            int c = cslot[i], n = cn[i];
+            asm volatile("" : "+v"(c), "+v"(n));      // keep the per-tap addresses out of loop-invariant hoisting (72 VGPRs)
+            rowb[i] = (c + tapoff) << 7;
+            sw[i] = ((n + tapoff_n) >> 1) & 7;
         }
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
@@ -338,7 +356,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     issue_w(0, 0, 0);
     issue_w(1, 1, 0);
 
+    int tile_it = 0;
+    auto stamp = [&](int k) {
+        if (p.stamps && tid == 0 && tile_it < 16)
+            p.stamps[((size_t)blockIdx.x * 16 + tile_it) * 4 + k] = __builtin_amdgcn_s_memtime();
+    };
     for (; tile < p.ntiles; tile += gridDim.x) {
+        stamp(0);
         resolve_centres(tile);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -381,18 +405,407 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                 if (tap < 7) issue_fill(hbuf ^ 1, ph_next, tap);
                 if (tap == 6 && last_ph && p.residual) prefetch_residual(tile);
                 // ---- compute
-                compute(hbuf, st, (tap / 3 - 1) * WE + (tap % 3 - 1));
+                compute(hbuf, st, (tap / 3 - 1) * WE + (tap % 3 - 1), (tap / 3 - 1) * (p.variant == 1 ? WE : W) + (tap % 3 - 1));
                 st = st == 2 ? 0 : st + 1;
                 sq = sq == 2 ? 0 : sq + 1;
             }
             hbuf ^= 1;
+            if (ph == 0) stamp(1);
         }
         asm volatile("" ::: "memory");
+        stamp(2);
         epilogue(tile);
         asm volatile("" ::: "memory");
+        stamp(3);
+        ++tile_it;
         fresh = 2;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the speculative DMA before the LDS is released
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant of the same convolution (same LDS map, same schedule): waves 4..7 only move data (every
+// LDS-DMA instruction of a K-step: 4 weight pieces + 2 halo pieces each), waves 0..3 only compute, each owning a
+// 128-pixel x 64-channel quarter of the tile (8 accumulators).  Why: in the kernel above every wave pays the issue cost
+// of 3 LDS-DMA instructions (60-185 cycles each), 16 ds_read_b128 and ~25 address VALU per K-step next to its 16 MFMAs,
+// and with two such waves per SIMD the issue port, not the MFMA pipe, sets the K-step (1430-1570 cycles against 1024 of
+// MFMA time: tools/halo_stamps.py).  Here a SIMD hosts one consumer (32 MFMAs + 24 ds_read_b128 per K-step: 0.75 reads
+// per MFMA instead of 1) and one producer, w and w+4 share a SIMD, and the consumer's epilogue stores no longer sit in the
+// same vmcnt queue as the DMA (no `fresh` bookkeeping).  One s_barrier per K-step, crossed by all 8 waves.
+__global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParams p) {
+    constexpr int ES = 2;
+    __shared__ __attribute__((aligned(16))) char smem[kWOFF + 3 * kWST];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nblk = blockIdx.y * 128;
+    const int H = p.H, W = p.W, WE = p.WE;
+    const int nph = p.ktot >> 6;                 // 64-channel phases per tile
+    constexpr unsigned kBadPix = 0x00FFFFFFu;
+    constexpr unsigned kBadOff = 0xFFFFFF00u;
+    if ((int)blockIdx.x >= p.ntiles) return;
+
+    if (wave >= 4) {
+        // =========================================== producer waves ===========================================
+        // Per K-step each of the 4 producers issues 4 weight pieces (tile q+2) and, behind taps 0..6, 2 halo pieces of the next
+        // phase — weights FIRST: vmcnt retires in issue order, and the step only needs the weight tile issued two steps ago, so
+        // with the halo pieces queued behind the weights of their step they may stay in flight one step longer (HBM latency)
+        // without holding up the barrier.
+        const int pw = wave - 4;
+        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, (int)p.nb0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs1 =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.c1 ? p.src1 : p.src0), 0, (int)(p.c1 ? p.nb1 : p.nb0), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.nbw, 0x00020000);
+        const int lrow = lane >> 3, lch = lane & 7;
+        // halo fill: piece j = slots [64j, 64j+64); this wave's two instructions cover slots 64j + (2pw+u)*8 + lrow
+        const int f_der = div_small(64, p.inv_we), f_dxe = 64 - f_der * WE;
+        int f_er0[2], f_xe0[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int fs0 = (pw * 2 + u) * 8 + lrow;
+            f_er0[u] = div_small(fs0, p.inv_we);
+            f_xe0[u] = fs0 - f_er0[u] * WE;
+        }
+        // weight tile rows: 32*pw + 8*u + lrow
+        unsigned w_off[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = 32 * pw + 8 * u + lrow;
+            w_off[u] = (unsigned)(p.n0 + nblk + row) * (unsigned)p.ktot * ES + (unsigned)((lch ^ ((row >> 1) & 7)) << 4);
+        }
+        // source pixel (24 bits) and swizzled chunk offset (bits 24..31, = f_ch >> 4) of this lane's slot in piece j of the
+        // tile being filled; resolved one piece at a time, right before the piece is first needed
+        unsigned hpix[7][2];
+        auto resolve_piece = [&](int tile, int j) {
+            const bool exists = tile < p.ntiles;
+            const int gr0 = tile * p.R;
+            const int b0 = gr0 / H;
+            const int y0 = gr0 - b0 * H;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                // slot = 64j + fs0: advance (er, xe) of fs0 by j * 64 slots
+                int xe = f_xe0[u] + j * f_dxe, er = f_er0[u] + j * f_der;
+                const int wraps = div_small(xe, p.inv_we);
+                xe -= wraps * WE; er += wraps;
+                const int n = er * WE + xe - 2 * er - 1;
+                const int E = er + y0;
+                const int k = div_small(E, p.inv_hp2);
+                const int y = E - k * (H + 2) - 1;
+                const int x = xe - 1;
+                const int b = b0 + k;
+                const bool ok = exists && y >= 0 && y < H && x >= 0 && x < W && b < p.B;
+                const unsigned pix = ok ? (unsigned)((b * (H >> p.shift) + (y >> p.shift)) * (W >> p.shift) + (x >> p.shift)) : kBadPix;
+                hpix[j][u] = pix | ((unsigned)(lch ^ ((n >> 1) & 7)) << 24);
+            }
+        };
+        auto issue_fill = [&](int hbuf, int ph, int j) {
+            const int kelem = ph << 6;
+            const bool second = kelem >= p.c0;
+            const unsigned cs_b = (unsigned)(second ? p.c1 : p.c0) * ES;
+            const unsigned koff_b = (unsigned)(second ? kelem - p.c0 : kelem) * ES;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                GMK_LDS char* dst = (GMK_LDS char*)(smem + hbuf * kHB + j * 8192 + (pw * 2 + u) * 1024);
+                const unsigned voff = __umul24(hpix[j][u], cs_b) + koff_b + ((hpix[j][u] >> 24) << 4);
+                if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (GMK_LDS void*)dst, 16, voff, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (GMK_LDS void*)dst, 16, voff, 0, 0, 0);
+            }
+        };
+        auto issue_w = [&](int stage, int tap, int ph) {
+            GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + pw * 4096);
+            const unsigned wk = (unsigned)tap * p.w_tap_stride_b + ((unsigned)ph << 7);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(dst + u * 1024), 16, w_off[u] + wk, 0, 0, 0);
+        };
+
+        int sq = 2, hbuf = 0;
+        int tile = blockIdx.x;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { resolve_piece(tile, j); issue_fill(0, 0, j); }
+        issue_w(0, 0, 0);
+        issue_w(1, 1, 0);
+        for (; tile < p.ntiles; tile += gridDim.x) {
+            for (int ph = 0; ph < nph; ++ph) {
+                const bool last_ph = ph + 1 == nph;
+                const int ph_next = last_ph ? 0 : ph + 1;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    // W(q) = the first 4 ops of step q-2 must have landed; the 2 halo pieces behind them and everything of step
+                    // q-1 may still fly.  Tap 0 additionally needs the phase's whole halo: all of it is older than tap 7's weights.
+                    if (p.variant >= 20 && p.variant <= 22) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (tap == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (tap == 1 || tap == 8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    const bool no_w = p.variant == 20 || p.variant == 22, no_f = p.variant == 21 || p.variant == 22;   // timing ablations
+                    if (!no_w) {
+                        if (tap < 7) issue_w(sq, tap + 2, ph);
+                        else issue_w(sq, tap - 7, ph_next);
+                    }
+                    if (tap < 7 && !no_f) {
+                        if (last_ph) resolve_piece(tile + gridDim.x, tap);      // the next fills belong to the next tile (or are zeros)
+                        issue_fill(hbuf ^ 1, ph_next, tap);
+                    }
+                    sq = sq == 2 ? 0 : sq + 1;
+                }
+                hbuf ^= 1;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the speculative DMA before the LDS is released
+        return;
+    }
+
+    // =============================================== consumer waves ===============================================
+    const int cm = wave >> 1, cw = wave & 1;          // pixel half (128) / channel half (64) of the tile
+    const int r = lane & 31, h = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.nbo, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
+    int rit[4], px_x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ml = cm * 128 + i * 32 + r;
+        rit[i] = div_small(ml, p.inv_w);
+        px_x[i] = ml - rit[i] * W;
+    }
+    int cslot[4], cn[4];
+    auto resolve_centres = [&](int tile) {
+        const int gr0 = tile * p.R;
+        const int b0 = gr0 / H;
+        const int y0 = gr0 - b0 * H;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = y0 + rit[i];
+            const int k = div_small(t, p.inv_h);
+            const int y = t - k * H;
+            const int er = k * (H + 2) + y + 1 - y0;
+            int s = er * WE + px_x[i] + 1;
+            int n = s - 2 * er - 1;
+            if (s < WE + 1 || s >= kHaloSlots - WE - 1) { s = WE + 1; n = WE - 2; }   // dead rows (m_local >= TP): any in-range slot
+            cslot[i] = s;
+            cn[i] = n;
+        }
+    };
+
+    f32x16 acc[2][4];     // [j: channel tile][i: pixel tile]
+    const int swz = (r >> 1) & 7;
+    const int b_off = kWOFF + (cw * 64 + r) * 128;
+
+    // Software pipeline of one K-step (tap): the pixel-fragment reads of group 0 and all address arithmetic of tap t+1 are
+    // issued before the last MFMA group of tap t (the halo does not change inside a phase), so after the barrier only the two
+    // weight-fragment reads of group 0 stand between the wave and its first MFMA.  Two fragment sets alternate per group.
+    bf16x8 px[2][4], wt[2][2];
+    int rowb[4], sw[4];
+#ifndef GMK_ABLATE
+#define GMK_ABLATE 0
+#endif
+    constexpr bool no_rd = GMK_ABLATE == 23, no_mm = GMK_ABLATE == 24;      // timing-only diagnostic builds (-DGMK_ABLATE=..)
+    auto pre = [&](int hbuf, int tap) {             // addresses of `tap` + its group-0 pixel fragments -> set 0
+        if (no_rd) return;
+        const char* Hb = smem + hbuf * kHB;
+        const int tapoff = (tap / 3 - 1) * WE + (tap % 3 - 1), tapoff_n = (tap / 3 - 1) * W + (tap % 3 - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int c = cslot[i], n = cn[i];
+            asm volatile("" : "+v"(c), "+v"(n));      // keep the per-tap addresses out of loop-invariant hoisting
+            rowb[i] = (c + tapoff) << 7;
+            sw[i] = ((n + tapoff_n) >> 1) & 7;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            px[0][i] = *reinterpret_cast<const bf16x8*>(Hb + rowb[i] + ((h ^ sw[i]) << 4));
+    };
+    auto load_px = [&](int hbuf, int kg, int set) {
+        if (no_rd) return;
+        const char* Hb = smem + hbuf * kHB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            px[set][i] = *reinterpret_cast<const bf16x8*>(Hb + rowb[i] + (((kg * 2 + h) ^ sw[i]) << 4));
+    };
+    auto load_wt = [&](int st, int kg, int set) {
+        if (no_rd) return;
+        const char* Wb = smem + st * kWST + b_off;
+        const int coff = ((kg * 2 + h) ^ swz) << 4;
+        wt[set][0] = *reinterpret_cast<const bf16x8*>(Wb + coff);
+        wt[set][1] = *reinterpret_cast<const bf16x8*>(Wb + 4096 + coff);
+    };
+    auto interleave_reads = [&]() {       // order of the enclosing scheduling region: (MFMA, 2 VALU, read) x 4, (MFMA, read) x 2, MFMA x 2
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    };
+    auto interleave_pre = [&]() {         // (MFMA, 5 VALU) x 4, (MFMA, 2 VALU, read) x 4
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    };
+    auto mfma_group = [&](int set) {
+        if (no_mm) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(px[set][i]), "v"(wt[set][i & 1]));
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[set][j], px[set][i], acc[j][i], 0, 0, 0);
+    };
+
+    auto epilogue = [&](int tile) {
+        u32x2_t resv[4][2][4];
+        if (p.residual) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ml = cm * 128 + i * 32 + r;
+                const int m = tile * p.TP + ml;
+                const bool live = ml < p.TP && m < p.M;
+                const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int cb = nblk + cw * 64 + j * 32;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const unsigned off = live ? row_b + (unsigned)(cb + 8 * q4 + 4 * h) * ES : kBadOff;
+                        resv[i][j][q4] = __builtin_amdgcn_raw_buffer_load_b64(rsr, off, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ml = cm * 128 + i * 32 + r;
+            const int m = tile * p.TP + ml;
+            const bool live = ml < p.TP && m < p.M;
+            const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
+            const float* embp = nullptr;
+            if (p.emb) embp = p.emb + (int64_t)((live ? m : 0) / (H * W)) * p.emb_stride;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cb = nblk + cw * 64 + j * 32;
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { v[e] = acc[j][i][e]; acc[j][i][e] = 0.f; }
+                if (p.bias) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        float t[4];
+                        load4(p.bias + cb + 8 * q4 + 4 * h, t);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * q4 + e] += t[e];
+                    }
+                }
+                if (p.emb) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        float t[4];
+                        load4(embp + cb + 8 * q4 + 4 * h, t);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * q4 + e] += t[e];
+                    }
+                }
+                if (p.residual) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const bf16x4 rb = __builtin_bit_cast(bf16x4, resv[i][j][q4]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * q4 + e] += (float)rb[e];
+                    }
+                }
+                unsigned pk[4][2];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    bf16x4 t = {(bf16_t)v[4 * q4], (bf16_t)v[4 * q4 + 1], (bf16_t)v[4 * q4 + 2], (bf16_t)v[4 * q4 + 3]};
+                    const auto u = __builtin_bit_cast(u32x2_t, t);
+                    pk[q4][0] = u[0]; pk[q4][1] = u[1];
+                }
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4 += 2) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[q4][0], pk[q4 + 1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q4][1], pk[q4 + 1][1], false, false);
+                    u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                    const unsigned off = live ? row_b + (unsigned)(cb + 8 * (q4 + h)) * ES : kBadOff;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rso, off, 0, 0);
+                }
+            }
+        }
+    };
+
+    int st = 0, hbuf = 0;
+    int tile_it = 0;
+    auto stamp = [&](int k) {
+        if (p.stamps && tid == 0 && tile_it < 16)
+            p.stamps[((size_t)blockIdx.x * 16 + tile_it) * 4 + k] = __builtin_amdgcn_s_memtime();
+    };
+    resolve_centres(blockIdx.x);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        stamp(0);
+        for (int ph = 0; ph < nph; ++ph) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                __builtin_amdgcn_s_barrier();
+                if (tap == 0) pre(hbuf, 0);           // the phase's halo only became valid with this barrier
+                load_wt(st, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // each region = the 6 reads (+ address VALU) of group kg+1 and the 8 MFMAs of group kg, interleaved one read per
+                // MFMA so that read issue hides in the 24 free issue cycles of every MFMA; sched_barrier(0) keeps the stages apart
+                // (left alone the scheduler re-serialises read -> use, and reads issued in a block let the MFMA pipe drain)
+                load_px(hbuf, 1, 1); load_wt(st, 1, 1);
+                mfma_group(0);
+                interleave_reads();
+                __builtin_amdgcn_sched_barrier(0);
+                load_px(hbuf, 2, 0); load_wt(st, 2, 0);
+                mfma_group(1);
+                interleave_reads();
+                __builtin_amdgcn_sched_barrier(0);
+                load_px(hbuf, 3, 1); load_wt(st, 3, 1);
+                mfma_group(0);
+                interleave_reads();
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap < 8) pre(hbuf, tap + 1);      // next tap's addresses + group-0 pixels, under the last MFMA group
+                mfma_group(1);
+                if (tap < 8) interleave_pre();
+                __builtin_amdgcn_sched_barrier(0);
+                st = st == 2 ? 0 : st + 1;
+            }
+            hbuf ^= 1;
+            if (ph == 0) stamp(1);
+        }
+        asm volatile("" ::: "memory");
+        stamp(2);
+        // the epilogue is bound by store issue: it also re-zeroes the accumulators and resolves the next tile's pixel rows in
+        // that shadow, so the next tile starts on its first barrier
+        epilogue(tile);
+        resolve_centres(tile + gridDim.x);
+        asm volatile("" ::: "memory");
+        stamp(3);
+        ++tile_it;
+    }
 }
 
 }  // namespace
@@ -429,9 +842,14 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     p.M = (int)M;
     p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1; p.nbw = (unsigned)nbw; p.nbo = (unsigned)nbo;
     p.stats = nullptr; p.stats_groups = out_cstride / 4;
+    const int dev = gmk_kernel_choice(3, "GMK_DEV_VARIANT");    // low byte: code variant; 0x100: write per-tile s_memtime stamps
+    p.variant = dev & 0xFF;
+    p.stamps = nullptr;
+    if ((dev & 0x100) && stats && stats_bytes >= 256 * 16 * 4 * 8) { p.stamps = (unsigned long long*)stats; stats = nullptr; }
     if (stats && cout == out_cstride && stats_bytes >= ntiles * 8 * 2 * (int64_t)(out_cstride / 4) * 2 * 4 && H * W >= 32) p.stats = stats;
     p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 2); p.inv_w = 1.0f / (float)W;
     dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256), cout / 128);
-    conv3x3_halo_kernel<<<grid, 512, 0, stream>>>(p);
+    if (p.variant != 1 && p.variant != 3 && !p.stats) conv3x3_halo_ws_kernel<<<grid, 512, 0, stream>>>(p);     // 1, 3: the 8-compute-wave kernel
+    else conv3x3_halo_kernel<<<grid, 512, 0, stream>>>(p);
     return 1;
 }

@@ -32,11 +32,12 @@ void gmk_note_kernel(int id) { g_last_kernel = id; }
 extern "C" int gmk_last_kernel(void) { return g_last_kernel; }
 
 // kernel-selection overrides (development / A-B measurement): -1 = unset (environment variable, then automatic)
-static int g_choice[3] = {-1, -1, -1};
+static int g_choice[4] = {-1, -1, -1, -1};
 extern "C" int gmk_set_kernel_choice(int conv, int wgrad, int gn) {
     g_choice[0] = conv; g_choice[1] = wgrad; g_choice[2] = gn;
     return 0;
 }
+extern "C" int gmk_set_dev_variant(int v) { g_choice[3] = v; return 0; }
 int gmk_kernel_choice(int which, const char* env) {
     if (g_choice[which] >= 0) return g_choice[which];
     const char* v = getenv(env);

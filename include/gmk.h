@@ -37,6 +37,9 @@ const char* gmk_last_error(void);
 int gmk_last_kernel(void);
 /* development aid: force kernel variants (0 = automatic; see GMK_CONV_KERNEL / GMK_WGRAD_KERNEL / GMK_GN_KERNEL); -1 = unset */
 int gmk_set_kernel_choice(int conv, int wgrad, int gn);
+/* development aid: a free integer (GMK_DEV_VARIANT) that experimental code paths may read for in-process A/B runs
+ * (tools/step_ab.py); 0 / unset = the shipped behaviour */
+int gmk_set_dev_variant(int v);
 /* number of bytes of scratch gmk_conv_wgrad needs for the given problem (split-K slabs) */
 int64_t gmk_conv_wgrad_workspace_bytes(int64_t n_pixels, int taps, int cout, int ktot);
 

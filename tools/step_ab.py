@@ -16,6 +16,7 @@ for rnd in range(4):
         lib.gmk_set_kernel_choice(*v[:3])
         ops.GN_STATS = (v[3] != 0) if len(v) > 3 else False
         ops.WGRAD_STREAM = (v[4] != 0) if len(v) > 4 else True
+        lib.gmk_set_dev_variant(v[5] if len(v) > 5 else 0)
         for _ in range(2):
             model.train_step(x, y.clone())
         torch.cuda.synchronize(); t0 = time.perf_counter()
