@@ -433,6 +433,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
 // MFMA time: tools/halo_stamps.py).  Here a SIMD hosts one consumer (32 MFMAs + 24 ds_read_b128 per K-step: 0.75 reads
 // per MFMA instead of 1) and one producer, w and w+4 share a SIMD, and the consumer's epilogue stores no longer sit in the
 // same vmcnt queue as the DMA (no `fresh` bookkeeping).  One s_barrier per K-step, crossed by all 8 waves.
+template <bool kPrefetchW>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParams p) {
     constexpr int ES = 2;
     __shared__ __attribute__((aligned(16))) char smem[kWOFF + 3 * kWST];
@@ -526,18 +527,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         for (int j = 0; j < 7; ++j) { resolve_piece(tile, j); issue_fill(0, 0, j); }
         issue_w(0, 0, 0);
         issue_w(1, 1, 0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // start-up barrier: weight tile 0 is in LDS
         for (; tile < p.ntiles; tile += gridDim.x) {
             for (int ph = 0; ph < nph; ++ph) {
                 const bool last_ph = ph + 1 == nph;
                 const int ph_next = last_ph ? 0 : ph + 1;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    // W(q) = the first 4 ops of step q-2 must have landed; the 2 halo pieces behind them and everything of step
-                    // q-1 may still fly.  Tap 0 additionally needs the phase's whole halo: all of it is older than tap 7's weights.
-                    if (p.variant >= 20 && p.variant <= 22) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (tap == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else if (tap == 1 || tap == 8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    // at barrier q the weight tile of step q+1 (the first 4 ops of step q-1) must have landed — the consumers read its
+                    // first fragments before barrier q+1; only the 2 halo pieces issued behind it may still fly.  Tap 0 also needs
+                    // the phase's whole halo (all older).
+                    if (kPrefetchW) {
+                        if ((p.variant >= 20 && p.variant <= 22) || tap == 0 || tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    } else {      // only the weight tile of THIS step (issued two steps ago) has to be there
+                        if (p.variant >= 20 && p.variant <= 22) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        else if (tap == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else if (tap == 1 || tap == 8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    }
                     __builtin_amdgcn_s_barrier();
                     const bool no_w = p.variant == 20 || p.variant == 22, no_f = p.variant == 21 || p.variant == 22;   // timing ablations
                     if (!no_w) {
@@ -657,6 +666,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     };
     auto mfma_group = [&](int set) {
         if (no_mm) {
@@ -763,6 +773,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+    __builtin_amdgcn_s_barrier();                          // start-up barrier: weight tile 0 is in LDS
+    if (kPrefetchW) load_wt(0, 0, 0);
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         stamp(0);
         for (int ph = 0; ph < nph; ++ph) {
@@ -770,7 +782,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             for (int tap = 0; tap < 9; ++tap) {
                 __builtin_amdgcn_s_barrier();
                 if (tap == 0) pre(hbuf, 0);           // the phase's halo only became valid with this barrier
-                load_wt(st, 0, 0);
+                if (!kPrefetchW) load_wt(st, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // each region = the 6 reads (+ address VALU) of group kg+1 and the 8 MFMAs of group kg, interleaved one read per
                 // MFMA so that read issue hides in the 24 free issue cycles of every MFMA; sched_barrier(0) keeps the stages apart
@@ -787,11 +799,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 mfma_group(0);
                 interleave_reads();
                 __builtin_amdgcn_sched_barrier(0);
+                st = st == 2 ? 0 : st + 1;
                 if (tap < 8) pre(hbuf, tap + 1);      // next tap's addresses + group-0 pixels, under the last MFMA group
+                if (kPrefetchW) load_wt(st, 0, 0);    // ... and the next step's first weight fragments (tile landed at this step's barrier)
                 mfma_group(1);
                 if (tap < 8) interleave_pre();
                 __builtin_amdgcn_sched_barrier(0);
-                st = st == 2 ? 0 : st + 1;
             }
             hbuf ^= 1;
             if (ph == 0) stamp(1);
@@ -849,7 +862,8 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     if (stats && cout == out_cstride && stats_bytes >= ntiles * 8 * 2 * (int64_t)(out_cstride / 4) * 2 * 4 && H * W >= 32) p.stats = stats;
     p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 2); p.inv_w = 1.0f / (float)W;
     dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256), cout / 128);
-    if (p.variant != 1 && p.variant != 3 && !p.stats) conv3x3_halo_ws_kernel<<<grid, 512, 0, stream>>>(p);     // 1, 3: the 8-compute-wave kernel
+    if (p.variant == 4 && !p.stats) conv3x3_halo_ws_kernel<false><<<grid, 512, 0, stream>>>(p);
+    else if (p.variant != 1 && p.variant != 3 && !p.stats) conv3x3_halo_ws_kernel<true><<<grid, 512, 0, stream>>>(p);     // 1, 3: the 8-compute-wave kernel
     else conv3x3_halo_kernel<<<grid, 512, 0, stream>>>(p);
     return 1;
 }
