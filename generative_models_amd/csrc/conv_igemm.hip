@@ -823,7 +823,7 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
     const int force = gmk_kernel_choice(0, "GMK_CONV_KERNEL");
     if ((force == 0 || force == 3) && dtype == GMK_BF16 && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2) && ksize == 3) {
         const int rc = gmk_conv3x3_halo_try(src0, src1, c0, c1, B, ho, wo, w, w_rows, n0, cout, bias, emb, emb_stride, residual,
-                                            out, out_cstride, force == 3 ? 1 : 256, mode == GMK_CONV_UPSAMPLE2, gn_stats,
+                                            out, out_cstride, force == 3 ? 1 : 32, mode == GMK_CONV_UPSAMPLE2, gn_stats,
                                             gn_stats_bytes, gmk_stream(stream));
         if (rc == 1) {
             gmk_note_kernel(3);
