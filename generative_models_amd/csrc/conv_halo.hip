@@ -823,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 
 }  // namespace
 
-// Returns 1 if the halo kernel was launched, 0 if the problem is not eligible (caller falls back), <0 / >0 on error.
+// Returns 1 (8-compute-wave kernel) or 2 (wave-specialised kernel) if a halo kernel was launched, 0 if the problem is not eligible (caller falls back), <0 / >0 on error.
 int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int B, int H, int W, const void* w, int w_rows,
                          int n0, int cout, const float* bias, const float* emb, int emb_stride, const void* residual,
                          void* out, int out_cstride, int min_tiles, int upsample, float* stats, int64_t stats_bytes,
@@ -864,6 +864,9 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256), cout / 128);
     if (p.variant == 4 && !p.stats) conv3x3_halo_ws_kernel<false><<<grid, 512, 0, stream>>>(p);
     else if (p.variant != 1 && p.variant != 3 && !p.stats) conv3x3_halo_ws_kernel<true><<<grid, 512, 0, stream>>>(p);     // 1, 3: the 8-compute-wave kernel
-    else conv3x3_halo_kernel<<<grid, 512, 0, stream>>>(p);
-    return 1;
+    else {
+        conv3x3_halo_kernel<<<grid, 512, 0, stream>>>(p);
+        return 1;
+    }
+    return 2;
 }

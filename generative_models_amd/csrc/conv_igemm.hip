@@ -825,8 +825,8 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
         const int rc = gmk_conv3x3_halo_try(src0, src1, c0, c1, B, ho, wo, w, w_rows, n0, cout, bias, emb, emb_stride, residual,
                                             out, out_cstride, force == 3 ? 1 : 32, mode == GMK_CONV_UPSAMPLE2, gn_stats,
                                             gn_stats_bytes, gmk_stream(stream));
-        if (rc == 1) {
-            gmk_note_kernel(3);
+        if (rc == 1 || rc == 2) {
+            gmk_note_kernel(rc == 2 ? 4 : 3);
             return gmk_check_launch("gmk_conv_igemm(halo)");
         }
     }

@@ -5,6 +5,8 @@ take the whole node down) and enqueues on torch's current HIP stream.
 """
 import math
 
+import os
+
 import torch
 
 from ._lib import check, lib
@@ -18,7 +20,7 @@ NORMAL, STRIDE2, UPSAMPLE2, TRANSPOSED2 = 0, 1, 2, 3
 PROFILE = None
 
 
-KERNEL_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_dma_kernel", 3: "conv3x3_halo_kernel", 11: "conv_wgrad_kernel",
+KERNEL_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_dma_kernel", 3: "conv3x3_halo_kernel", 4: "conv3x3_halo_ws_kernel", 11: "conv_wgrad_kernel",
                 12: "conv_wgrad_slots_kernel"}
 
 
@@ -93,7 +95,7 @@ def pack_conv_weight(w, w_fwd, w_dgrad):
 # measured on MI355X the DPP reductions in the conv epilogue cost as much as the statistics pass they save (27.25 vs
 # 27.19 ms/step), and with it a sample's result depends (in the last bits) on which tile neighbours it had.
 GN_STATS = False
-WGRAD_STREAM = True    # weight gradients on a side stream beside the data-gradient chain (simple_unet._wgrad)
+WGRAD_STREAM = os.environ.get("GMK_WGRAD_STREAM", "1") != "0"    # weight gradients on a side stream beside the data-gradient chain (simple_unet._wgrad)
 
 
 def gn_silu_fwd(x, gamma, beta, groups, eps=1e-5):
@@ -229,7 +231,7 @@ def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, 
                                  _p(bias), _p(emb), emb_stride, _p(residual), _p(out), cout, _p(part),
                                  part.numel() * 4 if part is not None else 0, _DT[s0.dtype], _s()),
               "conv_igemm")
-    if part is not None and lib.gmk_last_kernel() == 3 and ho * wo >= 32:
+    if part is not None and lib.gmk_last_kernel() == 3 and ho * wo >= 32:      # only the 8-compute-wave halo kernel emits statistics
         out._gn_stats = (part, tp, nt)     # consumed by gn_silu_fwd(out, ...)
     return out
 

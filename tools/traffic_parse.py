@@ -1,0 +1,38 @@
+"""Collect the rocprofv3 --pmc passes of tools/traffic.sh into one JSON: per kernel, HBM bytes per launch
+(FETCH_SIZE x 2 on gfx950 for 16-B/lane streaming reads — guides/MI355X_MICROARCH.md, HBM — plus WRITE_SIZE; both counters
+are in KiB) and the MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 4 SIMDs x 256 CUs ... reported raw)."""
+import csv, glob, json, sys, collections, re
+out = sys.argv[1]
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+    if m:
+        n = int(m.group(1)); start = m.end()
+        name = name[start:start + n]
+    name = re.sub(r"^void ", "", name)
+    return name.split("(")[0].split("<")[0].strip()
+
+
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(f"{out}/g*/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for k, c in agg.items():
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        continue
+    n = len(c["FETCH_SIZE"])
+    fetch = sum(c["FETCH_SIZE"]) / n * 1024 * 2
+    write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) * 1024
+    e = {"launches": n, "fetch_bytes_per_launch_corrected": int(fetch), "write_bytes_per_launch": int(write),
+         "hbm_bytes_per_launch": int(fetch + write)}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c and sum(c["SQ_BUSY_CYCLES"]) > 0:
+        # MFMA busy cycles are summed over SIMDs, SQ_BUSY_CYCLES over SEs/XCDs: report the ratio normalised per SIMD
+        e["mfma_busy_cycles"] = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"])
+        e["gui_active"] = sum(c.get("GRBM_GUI_ACTIVE", [0])) / max(1, len(c.get("GRBM_GUI_ACTIVE", [0])))
+        if e["gui_active"] > 0:
+            e["mfma_busy_frac"] = round(e["mfma_busy_cycles"] / (e["gui_active"] / 8 * 1024), 3)   # 8 XCDs summed; 256 CUs x 4 SIMDs
+    res[k] = e
+print(json.dumps(res, indent=1))
