@@ -68,12 +68,19 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__
     }
 }
 
-// one block per sample: loss and (optionally) d loss / d v
+// the network output parametrises x (gaussian_diffusion.py:58-73): mean_type 0 'v' (predict_x_from_v), 1 'eps'
+// (predict_x_from_eps), 2 'x'; d x / d out is the second function
+__device__ __forceinline__ float x_from_out(float out, float zz, const LogsnrCoef& c, int mt) {
+    return mt == 0 ? c.alpha * zz - c.sigma * out : (mt == 1 ? c.d1 * (zz - out * c.d2) : out);
+}
+__device__ __forceinline__ float dx_dout(const LogsnrCoef& c, int mt) { return mt == 0 ? -c.sigma : (mt == 1 ? -c.d1 * c.d2 : 1.0f); }
+
+// one block per sample: loss and (optionally) d loss / d (network output)
 __global__ __launch_bounds__(256) void v_loss_kernel(const float* __restrict__ v, const float* __restrict__ z,
                                                     const float* __restrict__ x, const float* __restrict__ eps,
                                                     const float* __restrict__ logsnr, float* __restrict__ loss_b,
                                                     float* __restrict__ x_mse_o, float* __restrict__ eps_mse_o,
-                                                    float* __restrict__ dv, float grad_scale, int64_t n, int loss_type) {
+                                                    float* __restrict__ dv, float grad_scale, int64_t n, int loss_type, int mt) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     const LogsnrCoef c = logsnr_coef(logsnr[b]);
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256) void v_loss_kernel(const float* __restrict__ v
     float sx = 0.f, se = 0.f;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const float zz = z[base + i];
-        const float xh = clip1(c.alpha * zz - c.sigma * v[base + i]);     // :63, :73
+        const float xh = clip1(x_from_out(v[base + i], zz, c, mt));        // :58-63, :73
         const float eh = c.c1 * (zz - xh * c.c2);                          // :76
         const float dx = xh - x[base + i], de = eh - eps[base + i];
         sx = fmaf(dx, dx, sx);
@@ -103,11 +110,11 @@ __global__ __launch_bounds__(256) void v_loss_kernel(const float* __restrict__ v
     const float ke = grad_scale * ge * 2.f / (float)n * (-c.c1 * c.c2);
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const float zz = z[base + i];
-        const float raw = c.alpha * zz - c.sigma * v[base + i];
+        const float raw = x_from_out(v[base + i], zz, c, mt);
         const float xh = clip1(raw);
         const float eh = c.c1 * (zz - xh * c.c2);
         const float dxh = kx * (xh - x[base + i]) + ke * (eh - eps[base + i]);
-        dv[base + i] = (raw >= -1.0f && raw <= 1.0f) ? -c.sigma * dxh : 0.f;
+        dv[base + i] = (raw >= -1.0f && raw <= 1.0f) ? dx_dout(c, mt) * dxh : 0.f;
     }
 }
 
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const float* __restri
                                                           const float* __restrict__ noise, float lt, float ls, int is_last,
                                                           float* __restrict__ z_next, float* __restrict__ x_pred,
                                                           float* __restrict__ eps_pred, int64_t n,
-                                                          const float* __restrict__ lt_vec, const float* __restrict__ ls_vec) {
+                                                          const float* __restrict__ lt_vec, const float* __restrict__ ls_vec, int mt) {
     const int b = blockIdx.y;
     if (lt_vec) { lt = lt_vec[b]; ls = ls_vec[b]; }      // per-sample times (teacher steps of the distillation loss)
     const LogsnrCoef c = logsnr_coef(lt);
@@ -132,10 +139,10 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const float* __restri
     const int64_t base = (int64_t)b * n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float zz = z[base + i];
-        float xh = clip1(c.alpha * zz - c.sigma * v[base + i]);
+        float xh = clip1(x_from_out(v[base + i], zz, c, mt));
         float eh = c.c1 * (zz - xh * c.c2);
         if (vu) {   // classifier-free guidance in eps space (:176-186)
-            const float xu = clip1(c.alpha * zz - c.sigma * vu[base + i]);
+            const float xu = clip1(x_from_out(vu[base + i], zz, c, mt));
             const float eu = c.c1 * (zz - xu * c.c2);
             const float e = (1.0f + w) * eh + (-w) * eu;
             xh = clip1(c.d1 * (zz - e * c.d2));
@@ -258,38 +265,41 @@ extern "C" int gmk_q_sample(const float* x, const float* eps, const float* u, fl
 }
 
 extern "C" int gmk_v_loss(const float* v, const float* z, const float* x, const float* eps, const float* logsnr,
-                          float* loss_b, float* x_mse, float* eps_mse, float* dv, float grad_scale, int loss_type, int B,
-                          int64_t n, void* stream) {
+                          float* loss_b, float* x_mse, float* eps_mse, float* dv, float grad_scale, int loss_type,
+                          int mean_type, int B, int64_t n, void* stream) {
     GMK_REQUIRE(v && z && x && eps && logsnr && loss_b, "gmk_v_loss: null pointer");
     GMK_REQUIRE(B > 0 && n > 0, "gmk_v_loss: bad shape");
     GMK_REQUIRE(loss_type == 0 || loss_type == 1, "gmk_v_loss: loss_type must be 0 (snr_trunc) or 1 (snr)");
-    v_loss_kernel<<<B, 256, 0, gmk_stream(stream)>>>(v, z, x, eps, logsnr, loss_b, x_mse, eps_mse, dv, grad_scale, n, loss_type);
+    GMK_REQUIRE(mean_type >= 0 && mean_type <= 2, "gmk_v_loss: mean_type must be 0 (v), 1 (eps) or 2 (x)");
+    v_loss_kernel<<<B, 256, 0, gmk_stream(stream)>>>(v, z, x, eps, logsnr, loss_b, x_mse, eps_mse, dv, grad_scale, n, loss_type, mean_type);
     return gmk_check_launch("gmk_v_loss");
 }
 
 extern "C" int gmk_sampler_step(const float* v, const float* v_uncond, const float* cond_w, const float* z,
                                 const float* noise, float logsnr_t, float logsnr_s, int is_last, float* z_next,
-                                float* x_pred, float* eps_pred, int B, int64_t n, void* stream) {
+                                float* x_pred, float* eps_pred, int mean_type, int B, int64_t n, void* stream) {
     GMK_REQUIRE(v && z && z_next, "gmk_sampler_step: null pointer");
+    GMK_REQUIRE(mean_type >= 0 && mean_type <= 2, "gmk_sampler_step: mean_type must be 0 (v), 1 (eps) or 2 (x)");
     GMK_REQUIRE((v_uncond == nullptr) == (cond_w == nullptr), "gmk_sampler_step: v_uncond and cond_w go together");
     GMK_REQUIRE(B > 0 && B < 65536 && n > 0, "gmk_sampler_step: bad shape");
     int gx = (int)((n + 255) / 256);
     if (gx > 64) gx = 64;
     sampler_step_kernel<<<dim3(gx, B), 256, 0, gmk_stream(stream)>>>(v, v_uncond, cond_w, z, noise, logsnr_t, logsnr_s,
-                                                                     is_last, z_next, x_pred, eps_pred, n, nullptr, nullptr);
+                                                                     is_last, z_next, x_pred, eps_pred, n, nullptr, nullptr, mean_type);
     return gmk_check_launch("gmk_sampler_step");
 }
 
 extern "C" int gmk_ddim_step_vec(const float* v, const float* v_uncond, const float* cond_w, const float* z,
                                  const float* logsnr_t, const float* logsnr_s, float* z_next, float* x_pred, float* eps_pred,
-                                 int B, int64_t n, void* stream) {
+                                 int mean_type, int B, int64_t n, void* stream) {
     GMK_REQUIRE(v && z && z_next && logsnr_t && logsnr_s, "gmk_ddim_step_vec: null pointer");
+    GMK_REQUIRE(mean_type >= 0 && mean_type <= 2, "gmk_ddim_step_vec: mean_type must be 0 (v), 1 (eps) or 2 (x)");
     GMK_REQUIRE((v_uncond == nullptr) == (cond_w == nullptr), "gmk_ddim_step_vec: v_uncond and cond_w go together");
     GMK_REQUIRE(B > 0 && B < 65536 && n > 0, "gmk_ddim_step_vec: bad shape");
     int gx = (int)((n + 255) / 256);
     if (gx > 64) gx = 64;
     sampler_step_kernel<<<dim3(gx, B), 256, 0, gmk_stream(stream)>>>(v, v_uncond, cond_w, z, nullptr, 0.f, 0.f, 0, z_next, x_pred,
-                                                                     eps_pred, n, logsnr_t, logsnr_s);
+                                                                     eps_pred, n, logsnr_t, logsnr_s, mean_type);
     return gmk_check_launch("gmk_ddim_step_vec");
 }
 

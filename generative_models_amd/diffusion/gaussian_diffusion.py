@@ -9,7 +9,8 @@ as the reference passes it (diffusion_model.py:77,85).  All arithmetic is in lib
 * DDIM / ancestral / guidance update   gmk_sampler_step (:174-243,:292)
 * RNG                                   counter-based Philox streams (gmk_rng_*), keyed (seed, rank, draw index)
 
-Only `mean_type='v'` (the reference default, diffusion_model.py:21) is implemented on the HIP path.  Progressive
+`mean_type` 'v' (the reference default, diffusion_model.py:21), 'eps' and 'x' (:58-63) are kernel arguments; 'both'
+(:64-69) splits a 1-channel output along W in the reference and cannot run there — it raises here too.  Progressive
 distillation (:87-91,:105-154) is supported: `teacher_net` is a frozen HIP `SimpleUnet`; teacher DDIM
 steps run through gmk_ddim_step_vec / gmk_distill_target, the student is conditioned on the guidance weight.
 """
@@ -72,8 +73,8 @@ class _VLoss(torch.autograd.Function):
     """loss_b = max(mse_x, mse_eps) of the clipped v-parameterised prediction, differentiable w.r.t. v."""
 
     @staticmethod
-    def forward(ctx, v, z, x, eps, logsnr, loss_type=0):
-        loss_b, _, _, dv = ops.v_loss(v.contiguous(), z, x, eps, logsnr, grad_scale=1.0, loss_type=loss_type)
+    def forward(ctx, v, z, x, eps, logsnr, loss_type=0, mean_type="v"):
+        loss_b, _, _, dv = ops.v_loss(v.contiguous(), z, x, eps, logsnr, grad_scale=1.0, loss_type=loss_type, mean_type=mean_type)
         ctx.save_for_backward(dv)
         return loss_b
 
@@ -82,14 +83,14 @@ class _VLoss(torch.autograd.Function):
         (dv,) = ctx.saved_tensors
         B = dv.shape[0]
         out = ops.scale_rows(dv.view(B, -1), g.contiguous().float()).view_as(dv)
-        return out, None, None, None, None, None
+        return out, None, None, None, None, None, None
 
 
 class GaussianDiffusion:
     def __init__(self, *, mean_type, num_steps, teacher_net=None, teacher_mode=None, sampler="ddim", sample_cond_w=None,
                  seed=0):
-        if mean_type != "v":
-            raise NotImplementedError(f"HIP path implements mean_type='v' (reference default); got {mean_type!r}")
+        if mean_type not in ops.MEAN_TYPES:                     # :70-71
+            raise NotImplementedError(mean_type)
         self.mean_type = mean_type
         self.num_steps = num_steps
         self.teacher_net = teacher_net
@@ -142,14 +143,14 @@ class GaussianDiffusion:
             logsnr_s = ops.logsnr_schedule(B, dev, u=u, shift=1.0 / self.num_steps)           # :118-119
             if self.teacher_mode == "step1":                                      # :121-126 one guided teacher step
                 v, vu = self._teacher_eval(z_t, logsnr, guide, None, guided=True)
-                _, x_target, eps_target = ops.ddim_step_vec(v, z_t, logsnr, logsnr_s, v_uncond=vu, cond_w=cond_w)
+                _, x_target, eps_target = ops.ddim_step_vec(v, z_t, logsnr, logsnr_s, v_uncond=vu, cond_w=cond_w, mean_type=self.mean_type)
                 loss_type = 1
             else:                                                                 # :128-154 two w-conditioned teacher steps
                 logsnr_mid = ops.logsnr_schedule(B, dev, u=u, shift=0.5 / self.num_steps)
                 v1, _ = self._teacher_eval(z_t, logsnr, guide, cond_w, guided=False)
-                z_mid, _, _ = ops.ddim_step_vec(v1, z_t, logsnr, logsnr_mid)
+                z_mid, _, _ = ops.ddim_step_vec(v1, z_t, logsnr, logsnr_mid, mean_type=self.mean_type)
                 v2, _ = self._teacher_eval(z_mid, logsnr_mid, guide, cond_w, guided=False)
-                z_teacher, x_pred_teacher, _ = ops.ddim_step_vec(v2, z_mid, logsnr_mid, logsnr_s)
+                z_teacher, x_pred_teacher, _ = ops.ddim_step_vec(v2, z_mid, logsnr_mid, logsnr_s, mean_type=self.mean_type)
                 x_target, eps_target = ops.distill_target(z_teacher, z_t, x_pred_teacher, logsnr, logsnr_s, i_times)
                 loss_type = 0
         return module, guide, cond_w, z_t, logsnr, x_target, eps_target, loss_type
@@ -160,9 +161,9 @@ class GaussianDiffusion:
         module, guide, w, z_t, logsnr, x_t, eps_t, loss_type = self._prepare(net, x, u, eps, i_times, cond_w)
         v = module(z_t, logsnr, guide=guide, cond_w=w)
         if torch.is_grad_enabled() and v.requires_grad:
-            loss = _VLoss.apply(v, z_t, x_t, eps_t, logsnr, loss_type)
+            loss = _VLoss.apply(v, z_t, x_t, eps_t, logsnr, loss_type, self.mean_type)
         else:
-            loss = ops.v_loss(v, z_t, x_t, eps_t, logsnr, loss_type=loss_type)[0]
+            loss = ops.v_loss(v, z_t, x_t, eps_t, logsnr, loss_type=loss_type, mean_type=self.mean_type)[0]
         return {"loss": loss}
 
     def train_forward_backward(self, *, net, x, grad_scale, u=None, eps=None, i_times=None, cond_w=None,
@@ -172,7 +173,7 @@ class GaussianDiffusion:
         module, guide, w, z_t, logsnr, x_t, eps_t, loss_type = self._prepare(net, x, u, eps, i_times, cond_w)
         ctx = {}
         v = module.forward_hip(z_t, logsnr, guide, w, ctx=ctx)
-        loss_b, x_mse, eps_mse, dv = ops.v_loss(v, z_t, x_t, eps_t, logsnr, grad_scale=grad_scale, loss_type=loss_type)
+        loss_b, x_mse, eps_mse, dv = ops.v_loss(v, z_t, x_t, eps_t, logsnr, grad_scale=grad_scale, loss_type=loss_type, mean_type=self.mean_type)
         module.backward_hip(ctx, dv, on_grads_ready=on_grads_ready)
         return {"loss": loss_b, "x_mse": x_mse, "eps_mse": eps_mse, "logsnr": logsnr}
 
@@ -233,7 +234,7 @@ class GaussianDiffusion:
             noise = None
             if self.sampler == "noisy":
                 noise = ops.aligned(noises[i]) if noises is not None else self.rng.normal(z_t.shape, dev)   # :241
-            z_t, xp, ep = ops.sampler_step(v, z_t, lt, ls, i == 0, v_uncond=vu, cond_w=w, noise=noise, want_pred=record)
+            z_t, xp, ep = ops.sampler_step(v, z_t, lt, ls, i == 0, v_uncond=vu, cond_w=w, noise=noise, want_pred=record, mean_type=self.mean_type)
             if record:
                 zs.append(z_t); xs.append(xp); es.append(ep)
         if record:

@@ -403,7 +403,10 @@ def q_sample(x, eps, u):
     return logsnr, z
 
 
-def v_loss(v, z, x, eps, logsnr, grad_scale=None, loss_type=0):
+MEAN_TYPES = {"v": 0, "eps": 1, "x": 2}      # what the network output parametrises (gaussian_diffusion.py:58-73)
+
+
+def v_loss(v, z, x, eps, logsnr, grad_scale=None, loss_type=0, mean_type="v"):
     """-> (loss_b, x_mse, eps_mse, dv or None).  loss_type 0 'snr_trunc', 1 'snr'."""
     for t, nm in ((v, "v"), (z, "z"), (x, "x"), (eps, "eps"), (logsnr, "logsnr")):
         _f32(t, nm)
@@ -414,11 +417,11 @@ def v_loss(v, z, x, eps, logsnr, grad_scale=None, loss_type=0):
     xm = torch.empty_like(loss_b); em = torch.empty_like(loss_b)
     dv = torch.empty_like(v) if grad_scale is not None else None
     check(lib.gmk_v_loss(_p(v), _p(z), _p(x), _p(eps), _p(logsnr), _p(loss_b), _p(xm), _p(em), _p(dv),
-                         float(grad_scale or 0.0), loss_type, B, n, _s()), "v_loss")
+                         float(grad_scale or 0.0), loss_type, MEAN_TYPES[mean_type], B, n, _s()), "v_loss")
     return loss_b, xm, em, dv
 
 
-def sampler_step(v, z, logsnr_t, logsnr_s, is_last, v_uncond=None, cond_w=None, noise=None, want_pred=False):
+def sampler_step(v, z, logsnr_t, logsnr_s, is_last, v_uncond=None, cond_w=None, noise=None, want_pred=False, mean_type="v"):
     _f32(v, "v"); _f32(z, "z")
     B = z.shape[0]
     n = z.numel() // B
@@ -432,7 +435,7 @@ def sampler_step(v, z, logsnr_t, logsnr_s, is_last, v_uncond=None, cond_w=None, 
     xp = torch.empty_like(z) if want_pred else None
     ep = torch.empty_like(z) if want_pred else None
     check(lib.gmk_sampler_step(_p(v), _p(v_uncond), _p(cond_w), _p(z), _p(noise), float(logsnr_t), float(logsnr_s),
-                               int(is_last), _p(z_next), _p(xp), _p(ep), B, n, _s()), "sampler_step")
+                               int(is_last), _p(z_next), _p(xp), _p(ep), MEAN_TYPES[mean_type], B, n, _s()), "sampler_step")
     return z_next, xp, ep
 
 
@@ -449,15 +452,15 @@ def logsnr_schedule(B, device, u=None, i_times=None, num_steps=1, shift=0.0, wan
     return (logsnr, uo) if want_u else logsnr
 
 
-def ddim_step_vec(v, z, logsnr_t, logsnr_s, v_uncond=None, cond_w=None):
+def ddim_step_vec(v, z, logsnr_t, logsnr_s, v_uncond=None, cond_w=None, mean_type="v"):
     """Teacher DDIM step with per-sample times.  -> (z_s, x_pred, eps_pred)"""
     for t, nm in ((v, "v"), (z, "z"), (logsnr_t, "logsnr_t"), (logsnr_s, "logsnr_s")):
         _f32(t, nm)
     B = z.shape[0]
     n = z.numel() // B
     zs, xp, ep = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
-    check(lib.gmk_ddim_step_vec(_p(v), _p(v_uncond), _p(cond_w), _p(z), _p(logsnr_t), _p(logsnr_s), _p(zs), _p(xp), _p(ep), B, n,
-                                _s()), "ddim_step_vec")
+    check(lib.gmk_ddim_step_vec(_p(v), _p(v_uncond), _p(cond_w), _p(z), _p(logsnr_t), _p(logsnr_s), _p(zs), _p(xp), _p(ep),
+                                MEAN_TYPES[mean_type], B, n, _s()), "ddim_step_vec")
     return zs, xp, ep
 
 

@@ -151,11 +151,14 @@ int gmk_rng_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void*
  * (gaussian_diffusion.py:95-100, diffusion_utils.py:65-73) */
 int gmk_q_sample(const float* x, const float* eps, const float* u, float* logsnr, float* z, int B, int64_t n,
                  void* stream);
-/* gaussian_diffusion.py:61-77,165-169 and their backward in one pass over each sample:
- * x_hat = clip(alpha z - sigma v); eps_hat = eps_from_x; loss_b = max(mean (x_hat-x)^2, mean (eps_hat-eps)^2);
- * dv (optional) = d(grad_scale * sum_b loss_b)/dv.  loss_b/x_mse/eps_mse: fp32 [B]. */
+/* gaussian_diffusion.py:58-77,165-169 and their backward in one pass over each sample:
+ * x_hat = clip(x_from_output(v)); eps_hat = eps_from_x; loss_b = max(mean (x_hat-x)^2, mean (eps_hat-eps)^2);
+ * dv (optional) = d(grad_scale * sum_b loss_b)/dv.  loss_b/x_mse/eps_mse: fp32 [B].
+ * mean_type (the reference's `mean_type`, :58-73) says what the network output v is: 0 'v' (x = alpha z - sigma v),
+ * 1 'eps' (x = (z - sigma v)/alpha), 2 'x' (x = v).  ('both' splits a 1-channel output along W in the reference — dead.) */
 int gmk_v_loss(const float* v, const float* z, const float* x, const float* eps, const float* logsnr, float* loss_b,
-               float* x_mse, float* eps_mse, float* dv, float grad_scale, int loss_type, int B, int64_t n, void* stream);
+               float* x_mse, float* eps_mse, float* dv, float grad_scale, int loss_type, int mean_type, int B, int64_t n,
+               void* stream);
 /* loss_type 0 = 'snr_trunc' (max of the two MSEs, :168-169), 1 = 'snr' (eps MSE only, :170-171, distillation step1);
  * x / eps are the denoising targets (x0, eps) or the teacher's (x_target, eps_target). */
 /* one reverse step on a batch (gaussian_diffusion.py:189-243,174-187,292):
@@ -164,7 +167,7 @@ int gmk_v_loss(const float* v, const float* z, const float* x, const float* eps,
  *   z_next is written; x_pred / eps_pred are optional outputs. */
 int gmk_sampler_step(const float* v, const float* v_uncond, const float* cond_w, const float* z, const float* noise,
                      float logsnr_t, float logsnr_s, int is_last, float* z_next, float* x_pred, float* eps_pred,
-                     int B, int64_t n, void* stream);
+                     int mean_type, int B, int64_t n, void* stream);
 
 /* ---- progressive distillation (gaussian_diffusion.py:87-91,105-154) ------------------------------------------ */
 /* logsnr[b] = schedule(u[b] - shift) with u given, or u = fp32(i_times[b] + 1) / num_steps (discrete time, :90-91);
@@ -173,7 +176,8 @@ int gmk_logsnr_schedule(const float* u, const int64_t* i_times, int num_steps, f
                         int B, void* stream);
 /* one DDIM step with per-sample times logsnr_t[b] -> logsnr_s[b] (teacher steps inside the loss, :116,:129-144) */
 int gmk_ddim_step_vec(const float* v, const float* v_uncond, const float* cond_w, const float* z, const float* logsnr_t,
-                      const float* logsnr_s, float* z_next, float* x_pred, float* eps_pred, int B, int64_t n, void* stream);
+                      const float* logsnr_s, float* z_next, float* x_pred, float* eps_pred, int mean_type, int B, int64_t n,
+                      void* stream);
 /* x_target = (z_teacher - f z_t) / (alpha_s - f alpha_t), f = exp((softplus(l) - softplus(l_s)) / 2); the i == 0 rows
  * take x_pred_teacher; eps_target = eps_from_x(z_t, x_target, l)  (:147-154) */
 int gmk_distill_target(const float* z_teacher, const float* z_t, const float* x_pred_teacher, const float* logsnr,

@@ -231,6 +231,40 @@ def gen_distill(C, S, B, T, seed, name):
     save(name, **out)
 
 
+def gen_meantypes(C, S, B, T, seed, name):
+    """`mean_type` 'eps' and 'x' (gaussian_diffusion.py:58-63): training loss + gradient norms, DDIM without and with guidance."""
+    x0, y = inputs(B, S, seed)
+    y = y.clone(); y[0] = 3
+    torch.manual_seed(seed)
+    eps = torch.randn(x0.shape)
+    u = torch.rand(size=(B,))
+    g = torch.Generator().manual_seed(seed + 2)
+    init = torch.randn((B, 1, S, S), generator=g)
+    out = {"x0": x0, "y": y, "eps": eps, "u": u, "init": init}
+    for mt in ("eps", "x"):
+        net = ref_net(C).train()
+        diff = R_gd.GaussianDiffusion(mean_type=mt, num_steps=T, sampler="ddim", sample_cond_w=-1.0)
+        torch.manual_seed(seed)
+        losses = diff.training_losses(net=partial(net, guide=y), x=x0)["loss"]
+        losses.mean().backward()
+        out[f"{mt}_loss_b"] = losses.detach()
+        names = [k for k, _ in net.named_parameters()]
+        out["grad_names"] = np.array(names)
+        out[f"{mt}_grad_norms"] = torch.stack([p.grad.norm() if p.grad is not None else torch.tensor(0.0)
+                                               for _, p in net.named_parameters()])
+        out[f"{mt}_grad_out2"] = dict(net.named_parameters())["out.2.weight"].grad.detach().clone()
+        net.eval()
+        with torch.no_grad():
+            zs, xs, es = diff.sample(net=partial(net, guide=y), init_x=init)
+            out[f"{mt}_ddim_zs"], out[f"{mt}_ddim_xs"] = zs, xs
+            torch.manual_seed(seed + 3)
+            w = 4.0 * torch.rand(B)
+            torch.manual_seed(seed + 3)
+            zs, xs, es = diff.sample(net=partial(net, guide=y), init_x=init, cond_w=0.5)
+            out[f"{mt}_cfg_w"], out[f"{mt}_cfg_zs"] = w, zs
+    save(name, **out)
+
+
 def main():
     torch.set_num_threads(4)
     gen_schedule()
@@ -249,6 +283,7 @@ def main():
     gen_sample(32, 12, 2, 8, 31, "sample_c32_s12_T8.npz")
     gen_distill(64, 8, 3, 8, 40, "distill_c64_s8.npz")
     gen_distill(128, 8, 3, 8, 41, "distill_c128_s8.npz")
+    gen_meantypes(128, 8, 3, 4, 50, "meantype_c128_s8.npz")
 
 
 if __name__ == "__main__":

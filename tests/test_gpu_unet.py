@@ -283,3 +283,34 @@ def test_odd_batches_and_sizes_bf16_vs_fp32_vs_oracle(B, S):
                      "up.seq.5.skip_connection.weight", "out.2.weight", "time_embed.0.weight", "turn.out_layers.0.bias"):
             gr = p[name].grad
             assert rel_err(net.grad(name), gr) < 6 * tol, name
+
+
+@pytest.mark.parametrize("mt", ["eps", "x"])
+def test_mean_types_vs_golden(golden, mt):
+    """Row D2: the network output read as eps or as x (gaussian_diffusion.py:58-63) — loss, every gradient norm, DDIM
+    trajectories with and without guidance, against vectors captured from the reference (fp32 mode, 1e-3)."""
+    from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    from generative_models_amd.diffusion.simple_unet import SimpleUnet
+    from oracle import unet_ref as U
+    g = golden("meantype_c128_s8.npz")
+    net = SimpleUnet(128, 0.0, compute_dtype=torch.float32); net.load_state_dict(U.closed_form_params(128)); net = net.cuda()
+    diff = GaussianDiffusion(mean_type=mt, num_steps=4, sampler="ddim", sample_cond_w=-1.0)
+    x0, y, u, eps = (T(g[k]).cuda() for k in ("x0", "y", "u", "eps"))
+    B = x0.shape[0]
+    out = diff.train_forward_backward(net=partial(net, guide=y), x=x0, grad_scale=1.0 / B, u=u, eps=eps)
+    assert rel_err(out["loss"], T(g[f"{mt}_loss_b"])) < 1e-3
+    names = [str(n) for n in g["grad_names"]]
+    norms = torch.stack([net.grad(n).norm() for n in names]).cpu()
+    ref = T(g[f"{mt}_grad_norms"])
+    ok = (norms - ref).abs() <= 3e-3 * ref.abs() + 1e-5 * ref.abs().max()
+    assert bool(ok.all()), [(names[i], float(norms[i]), float(ref[i])) for i in (~ok).nonzero().flatten()[:8]]
+    assert rel_err(net.grad("out.2.weight"), T(g[f"{mt}_grad_out2"])) < 3e-3
+    # the same loss through the autograd bridge
+    with torch.no_grad():
+        l2 = diff.training_losses(net=partial(net, guide=y), x=x0, u=u, eps=eps)["loss"]
+    assert rel_err(l2, T(g[f"{mt}_loss_b"])) < 1e-3
+    init = T(g["init"]).cuda()
+    zs, xs, _ = diff.sample(net=partial(net, guide=y), init_x=init)
+    assert rel_err(zs, T(g[f"{mt}_ddim_zs"])) < 5e-3 and rel_err(xs, T(g[f"{mt}_ddim_xs"])) < 5e-3
+    zs, _, _ = diff.sample(net=partial(net, guide=y), init_x=init, cond_w=0.5, net_cond_w=T(g[f"{mt}_cfg_w"]).cuda())
+    assert rel_err(zs, T(g[f"{mt}_cfg_zs"])) < 5e-3

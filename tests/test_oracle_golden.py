@@ -158,3 +158,24 @@ def test_distillation_losses(golden, name, C, mode):
     ref = T(g[f"{mode}_grad_norms"])
     assert bool(((norms - ref).abs() <= 2e-3 * ref.abs() + 1e-5 * ref.abs().max()).all())
     close(student["cond_w_embed.2.weight"].grad, g[f"{mode}_grad_cond_w_embed"], 5e-4)
+
+
+@pytest.mark.parametrize("mt", ["eps", "x"])
+def test_mean_types(golden, mt):
+    """`mean_type` 'eps' / 'x' (gaussian_diffusion.py:58-63): loss, gradient norms, DDIM with and without guidance."""
+    g = golden("meantype_c128_s8.npz")
+    p = {k: v.clone().requires_grad_(True) for k, v in U.closed_form_params(128).items()}
+    out = D.training_losses(p, T(g["x0"]), T(g["y"]), T(g["u"]), T(g["eps"]), mean_type=mt)
+    close(out["loss"], g[f"{mt}_loss_b"], 2e-5)
+    out["loss"].mean().backward()
+    names = [str(n) for n in g["grad_names"]]
+    norms = torch.stack([p[n].grad.norm() if p[n].grad is not None else torch.tensor(0.0) for n in names])
+    ref = T(g[f"{mt}_grad_norms"])
+    assert bool(((norms - ref).abs() <= 2e-3 * ref.abs() + 1e-5 * ref.abs().max()).all())
+    close(p["out.2.weight"].grad, g[f"{mt}_grad_out2"], 2e-4)
+    q = U.closed_form_params(128)
+    with torch.no_grad():
+        zs, xs, _ = D.sample(q, T(g["init"]), T(g["y"]), 4, "ddim", mean_type=mt)
+        close(zs, g[f"{mt}_ddim_zs"], 5e-5); close(xs, g[f"{mt}_ddim_xs"], 5e-5)
+        zs, _, _ = D.sample(q, T(g["init"]), T(g["y"]), 4, "ddim", cond_w=T(g[f"{mt}_cfg_w"]), mean_type=mt)
+        close(zs, g[f"{mt}_cfg_zs"], 1e-4)
