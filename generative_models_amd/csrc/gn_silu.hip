@@ -12,6 +12,20 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// nn.Dropout(p) behind the SiLU (simple_unet.py:171): element e of the NHWC tensor is kept iff its Philox uniform
+// u01(philox4x32(offset + e/4, seed)[e%4]) >= p — exactly gmk_rng_uniform(seed, offset) of the same shape, so the mask can be
+// regenerated anywhere (the backward kernel does); kept values are scaled by 1/(1-p).  v: 8 consecutive channels from e0.
+__device__ __forceinline__ void drop8(float (&v)[8], size_t e0, float p, uint64_t seed, uint64_t off) {
+    const float scale = 1.0f / (1.0f - p);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        uint32_t r[4];
+        philox4x32(off + (uint64_t)(e0 >> 2) + q, seed, r);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[4 * q + k] = u01(r[k]) >= p ? v[4 * q + k] * scale : 0.f;
+    }
+}
+
 // A workgroup handles one (sample, channel slab).  Slabs narrower than the sample keep the set of lines the resident
 // workgroups of an XCD are sweeping (32 CUs x a few workgroups x HW*CS*2 B) inside that XCD's 4 MiB L2, so the second
 // sweep of the two-sweep kernels below is an L2 hit instead of a second trip to HBM.  Workgroup ids round-robin over the 8
@@ -35,7 +49,8 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
                                                               float* __restrict__ mean, float* __restrict__ rstd,
                                                               int HW, int C, int G, float eps,
                                                               const float* __restrict__ part, int TP, int ntiles,
-                                                              int CS, int B) {
+                                                              int CS, int B, float drop_p, uint64_t drop_seed,
+                                                              uint64_t drop_off) {
     __shared__ float red[kThreads * 4];
     __shared__ float smean[64], srstd[64];
     const int tid = threadIdx.x;
@@ -116,6 +131,7 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
         load8(xb + (size_t)p * C, v);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = siluf_(fmaf(v[i], sc[i], sh[i]));
+        if (drop_p > 0.f) drop8(v, ((size_t)b * HW + p) * C + c0 + vec * 8, drop_p, drop_seed, drop_off);
         store8(yb + (size_t)p * C, v);
     }
 }
@@ -125,7 +141,8 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd, const T* __restrict__ dadd1,
     const T* __restrict__ dadd2, T* __restrict__ dx, float* __restrict__ dgp, float* __restrict__ dbp,
-    float* __restrict__ dxsum, int dxsum_stride, int HW, int C, int G, int CS, int B) {
+    float* __restrict__ dxsum, int dxsum_stride, int HW, int C, int G, int CS, int B, float drop_p, uint64_t drop_seed,
+    uint64_t drop_off) {
     __shared__ float red[kThreads * 16];
     __shared__ float chg[256], chb[256];
     __shared__ float sA[64], sB[64];
@@ -154,6 +171,7 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
         float xv[8], dv[8];
         load8(x + base + (size_t)p * C, xv);
         load8(dy + base + (size_t)p * C, dv);
+        if (drop_p > 0.f) drop8(dv, base + (size_t)p * C, drop_p, drop_seed, drop_off);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float xh = (xv[i] - mu[i]) * rs[i];
@@ -198,6 +216,7 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
         float xv[8], dv[8], o[8];
         load8(x + base + (size_t)p * C, xv);
         load8(dy + base + (size_t)p * C, dv);
+        if (drop_p > 0.f) drop8(dv, base + (size_t)p * C, drop_p, drop_seed, drop_off);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float xh = (xv[i] - mu[i]) * rs[i];
@@ -554,7 +573,8 @@ int gn_slab_channels(int mode, int C, int G, int HW, int elem_bytes, bool backwa
 
 extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                                int B, int HW, int C, int groups, float eps, const float* stats_part, int tile_pixels,
-                               int ntiles, int dtype, void* stream) {
+                               int ntiles, float drop_p, uint64_t drop_seed, uint64_t drop_offset, int dtype, void* stream) {
+    GMK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gmk_gn_silu_fwd: dropout probability %g outside [0, 1)", (double)drop_p);
     GMK_REQUIRE(!stats_part || (tile_pixels >= 32 && ntiles > 0 && HW >= 32 && C % 4 == 0),
                 "gmk_gn_silu_fwd: bad statistics geometry");
     GMK_REQUIRE(x && y && gamma && beta && mean && rstd, "gmk_gn_silu_fwd: null pointer");
@@ -564,7 +584,7 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
     // 0-50 % SLOWER than the streaming kernels at 28x28 / 14x14 / 7x7 — one or few resident workgroups per CU serialise their
     // load / compute / store phases, while the streaming kernels' second sweep is served from L2 / Infinity Cache)
     const int gn_mode = gmk_kernel_choice(2, "GMK_GN_KERNEL");
-    const int lds_ok = gn_mode == 2;
+    const int lds_ok = gn_mode == 2 && drop_p == 0.f;
     const int lds_max_hw = 1024;
     const int64_t nbytes = (int64_t)B * HW * C * 2;
     if (dtype == GMK_BF16 && lds_ok && !stats_part && C % 64 == 0 && HW <= lds_max_hw && nbytes < 0xFFFF0000ll) {
@@ -578,11 +598,13 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
     } else if (dtype == GMK_BF16) {
         const int CS = stats_part ? C : gn_slab_channels(gn_mode, C, groups, HW, 2, false);
         gn_silu_fwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
-            (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, HW, C, groups, eps, stats_part, tile_pixels, ntiles, CS, B);
+            (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, HW, C, groups, eps, stats_part, tile_pixels, ntiles, CS, B, drop_p,
+            drop_seed, drop_offset);
     } else if (dtype == GMK_F32) {
         const int CS = stats_part ? C : gn_slab_channels(gn_mode, C, groups, HW, 4, false);
         gn_silu_fwd_kernel<float><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
-            (const float*)x, (float*)y, gamma, beta, mean, rstd, HW, C, groups, eps, stats_part, tile_pixels, ntiles, CS, B);
+            (const float*)x, (float*)y, gamma, beta, mean, rstd, HW, C, groups, eps, stats_part, tile_pixels, ntiles, CS, B, drop_p,
+            drop_seed, drop_offset);
     }
     else
         GMK_REQUIRE(false, "gmk_gn_silu_fwd: bad dtype %d", dtype);
@@ -592,7 +614,8 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
 extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                                const float* rstd, const void* dadd1, const void* dadd2, void* dx, float* dgamma_part,
                                float* dbeta_part, float* dxsum, int dxsum_stride, int B, int HW, int C, int groups,
-                               int dtype, void* stream) {
+                               float drop_p, uint64_t drop_seed, uint64_t drop_offset, int dtype, void* stream) {
+    GMK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gmk_gn_silu_bwd: dropout probability %g outside [0, 1)", (double)drop_p);
     GMK_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma_part && dbeta_part,
                 "gmk_gn_silu_bwd: null pointer");
     GMK_REQUIRE(B > 0 && HW > 0 && gn_shape_ok(C, groups), "gmk_gn_silu_bwd: unsupported shape B=%d HW=%d C=%d G=%d", B,
@@ -602,7 +625,7 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
     // 0-50 % SLOWER than the streaming kernels at 28x28 / 14x14 / 7x7 — one or few resident workgroups per CU serialise their
     // load / compute / store phases, while the streaming kernels' second sweep is served from L2 / Infinity Cache)
     const int gn_mode = gmk_kernel_choice(2, "GMK_GN_KERNEL");
-    const int lds_ok = gn_mode == 2;
+    const int lds_ok = gn_mode == 2 && drop_p == 0.f;
     const int lds_max_hw = 1024;
     const int64_t nbytes = (int64_t)B * HW * C * 2;
     if (dtype == GMK_BF16 && lds_ok && C % 32 == 0 && HW <= lds_max_hw && nbytes < 0xFFFF0000ll) {
@@ -619,12 +642,12 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
         const int CS = gn_slab_channels(gn_mode, C, groups, HW, 2, true);
         gn_silu_bwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2,
-            (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, CS, B);
+            (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, CS, B, drop_p, drop_seed, drop_offset);
     } else if (dtype == GMK_F32) {
         const int CS = gn_slab_channels(gn_mode, C, groups, HW, 4, true);
         gn_silu_bwd_kernel<float><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const float*)dy, (const float*)x, gamma, beta, mean, rstd, (const float*)dadd1, (const float*)dadd2,
-            (float*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, CS, B);
+            (float*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, CS, B, drop_p, drop_seed, drop_offset);
     }
     else
         GMK_REQUIRE(false, "gmk_gn_silu_bwd: bad dtype %d", dtype);

@@ -69,6 +69,7 @@ def make_plugin(GMBase, AttrDict):
                                                sampler=get("sampler"), teacher_net=self.teacher_net,
                                                teacher_mode=get("teacher_mode"), sample_cond_w=get("sample_cond_w"),
                                                seed=seed)
+            self.net.drop_seed = seed + 104729              # per-rank dropout masks (only used when dropout > 0)
             self.optimizer = FusedAdam(self.net, lr=G.lr if "lr" in G else 3e-4)
             self.size = 32 if ("pad32" in G and G.pad32) else 28
             self._aux_rng = PhiloxStream(seed + 7919)

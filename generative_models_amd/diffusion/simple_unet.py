@@ -86,13 +86,15 @@ class SimpleUnet(nn.Module):
         super().__init__()
         if channels % 128 != 0 or channels > 256:
             raise ValueError(f"the HIP path supports hidden_size 128 or 256 (MFMA tile width 128); got {channels}")
-        if dropout != 0.0:
-            raise NotImplementedError("dropout > 0 is not implemented on the HIP path (reference default is 0.0)")
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), got {dropout}")
         if not 1 <= in_channels <= 4:
             raise ValueError("in_channels must be 1..4")
         if compute_dtype not in (torch.bfloat16, torch.float32):
             raise ValueError("compute_dtype must be torch.bfloat16 or torch.float32")
         self.channels, self.in_channels, self.compute_dtype = channels, in_channels, compute_dtype
+        self.dropout = float(dropout)      # nn.Dropout(p) of every ResBlock's out_layers (simple_unet.py:171); training mode only
+        self.drop_seed, self._drop_counter = 0x5EEDD0, 0
         self._inventory = param_inventory(channels, in_channels)
         # arena order: the 12 emb_layers Linear weights, then their biases (one batched GEMM serves all 12
         # ResBlocks), then everything else in reference order; every tensor starts on a 16-byte boundary.
@@ -283,7 +285,11 @@ class SimpleUnet(nn.Module):
         wf1, _ = self._packs[f"{name}.in_layers.2"]
         h = ops.conv_igemm(a, wf1, C, 3, ops.NORMAL, (H, W), bias=P[f"{name}.in_layers.2.bias"],
                            emb=emb_all[:, blk * C:(blk + 1) * C], gn_stats=True)
-        a2, mean2, rstd2 = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], 32)
+        drop = None
+        if self.dropout > 0.0 and self.training:              # mask = Philox uniform >= p, regenerated by the backward kernel
+            drop = (self.dropout, self.drop_seed, self._drop_counter)
+            self._drop_counter += (h.numel() + 3) // 4
+        a2, mean2, rstd2 = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], 32, dropout=drop)
         if len(srcs) == 2:
             wfs, _ = self._packs[f"{name}.skip_connection"]
             res = ops.conv_igemm(srcs, wfs, C, 1, ops.NORMAL, (H, W), bias=P[f"{name}.skip_connection.bias"])
@@ -294,6 +300,7 @@ class SimpleUnet(nn.Module):
                              gn_stats=True)
         if ctx is not None:
             ctx[name] = (srcs, a, stats1, h, a2, (mean2, rstd2))
+            ctx[name + ".dropout"] = drop
         return out
 
     def _wgrad(self, dy, srcs, ksize, mode, dw):
@@ -329,7 +336,7 @@ class SimpleUnet(nn.Module):
         _, wd2 = self._packs[f"{name}.out_layers.3"]
         da2 = ops.conv_igemm([dout], wd2, C, 3, ops.NORMAL, (H, W))
         dh, dgp, dbp = ops.gn_silu_bwd(da2, h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], mean2,
-                                       rstd2, dxsum=demb_all[:, blk * C:(blk + 1) * C])
+                                       rstd2, dxsum=demb_all[:, blk * C:(blk + 1) * C], dropout=ctx.pop(name + ".dropout", None))
         ops.colsum(dgp, G[f"{name}.out_layers.0.weight"], defer=True); ops.colsum(dbp, G[f"{name}.out_layers.0.bias"], defer=True)
         # conv1 (in_layers.2): bias gradient = column sum of the embedding gradient slice (both are sum_hw dh)
         ops.colsum(demb_all[:, blk * C:(blk + 1) * C], G[f"{name}.in_layers.2.bias"], defer=True)

@@ -98,9 +98,10 @@ GN_STATS = False
 WGRAD_STREAM = os.environ.get("GMK_WGRAD_STREAM", "1") != "0"    # weight gradients on a side stream beside the data-gradient chain (simple_unet._wgrad)
 
 
-def gn_silu_fwd(x, gamma, beta, groups, eps=1e-5):
+def gn_silu_fwd(x, gamma, beta, groups, eps=1e-5, dropout=None):
     """x NHWC [B,H,W,C] -> (y, mean[B,G], rstd[B,G]).  If the convolution that produced x attached its partial
-    GroupNorm statistics (x._gn_stats), the statistics pass over x is skipped."""
+    GroupNorm statistics (x._gn_stats), the statistics pass over x is skipped.  dropout = (p, seed, offset): nn.Dropout(p)
+    behind the SiLU with the mask `rng_uniform(x.shape, seed, offset) >= p` (pass the same triple to gn_silu_bwd)."""
     _chk(x, name="x"); _f32(gamma, "gamma"); _f32(beta, "beta")
     B, H, W, C = x.shape
     assert gamma.numel() == C and beta.numel() == C
@@ -109,12 +110,13 @@ def gn_silu_fwd(x, gamma, beta, groups, eps=1e-5):
     rstd = torch.empty_like(mean)
     st = getattr(x, "_gn_stats", None)
     part, tp, nt = st if st is not None else (None, 0, 0)
+    dp, dseed, doff = dropout if dropout is not None else (0.0, 0, 0)
     check(lib.gmk_gn_silu_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), B, H * W, C, groups, eps, _p(part), tp, nt,
-                              _DT[x.dtype], _s()), "gn_silu_fwd")
+                              float(dp), int(dseed), int(doff), _DT[x.dtype], _s()), "gn_silu_fwd")
     return y, mean, rstd
 
 
-def gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=None, dadd2=None, dxsum=None):
+def gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=None, dadd2=None, dxsum=None, dropout=None):
     """-> (dx, dgamma_part[B,C], dbeta_part[B,C]); dxsum (optional fp32 [B, >=C] view with row stride) is filled."""
     _chk(x, name="x"); _chk(dy, x.dtype, "dy")
     assert dy.shape == x.shape
@@ -130,8 +132,10 @@ def gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=None, dadd2=None, dxsum=No
     if dxsum is not None:
         assert dxsum.dtype == torch.float32 and dxsum.shape == (B, C) and dxsum.stride(1) == 1
         stride = dxsum.stride(0)
+    dp, dseed, doff = dropout if dropout is not None else (0.0, 0, 0)
     check(lib.gmk_gn_silu_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dadd1), _p(dadd2), _p(dx),
-                              _p(dgp), _p(dbp), _p(dxsum), stride, B, H * W, C, G, _DT[x.dtype], _s()), "gn_silu_bwd")
+                              _p(dgp), _p(dbp), _p(dxsum), stride, B, H * W, C, G, float(dp), int(dseed), int(doff),
+                              _DT[x.dtype], _s()), "gn_silu_bwd")
     return dx, dgp, dbp
 
 

@@ -57,16 +57,19 @@ int gmk_pack_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int cout, i
  * two calls of 16 groups each, simple_unet.py:150,161); mean/rstd: fp32 [B][groups] (written). */
 int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                     int B, int HW, int C, int groups, float eps, const float* stats_part, int tile_pixels, int ntiles,
-                    int dtype, void* stream);
+                    float drop_p, uint64_t drop_seed, uint64_t drop_offset, int dtype, void* stream);
 /* stats_part (optional): partial sums emitted by the producing convolution (see gmk_conv_igemm gn_stats); when given,
- * the statistics pass over x is skipped (x is read once). */
+ * the statistics pass over x is skipped (x is read once).
+ * drop_p > 0: nn.Dropout(p) behind the SiLU (simple_unet.py:171, training mode): element e of y (NHWC order) is kept and
+ * scaled by 1/(1-p) iff gmk_rng_uniform(seed = drop_seed, offset = drop_offset)[e] >= drop_p, else zeroed; pass the same
+ * triple to gmk_gn_silu_bwd. */
 /* backward of the above.  dx = d/dx + dadd1 + dadd2 (optional NHWC addends, e.g. the identity-skip gradient).
  * dgamma_part/dbeta_part: fp32 [B][C] per-sample partials (reduce with gmk_colsum); dxsum: optional fp32
  * [B][dxsum_stride] per-sample channel sums of the final dx (bias / embedding gradients). */
 int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                     const float* rstd, const void* dadd1, const void* dadd2, void* dx, float* dgamma_part,
                     float* dbeta_part, float* dxsum, int dxsum_stride, int B, int HW, int C, int groups,
-                    int dtype, void* stream);
+                    float drop_p, uint64_t drop_seed, uint64_t drop_offset, int dtype, void* stream);
 /* out[b][c] = sum over pixels of x[b][:, c]  (NHWC, fp32 result [B][out_stride]) */
 int gmk_chansum(const void* x, float* out, int out_stride, int B, int HW, int C, int dtype, void* stream);
 /* out[c] (+)= sum_r part[r*stride + c], r < R, c < C  (fp32) */

@@ -166,23 +166,27 @@ def gn_silu(x, w, b, groups=32, eps=1e-5):
     return F.silu(F.group_norm(x, groups, w, b, eps))
 
 
-def resblock(p, prefix, x, emb):
-    """simple_unet.py:181-186."""
+def resblock(p, prefix, x, emb, drop=None):
+    """simple_unet.py:181-186.  drop = (mask, p): the nn.Dropout(p) of out_layers (:171) with an explicit keep-mask."""
     h = gn_silu(x, p[f"{prefix}.in_layers.0.weight"], p[f"{prefix}.in_layers.0.bias"])
     h = F.conv2d(h, p[f"{prefix}.in_layers.2.weight"], p[f"{prefix}.in_layers.2.bias"], padding=1)
     e = F.linear(F.silu(emb), p[f"{prefix}.emb_layers.1.weight"], p[f"{prefix}.emb_layers.1.bias"])
     h = h + e[..., None, None]
     h = gn_silu(h, p[f"{prefix}.out_layers.0.weight"], p[f"{prefix}.out_layers.0.bias"])
+    if drop is not None:
+        h = h * drop[0] / (1.0 - drop[1])
     h = F.conv2d(h, p[f"{prefix}.out_layers.3.weight"], p[f"{prefix}.out_layers.3.bias"], padding=1)
     if f"{prefix}.skip_connection.weight" in p:
         x = F.conv2d(x, p[f"{prefix}.skip_connection.weight"], p[f"{prefix}.skip_connection.bias"])
     return x + h
 
 
-def unet_forward(p, x, logsnr, guide=None, cond_w=None, taps=None):
+def unet_forward(p, x, logsnr, guide=None, cond_w=None, taps=None, dropout=None):
     """v_hat = net(z, logsnr, guide, cond_w) — simple_unet.py:44-72.
 
-    `taps`, if a dict, receives named intermediate activations (NCHW) for per-layer checks."""
+    `taps`, if a dict, receives named intermediate activations (NCHW) for per-layer checks.
+    `dropout` = (masks, p): training-mode nn.Dropout(p) with one explicit NCHW keep-mask per ResBlock name."""
+    dm = (lambda n: (dropout[0][n], dropout[1])) if dropout is not None else (lambda n: None)
     emb = embed(p, logsnr, guide, cond_w)
     t = taps if taps is not None else {}
     t["emb"] = emb
@@ -191,29 +195,29 @@ def unet_forward(p, x, logsnr, guide=None, cond_w=None, taps=None):
     h = F.conv2d(x, p["down.seq.0.conv.weight"], p["down.seq.0.conv.bias"], padding=1)
     cache.append(h)
     for i in (1, 2):
-        h = resblock(p, f"down.seq.{i}", h, emb)
+        h = resblock(p, f"down.seq.{i}", h, emb, dm(f"down.seq.{i}"))
         cache.append(h)
     h = F.conv2d(h, p["down.seq.3.conv.weight"], p["down.seq.3.conv.bias"], stride=2, padding=1)
     cache.append(h)
     for i in (4, 5):
-        h = resblock(p, f"down.seq.{i}", h, emb)
+        h = resblock(p, f"down.seq.{i}", h, emb, dm(f"down.seq.{i}"))
         cache.append(h)
     h = F.conv2d(h, p["down.seq.6.conv.weight"], p["down.seq.6.conv.bias"], stride=2, padding=1)
     cache.append(h)
     for i, c in enumerate(cache):
         t[f"down.{i}"] = c
     # turn (:68)
-    h = resblock(p, "turn", h, emb)
+    h = resblock(p, "turn", h, emb, dm("turn"))
     t["turn"] = h
     # Up (:146-152): cat with the reversed cache, ResBlock(2C->C), nearest x2 + conv at idx 0 and 3
     for i in range(7):
         h = torch.cat([h, cache[6 - i]], 1)
         if i in (0, 3):
-            h = resblock(p, f"up.seq.{i}.0", h, emb)
+            h = resblock(p, f"up.seq.{i}.0", h, emb, dm(f"up.seq.{i}.0"))
             h = F.interpolate(h, scale_factor=2, mode="nearest")
             h = F.conv2d(h, p[f"up.seq.{i}.1.conv.weight"], p[f"up.seq.{i}.1.conv.bias"], padding=1)
         else:
-            h = resblock(p, f"up.seq.{i}", h, emb)
+            h = resblock(p, f"up.seq.{i}", h, emb, dm(f"up.seq.{i}"))
         t[f"up.{i}"] = h
     # head (:38-42)
     h = gn_silu(h, p["out.0.weight"], p["out.0.bias"])

@@ -314,3 +314,46 @@ def test_mean_types_vs_golden(golden, mt):
     assert rel_err(zs, T(g[f"{mt}_ddim_zs"])) < 5e-3 and rel_err(xs, T(g[f"{mt}_ddim_xs"])) < 5e-3
     zs, _, _ = diff.sample(net=partial(net, guide=y), init_x=init, cond_w=0.5, net_cond_w=T(g[f"{mt}_cfg_w"]).cuda())
     assert rel_err(zs, T(g[f"{mt}_cfg_zs"])) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dropout_training_mode_vs_oracle(dtype):
+    """`--dropout p` (simple_unet.py:171, nn.Dropout behind the out_layers SiLU): the kernel's keep-mask is the Philox uniform
+    stream `rng_uniform(shape, seed, offset) >= p`, so the oracle can be run with exactly the same masks; eval mode drops nothing."""
+    from generative_models_amd import ops
+    from generative_models_amd.diffusion.simple_unet import SimpleUnet, RES_BLOCKS
+    from oracle import unet_ref as U
+    p_drop, B, S = 0.2, 3, 12
+    params = U.reference_init_params(128, zero_out_layers=False)
+    net = SimpleUnet(128, p_drop, compute_dtype=dtype); net.load_state_dict(params); net = net.cuda().train()
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn((B, 1, S, S), generator=g); l = torch.tensor([-4.0, 1.0, 6.0]); y = torch.tensor([2, -1, 8])
+    dout = torch.randn((B, 1, S, S), generator=g)
+    ctx = {}
+    out = net.forward_hip(z.cuda(), l.cuda(), y.cuda(), None, ctx=ctx)
+    masks, kept = {}, []
+    for name in RES_BLOCKS:
+        pd, seed, off = ctx[name + ".dropout"]
+        h = ctx[name][3]                                           # conv1 output, NHWC: the tensor the mask is laid over
+        m = (ops.rng_uniform(tuple(h.shape), seed, off, h.device) >= pd).float()
+        masks[name] = m.permute(0, 3, 1, 2).cpu()
+        kept.append(float(m.mean()))
+    assert all(abs(k - (1 - p_drop)) < 0.02 for k in kept), kept
+    assert len({ctx[n + ".dropout"][2] for n in RES_BLOCKS}) == len(RES_BLOCKS)      # disjoint counter ranges
+    pr = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = U.unet_forward(pr, z, l, guide=y, dropout=(masks, p_drop))
+    tol = TOL[dtype]
+    assert rel_err(out, ref) < tol
+    ref.backward(dout)
+    net.backward_hip(ctx, dout.cuda())
+    for name in ("down.seq.1.out_layers.3.weight", "down.seq.1.out_layers.0.weight", "up.seq.5.in_layers.2.weight",
+                 "turn.out_layers.0.bias", "time_embed.0.weight", "down.seq.0.conv.weight"):
+        assert rel_err(net.grad(name), pr[name].grad) < 6 * tol, name
+    # eval mode: no dropout, equals the oracle without masks
+    net.eval()
+    with torch.no_grad():
+        ref_eval = U.unet_forward(params, z, l, guide=y)
+    out_eval = net.forward_hip(z.cuda(), l.cuda(), y.cuda(), None)
+    l2 = float((out_eval.cpu().double() - ref_eval.double()).norm() / ref_eval.double().norm())
+    # bf16: relative-L2 bar with the worst element at 1.5x (bf16 storage noise of an all-layers-live net, see the ragged-shape test)
+    assert l2 < tol and rel_err(out_eval, ref_eval) < (tol if dtype == torch.float32 else 1.5 * tol), (l2, rel_err(out_eval, ref_eval))
