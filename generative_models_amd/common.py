@@ -134,6 +134,24 @@ class NullWriter:
         pass
 
 
+def write_grid(writer, tag, x, epoch):
+    """25 samples as one 5x5 image (gms/common.py:177-180: '(n1 n2) c h w -> c (n1 h) (n2 w)')."""
+    assert tuple(x.shape) == (25, 1, 28, 28)
+    grid = x.reshape(5, 5, 1, 28, 28).permute(2, 0, 3, 1, 4).reshape(1, 140, 140)
+    writer.add_image(tag, grid, epoch)
+    return grid
+
+
+def write_gridvid(writer, tag, x, epoch):
+    """A [T, 25, 1, 28, 28] trajectory as a 3-channel 5x5-grid video, fps = min(T // 3, 60) (gms/common.py:183-193)."""
+    T = x.shape[0]
+    assert tuple(x.shape[1:]) == (25, 1, 28, 28)
+    vid = x.reshape(T, 5, 5, 1, 28, 28).permute(0, 3, 1, 4, 2, 5).reshape(T, 1, 140, 140)[None]
+    vid = vid.repeat(1, 1, 3, 1, 1)
+    writer.add_video(tag, vid, epoch, fps=min(T // 3, 60))
+    return vid
+
+
 def dump_logger(logger, writer, i, G):
     """Print + write the epoch means and hps.yaml (gms/common.py:65-82).  The git hash is best-effort: the
     reference requires a checkout; outside one it is recorded as 'unknown'."""

@@ -123,9 +123,11 @@ def make_plugin(GMBase, AttrDict):
             zs, xs, eps = self.diffusion.sample(net=partial(self.net, guide=labels), init_x=noise)
             zs, xs, eps = proc(zs), proc(xs), proc(eps)
             self.last_eval = {"samples": zs[-1], "sampling_process": zs, "eps": eps, "x": xs}
-            if writer is not None and hasattr(writer, "add_image"):
-                grid = zs[-1].reshape(5, 5, *zs.shape[-2:]).permute(0, 2, 1, 3).reshape(1, 5 * zs.shape[-2], 5 * zs.shape[-1])
-                writer.add_image("samples", grid, epoch)
+            if writer is not None and self.net.in_channels == 1:        # :105-110, same tags
+                common.write_grid(writer, "samples", zs[-1], epoch)
+                common.write_gridvid(writer, "sampling_process", zs, epoch)
+                common.write_gridvid(writer, "diffusion_model/eps", eps, epoch)
+                common.write_gridvid(writer, "diffusion_model/x", xs, epoch)
             random.randint(0, 2 ** 32)                                # :111 keeps the host RNG consumption
 
     return DiffusionModel

@@ -45,7 +45,8 @@ DG.classifier = Path("./weights/classifier.pt")
 DG.eval_heavy = 0
 DG.skip_training = 0
 # additions
-DG.data = "synthetic"
+DG.data = "synthetic"      # 'synthetic' | 'mnist' (IDX files under <data_root>/MNIST/raw)
+DG.data_root = Path("data")
 DG.train_batches = 8       # synthetic batches per epoch (per rank)
 DG.test_batches = 2
 
@@ -113,11 +114,16 @@ def load_model_and_data(argv=None):
         model.load_state_dict(torch.load(G.weights_from, map_location=G.device), strict=False)
     if parallel.world() > 1 and hasattr(model, "net"):
         parallel.GradSync(model.net).broadcast_params(0)
-    if G.data != "synthetic":
-        raise NotImplementedError("only --data synthetic is available (no network for MNIST in this environment)")
     r = parallel.rank()
-    train_ds = SyntheticMNIST(G.bs, G.train_batches, G.pad32, G.binarize, G.device, seed=1000 + r)
-    test_ds = SyntheticMNIST(G.bs, G.test_batches, G.pad32, G.binarize, G.device, seed=2000 + r)
+    if G.data == "mnist":         # gms/main.py:84 load_mnist: the IDX files under data/MNIST/raw (cannot be downloaded here)
+        from . import data as mnist_data
+        train_ds, test_ds = mnist_data.load_mnist(G.bs, G.binarize, G.pad32, root=str(G.data_root), device=G.device, seed=1000,
+                                                  rank=r, world=parallel.world())
+    elif G.data == "synthetic":
+        train_ds = SyntheticMNIST(G.bs, G.train_batches, G.pad32, G.binarize, G.device, seed=1000 + r)
+        test_ds = SyntheticMNIST(G.bs, G.test_batches, G.pad32, G.binarize, G.device, seed=2000 + r)
+    else:
+        raise ValueError(f"--data {G.data!r}: 'synthetic' or 'mnist'")
     print("num_vars", common.count_vars(model))
     return model, train_ds, test_ds, None, None, G
 

@@ -187,3 +187,71 @@ def test_gradient_exchange_two_ranks_gloo(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_mnist_idx_loader_and_transform(tmp_path):
+    """Row N4: IDX reader + the reference's transform chain (gms/common.py:104-111) + shuffle / drop_last batching."""
+    import numpy as np
+    from generative_models_amd import data
+    rng = np.random.default_rng(0)
+    raw = tmp_path / "MNIST" / "raw"
+    raw.mkdir(parents=True)
+    imgs = {True: rng.integers(0, 256, (70, 28, 28), dtype=np.uint8), False: rng.integers(0, 256, (23, 28, 28), dtype=np.uint8)}
+    labs = {True: rng.integers(0, 10, 70, dtype=np.uint8), False: rng.integers(0, 10, 23, dtype=np.uint8)}
+    for train in (True, False):
+        data.write_idx(raw / data.FILES[train][0], imgs[train])
+        data.write_idx(raw / (data.FILES[train][1] + ".gz"), labs[train])          # gz and plain are both accepted
+    assert np.array_equal(data.read_idx(raw / data.FILES[True][0]), imgs[True])
+    with pytest.raises(ValueError):
+        (tmp_path / "bad").write_bytes(b"\x01\x02\x03\x04rest")
+        data.read_idx(tmp_path / "bad")
+    # transform chain restated from the reference
+    x8 = imgs[True]
+    to_tensor = torch.from_numpy(x8).float().div(255).unsqueeze(1)
+    assert torch.equal(data.transform(x8, binarize=True, pad32=False), (to_tensor > 0.5).float())
+    ref = torch.nn.functional.pad(2 * to_tensor - 1, (2, 2, 2, 2))
+    got = data.transform(x8, binarize=False, pad32=True)
+    assert got.shape == (70, 1, 32, 32) and torch.equal(got, ref) and float(got[:, :, 0].abs().max()) == 0.0   # zero border
+    # loaders: drop_last, every sample at most once per epoch, labels follow their images, epochs reshuffle
+    tr, te = data.load_mnist(16, binarize=False, pad32=False, root=str(tmp_path), seed=3)
+    assert len(tr) == 4 and len(te) == 1
+    full = data.transform(imgs[True], False, False)
+    seen = []
+    for x, y in tr:
+        assert x.shape == (16, 1, 28, 28) and y.dtype == torch.int64 and float(x.min()) >= -1 and float(x.max()) <= 1
+        for xi, yi in zip(x, y):
+            idx = int((full == xi).flatten(1).all(1).nonzero()[0])
+            assert int(labs[True][idx]) == int(yi)
+            seen.append(idx)
+    assert len(set(seen)) == 64
+    assert [int(i) for i in seen] != [int((full == xi).flatten(1).all(1).nonzero()[0]) for x, _ in tr for xi in x]
+    # two ranks see disjoint shards of one permutation
+    a = data.MnistLoader(str(tmp_path), True, 8, False, False, seed=5, rank=0, world=2)
+    b = data.MnistLoader(str(tmp_path), True, 8, False, False, seed=5, rank=1, world=2)
+    ia = {int((full == xi).flatten(1).all(1).nonzero()[0]) for x, _ in a for xi in x}
+    ib = {int((full == xi).flatten(1).all(1).nonzero()[0]) for x, _ in b for xi in x}
+    assert len(a) == 4 and not (ia & ib)
+    with pytest.raises(FileNotFoundError):
+        data.load_mnist(4, root=str(tmp_path / "nowhere"))
+
+
+def test_write_grid_and_gridvid_match_the_einops_patterns():
+    """gms/common.py:177-193: '(n1 n2) c h w -> c (n1 h) (n2 w)' and the 3-channel video with fps = min(T // 3, 60)."""
+    from einops import rearrange, repeat
+    from generative_models_amd import common
+
+    class W:
+        def add_image(self, tag, img, epoch): self.img = (tag, img, epoch)
+        def add_video(self, tag, vid, epoch, fps): self.vid = (tag, vid, epoch, fps)
+
+    w = W()
+    x = torch.arange(25 * 28 * 28, dtype=torch.float32).reshape(25, 1, 28, 28)
+    common.write_grid(w, "samples", x, 7)
+    assert w.img[0] == "samples" and w.img[2] == 7
+    assert torch.equal(w.img[1], rearrange(x, "(n1 n2) c h w -> c (n1 h) (n2 w)", n1=5, n2=5))
+    t = torch.arange(9 * 25 * 28 * 28, dtype=torch.float32).reshape(9, 25, 1, 28, 28)
+    common.write_gridvid(w, "sampling_process", t, 2)
+    ref = repeat(rearrange(t, "t (n1 n2) c h w -> t c (n1 h) (n2 w)", n1=5, n2=5)[None], "b t c h w -> b t (repeat c) h w", repeat=3)
+    assert torch.equal(w.vid[1], ref) and w.vid[3] == 3 and w.vid[0] == "sampling_process"
+    with pytest.raises(AssertionError):
+        common.write_grid(w, "samples", x[:24], 0)
