@@ -25,6 +25,7 @@ import torch.distributed as dist
 import yaml
 
 from . import common, parallel
+from . import metrics as heavy
 
 DG = common.AttrDict()     # gms/main.py:20-40
 DG.model = "vae"
@@ -125,7 +126,14 @@ def load_model_and_data(argv=None):
     else:
         raise ValueError(f"--data {G.data!r}: 'synthetic' or 'mnist'")
     print("num_vars", common.count_vars(model))
-    return model, train_ds, test_ds, None, None, G
+    # heavy eval (gms/main.py:86-91): TorchScript feature extractors; the reference's weight files are not in the checkout
+    # (.MISSING_LARGE_BLOBS), so a missing file is an error only when --eval_heavy asks for it
+    autoencoder = classifier = None
+    if G.eval_heavy:
+        autoencoder = torch.jit.load(str(G.autoencoder)).to(G.device)
+        if G.get("class_cond", 0):
+            classifier = torch.jit.load(str(G.classifier)).to(G.device)
+    return model, train_ds, test_ds, autoencoder, classifier, G
 
 
 def train(model, train_ds, test_ds, autoencoder, classifier, G):
@@ -153,6 +161,12 @@ def train(model, train_ds, test_ds, autoencoder, classifier, G):
             Path(G.logdir).mkdir(parents=True, exist_ok=True)
             model.save(Path(G.logdir), test_x, test_y)
             print("SAVED MODEL", G.logdir)
+            if G.eval_heavy:                       # gms/main.py:191-196
+                print("RUNNING HEAVY EVAL...")
+                eval_heavy_time = time.time()
+                heavy.eval_heavy(logger, model, test_ds, autoencoder, classifier, G)
+                logger["dt/eval_heavy"] = time.time() - eval_heavy_time
+                print("DONE HEAVY EVAL")
         logger = common.dump_logger(logger, writer, epoch, G)
         if epoch >= G.epochs:
             break

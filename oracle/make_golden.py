@@ -265,6 +265,31 @@ def gen_meantypes(C, S, B, T, seed, name):
     save(name, **out)
 
 
+def gen_metrics(name):
+    """compute_fid / precision_recall_f1 (gms/common.py:267-319).  gms.common itself cannot be imported here (torchvision is
+    absent), so the two function definitions are taken out of the reference file with `ast` and executed as they stand."""
+    import ast
+    from scipy.linalg import fractional_matrix_power
+    src = open(os.path.join(REF, "gms", "common.py")).read()
+    ns = {"np": np, "torch": torch, "fractional_matrix_power": fractional_matrix_power}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("compute_fid", "precision_recall_f1"):
+            exec(compile(ast.Module([node], []), "gms/common.py", "exec"), ns)
+    g = torch.Generator().manual_seed(60)
+    real = torch.randn((120, 16), generator=g)
+    gen_near = real[torch.randperm(120, generator=g)] * 0.9 + 0.1 * torch.randn((120, 16), generator=g)
+    gen_far = torch.randn((90, 16), generator=g) * 0.5 + 1.0
+    gen_mid = torch.randn((100, 16), generator=g) * 0.8 + 0.35
+    out = {"real": real, "gen_near": gen_near, "gen_far": gen_far, "gen_mid": gen_mid}
+    for tag, gen in (("near", gen_near), ("far", gen_far), ("mid", gen_mid)):
+        out[f"fid_{tag}"] = np.float64(ns["compute_fid"](gen.numpy(), real.numpy()))
+        for k in (1, 3):
+            prf = ns["precision_recall_f1"](real=real, gen=gen, k=k)
+            out[f"prf_{tag}_k{k}"] = torch.stack([prf["precision"], prf["recall"], prf["f1"]])
+    out["fid_bad"] = np.float64(ns["compute_fid"](real.numpy()[0], real.numpy()))      # wrong rank -> NaN
+    save(name, **out)
+
+
 def main():
     torch.set_num_threads(4)
     gen_schedule()
@@ -284,6 +309,7 @@ def main():
     gen_distill(64, 8, 3, 8, 40, "distill_c64_s8.npz")
     gen_distill(128, 8, 3, 8, 41, "distill_c128_s8.npz")
     gen_meantypes(128, 8, 3, 4, 50, "meantype_c128_s8.npz")
+    gen_metrics("metrics.npz")
 
 
 if __name__ == "__main__":
