@@ -256,6 +256,116 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Register-resident variants (bf16): one workgroup = one (sample, 32-channel slab); every thread loads ALL its pixels'
+// 16-byte vectors up front (ITER independent loads in flight per thread), the statistics are reduced over the workgroup,
+// and the apply sweep runs from registers: the tensor is read from HBM exactly once (the streaming kernels read it twice;
+// PMC shows their second sweep is NOT served by L2).  Thread = (vec = tid & 3, plane = tid >> 2); pixel p = plane + i*planes.
+// ------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+__device__ __forceinline__ void unpack8(const u32x4_t r, float (&v)[8]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[2 * k] = __builtin_bit_cast(float, r[k] << 16);
+        v[2 * k + 1] = __builtin_bit_cast(float, r[k] & 0xFFFF0000u);
+    }
+}
+
+// sum over the lanes of a wave that share (lane & (NVEC-1)); every such lane ends with the total
+template <int NVEC>
+__device__ __forceinline__ float vec_lane_sum(float v) {
+#pragma unroll
+    for (int off = NVEC; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int ITER, int NVEC>
+__global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ mean, float* __restrict__ rstd, int HW, int C,
+                                                             int G, float eps, int B, int planes, float drop_p,
+                                                             uint64_t drop_seed, uint64_t drop_off) {
+    __shared__ float red[8][NVEC][4];       // [wave][vec][s0, q0, s1, q1]
+    __shared__ float smean[16], srstd[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    constexpr int CS = NVEC * 8, LOGV = NVEC == 8 ? 3 : 2;
+    const int vec = tid & (NVEC - 1), pl = tid >> LOGV;
+    int b, slab;
+    slab_of_block(blockIdx.x, C / CS, B, b, slab);
+    const int cpg = C / G, c0 = slab * CS, g0 = c0 / cpg, gps = CS / cpg;
+    const size_t base = (size_t)b * HW * C + c0 + vec * 8;
+    u32x4_t raw[ITER];
+    bool ok[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int p = pl + i * planes;
+        ok[i] = pl < planes && p < HW;
+        raw[i] = ok[i] ? *reinterpret_cast<const u32x4_t*>(x + base + (size_t)p * C) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        float v[8];
+        unpack8(raw[i], v);
+        s0 += (v[0] + v[1]) + (v[2] + v[3]);
+        q0 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        s1 += (v[4] + v[5]) + (v[6] + v[7]);
+        q1 += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
+    }
+    // keep the pixels PACKED across the reduction (the apply sweep unpacks again): otherwise the compiler carries all 8*ITER
+    // floats through the barrier and the register count halves the occupancy
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) asm volatile("" : "+v"(raw[i]));
+    s0 = vec_lane_sum<NVEC>(s0); q0 = vec_lane_sum<NVEC>(q0); s1 = vec_lane_sum<NVEC>(s1); q1 = vec_lane_sum<NVEC>(q1);
+    if (lane < NVEC) { red[wave][lane][0] = s0; red[wave][lane][1] = q0; red[wave][lane][2] = s1; red[wave][lane][3] = q1; }
+    __syncthreads();
+    if (tid < gps) {
+        const int hv_per_g = cpg >> 2;          // 4-channel half-vectors per group
+        float s = 0.f, q = 0.f;
+        for (int j = 0; j < hv_per_g; ++j) {
+            const int hv = tid * hv_per_g + j, vv = hv >> 1, hf = hv & 1;
+            for (int w = 0; w < nwaves; ++w) { s += red[w][vv][hf * 2]; q += red[w][vv][hf * 2 + 1]; }
+        }
+        const float n = (float)cpg * (float)HW;
+        const float m = s / n;
+        const float var = fmaxf(q / n - m * m, 0.f);
+        const float r = 1.0f / sqrtf(var + eps);
+        smean[tid] = m; srstd[tid] = r;
+        mean[b * G + g0 + tid] = m; rstd[b * G + g0 + tid] = r;
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int cl = vec * 8 + i, g = cl / cpg, c = c0 + cl;
+        sc[i] = srstd[g] * gamma[c];
+        sh[i] = beta[c] - smean[g] * sc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        if (!ok[i]) continue;
+        const int p = pl + i * planes;
+        float v[8];
+        unpack8(raw[i], v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = siluf_(fmaf(v[k], sc[k], sh[k]));
+        if (drop_p > 0.f) drop8(v, base + (size_t)p * C, drop_p, drop_seed, drop_off);
+        store8(y + base + (size_t)p * C, v);
+    }
+}
+
+// (A backward kernel with the same residency — x and dy packed in registers, both sweeps from them — was built and measured
+// 30-60 % SLOWER than the streaming backward: it needs 188 VGPRs at 8 pixels per thread (one workgroup per CU) or spills at
+// 128, and it recomputes the sigmoid in both sweeps.  Removed; the streaming kernel with 32-channel slabs stays.)
+
+// pixels per thread of the register-resident kernels: the smallest of 1, 2, 4, 8 that fits the slab into <= 512 threads
+int gn_reg_iter(int HW, int nvec) {
+    for (int it = 1; it <= 16; it <<= 1)
+        if (((HW + it - 1) / it) * nvec <= 512) return it;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // LDS-resident variants (bf16): one workgroup = one sample x one channel slice, whose data is pulled into LDS ONCE by
 // LDS-DMA (`buffer_load_dwordx4 ... lds`), so statistics and apply read HBM a single time:
 //   forward  (sample, 64 channels):  1 read + 1 write of the tensor   (3-pass kernel: 2 reads + 1 write)
@@ -595,6 +705,28 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
         else
             gn_silu_fwd_lds_kernel<1024><<<grid, kThreads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta,
                                                                                  mean, rstd, HW, C, groups, eps, (unsigned)nbytes);
+    } else if (dtype == GMK_BF16 && !stats_part && (gn_mode == 0 || gn_mode == 5 || gn_mode == 6) && C % 64 == 0 &&
+               32 % (C / groups) == 0 && gn_reg_iter(HW, 8) > 0) {
+        const int nvec = gn_mode == 5 ? 4 : 8;                 // 32- or 64-channel slabs (64 = whole 128-B lines)
+        const int it = gn_reg_iter(HW, nvec), planes = (HW + it - 1) / it, threads = (planes * nvec + 63) / 64 * 64;
+        const int nblk = B * (C / (nvec * 8));
+#define GMK_GN_FWD_REG(IT, NV)                                                                                                   \
+    gn_silu_fwd_reg_kernel<IT, NV><<<nblk, threads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, \
+                                                                             HW, C, groups, eps, B, planes, drop_p, drop_seed,     \
+                                                                             drop_offset)
+        if (nvec == 4) {
+            if (it == 1) GMK_GN_FWD_REG(1, 4);
+            else if (it == 2) GMK_GN_FWD_REG(2, 4);
+            else if (it == 4) GMK_GN_FWD_REG(4, 4);
+            else GMK_GN_FWD_REG(8, 4);
+        } else {
+            if (it == 1) GMK_GN_FWD_REG(1, 8);
+            else if (it == 2) GMK_GN_FWD_REG(2, 8);
+            else if (it == 4) GMK_GN_FWD_REG(4, 8);
+            else if (it == 8) GMK_GN_FWD_REG(8, 8);
+            else GMK_GN_FWD_REG(16, 8);
+        }
+#undef GMK_GN_FWD_REG
     } else if (dtype == GMK_BF16) {
         const int CS = stats_part ? C : gn_slab_channels(gn_mode, C, groups, HW, 2, false);
         gn_silu_fwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(

@@ -130,9 +130,15 @@ def load_model_and_data(argv=None):
     # (.MISSING_LARGE_BLOBS), so a missing file is an error only when --eval_heavy asks for it
     autoencoder = classifier = None
     if G.eval_heavy:
-        autoencoder = torch.jit.load(str(G.autoencoder)).to(G.device)
-        if G.get("class_cond", 0):
-            classifier = torch.jit.load(str(G.classifier)).to(G.device)
+        need = [Path(G.autoencoder)] + ([Path(G.classifier)] if G.get("class_cond", 0) else [])
+        missing = [str(f) for f in need if not f.exists()]
+        if missing:       # DiffusionModel.DG.eval_heavy defaults to 1 as in the reference; without the files it cannot run
+            print(f"eval_heavy disabled: {', '.join(missing)} not found (the reference's weight files are not in its checkout)")
+            G.eval_heavy = 0
+        else:
+            autoencoder = torch.jit.load(str(G.autoencoder)).to(G.device)
+            if G.get("class_cond", 0):
+                classifier = torch.jit.load(str(G.classifier)).to(G.device)
     return model, train_ds, test_ds, autoencoder, classifier, G
 
 
