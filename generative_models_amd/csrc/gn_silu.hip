@@ -50,7 +50,8 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
                                                               int HW, int C, int G, float eps,
                                                               const float* __restrict__ part, int TP, int ntiles,
                                                               int CS, int B, float drop_p, uint64_t drop_seed,
-                                                              uint64_t drop_off) {
+                                                              uint64_t drop_off, const float* __restrict__ xadd,
+                                                              int xadd_stride) {
     __shared__ float red[kThreads * 4];
     __shared__ float smean[64], srstd[64];
     const int tid = threadIdx.x;
@@ -61,6 +62,9 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
     const int cpg = C / G, c0 = slab * CS, g0 = c0 / cpg, gps = CS / cpg;
     const T* xb = x + (size_t)b * HW * C + c0 + vec * 8;
     T* yb = y + (size_t)b * HW * C + c0 + vec * 8;
+    float ea[8];           // per-(sample, channel) addend applied to x on load (conv bias + embedding broadcast of the producer)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ea[i] = xadd ? xadd[(size_t)b * xadd_stride + c0 + vec * 8 + i] : 0.f;
 
     if (part) {
         // statistics from the producer's partial sums: [tile][8 pixel groups][2 sample slots][C/4 units][sum, sumsq],
@@ -92,6 +96,8 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
     for (int p = pl; p < HW; p += planes) {
         float v[8];
         load8(xb + (size_t)p * C, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += ea[i];
         s0 += (v[0] + v[1]) + (v[2] + v[3]);
         q0 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         s1 += (v[4] + v[5]) + (v[6] + v[7]);
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
         float v[8];
         load8(xb + (size_t)p * C, v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = siluf_(fmaf(v[i], sc[i], sh[i]));
+        for (int i = 0; i < 8; ++i) v[i] = siluf_(fmaf(v[i] + ea[i], sc[i], sh[i]));
         if (drop_p > 0.f) drop8(v, ((size_t)b * HW + p) * C + c0 + vec * 8, drop_p, drop_seed, drop_off);
         store8(yb + (size_t)p * C, v);
     }
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd, const T* __restrict__ dadd1,
     const T* __restrict__ dadd2, T* __restrict__ dx, float* __restrict__ dgp, float* __restrict__ dbp,
     float* __restrict__ dxsum, int dxsum_stride, int HW, int C, int G, int CS, int B, float drop_p, uint64_t drop_seed,
-    uint64_t drop_off) {
+    uint64_t drop_off, const float* __restrict__ xadd, int xadd_stride) {
     __shared__ float red[kThreads * 16];
     __shared__ float chg[256], chb[256];
     __shared__ float sA[64], sB[64];
@@ -161,7 +167,9 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
         const int cl = vec * 8 + i, c = c0 + cl;
         grp[i] = cl / cpg;
         gam[i] = gamma[c]; bet[i] = beta[c];
-        mu[i] = mean[b * G + g0 + grp[i]]; rs[i] = rstd[b * G + g0 + grp[i]];
+        // x enters as x + xadd[b][c]: fold the addend into the mean that is subtracted
+        mu[i] = mean[b * G + g0 + grp[i]] - (xadd ? xadd[(size_t)b * xadd_stride + c] : 0.f);
+        rs[i] = rstd[b * G + g0 + grp[i]];
     }
     float ag[8], ab[8];
 #pragma unroll
@@ -284,7 +292,8 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ mean, float* __restrict__ rstd, int HW, int C,
                                                              int G, float eps, int B, int planes, float drop_p,
-                                                             uint64_t drop_seed, uint64_t drop_off) {
+                                                             uint64_t drop_seed, uint64_t drop_off, const float* __restrict__ xadd,
+                                                             int xadd_stride) {
     __shared__ float red[8][NVEC][4];       // [wave][vec][s0, q0, s1, q1]
     __shared__ float smean[16], srstd[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -302,11 +311,16 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
         ok[i] = pl < planes && p < HW;
         raw[i] = ok[i] ? *reinterpret_cast<const u32x4_t*>(x + base + (size_t)p * C) : u32x4_t{0u, 0u, 0u, 0u};
     }
+    float ea[8];           // per-(sample, channel) addend applied to x on load (conv bias + embedding broadcast of the producer)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ea[k] = xadd ? xadd[(size_t)b * xadd_stride + c0 + vec * 8 + k] : 0.f;
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
         float v[8];
         unpack8(raw[i], v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = ok[i] ? v[k] + ea[k] : 0.f;
         s0 += (v[0] + v[1]) + (v[2] + v[3]);
         q0 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         s1 += (v[4] + v[5]) + (v[6] + v[7]);
@@ -339,7 +353,7 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
     for (int i = 0; i < 8; ++i) {
         const int cl = vec * 8 + i, g = cl / cpg, c = c0 + cl;
         sc[i] = srstd[g] * gamma[c];
-        sh[i] = beta[c] - smean[g] * sc[i];
+        sh[i] = beta[c] - (smean[g] - ea[i]) * sc[i];          // (x + ea - mean) * sc + beta
     }
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
@@ -683,7 +697,10 @@ int gn_slab_channels(int mode, int C, int G, int HW, int elem_bytes, bool backwa
 
 extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                                int B, int HW, int C, int groups, float eps, const float* stats_part, int tile_pixels,
-                               int ntiles, float drop_p, uint64_t drop_seed, uint64_t drop_offset, int dtype, void* stream) {
+                               int ntiles, float drop_p, uint64_t drop_seed, uint64_t drop_offset, const float* xadd,
+                               int xadd_stride, int dtype, void* stream) {
+    GMK_REQUIRE(!xadd || xadd_stride >= C, "gmk_gn_silu_fwd: xadd_stride %d < C %d", xadd_stride, C);
+    if (xadd) stats_part = nullptr;     // the producer's statistics are those of x without the addend
     GMK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gmk_gn_silu_fwd: dropout probability %g outside [0, 1)", (double)drop_p);
     GMK_REQUIRE(!stats_part || (tile_pixels >= 32 && ntiles > 0 && HW >= 32 && C % 4 == 0),
                 "gmk_gn_silu_fwd: bad statistics geometry");
@@ -694,7 +711,7 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
     // 0-50 % SLOWER than the streaming kernels at 28x28 / 14x14 / 7x7 — one or few resident workgroups per CU serialise their
     // load / compute / store phases, while the streaming kernels' second sweep is served from L2 / Infinity Cache)
     const int gn_mode = gmk_kernel_choice(2, "GMK_GN_KERNEL");
-    const int lds_ok = gn_mode == 2 && drop_p == 0.f;
+    const int lds_ok = gn_mode == 2 && drop_p == 0.f && !xadd;
     const int lds_max_hw = 1024;
     const int64_t nbytes = (int64_t)B * HW * C * 2;
     if (dtype == GMK_BF16 && lds_ok && !stats_part && C % 64 == 0 && HW <= lds_max_hw && nbytes < 0xFFFF0000ll) {
@@ -713,7 +730,7 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
 #define GMK_GN_FWD_REG(IT, NV)                                                                                                   \
     gn_silu_fwd_reg_kernel<IT, NV><<<nblk, threads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, \
                                                                              HW, C, groups, eps, B, planes, drop_p, drop_seed,     \
-                                                                             drop_offset)
+                                                                             drop_offset, xadd, xadd_stride)
         if (nvec == 4) {
             if (it == 1) GMK_GN_FWD_REG(1, 4);
             else if (it == 2) GMK_GN_FWD_REG(2, 4);
@@ -731,12 +748,12 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
         const int CS = stats_part ? C : gn_slab_channels(gn_mode, C, groups, HW, 2, false);
         gn_silu_fwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, HW, C, groups, eps, stats_part, tile_pixels, ntiles, CS, B, drop_p,
-            drop_seed, drop_offset);
+            drop_seed, drop_offset, xadd, xadd_stride);
     } else if (dtype == GMK_F32) {
         const int CS = stats_part ? C : gn_slab_channels(gn_mode, C, groups, HW, 4, false);
         gn_silu_fwd_kernel<float><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const float*)x, (float*)y, gamma, beta, mean, rstd, HW, C, groups, eps, stats_part, tile_pixels, ntiles, CS, B, drop_p,
-            drop_seed, drop_offset);
+            drop_seed, drop_offset, xadd, xadd_stride);
     }
     else
         GMK_REQUIRE(false, "gmk_gn_silu_fwd: bad dtype %d", dtype);
@@ -746,7 +763,9 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
 extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                                const float* rstd, const void* dadd1, const void* dadd2, void* dx, float* dgamma_part,
                                float* dbeta_part, float* dxsum, int dxsum_stride, int B, int HW, int C, int groups,
-                               float drop_p, uint64_t drop_seed, uint64_t drop_offset, int dtype, void* stream) {
+                               float drop_p, uint64_t drop_seed, uint64_t drop_offset, const float* xadd, int xadd_stride,
+                               int dtype, void* stream) {
+    GMK_REQUIRE(!xadd || xadd_stride >= C, "gmk_gn_silu_bwd: xadd_stride %d < C %d", xadd_stride, C);
     GMK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gmk_gn_silu_bwd: dropout probability %g outside [0, 1)", (double)drop_p);
     GMK_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma_part && dbeta_part,
                 "gmk_gn_silu_bwd: null pointer");
@@ -757,7 +776,7 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
     // 0-50 % SLOWER than the streaming kernels at 28x28 / 14x14 / 7x7 — one or few resident workgroups per CU serialise their
     // load / compute / store phases, while the streaming kernels' second sweep is served from L2 / Infinity Cache)
     const int gn_mode = gmk_kernel_choice(2, "GMK_GN_KERNEL");
-    const int lds_ok = gn_mode == 2 && drop_p == 0.f;
+    const int lds_ok = gn_mode == 2 && drop_p == 0.f && !xadd;
     const int lds_max_hw = 1024;
     const int64_t nbytes = (int64_t)B * HW * C * 2;
     if (dtype == GMK_BF16 && lds_ok && C % 32 == 0 && HW <= lds_max_hw && nbytes < 0xFFFF0000ll) {
@@ -774,12 +793,14 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
         const int CS = gn_slab_channels(gn_mode, C, groups, HW, 2, true);
         gn_silu_bwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2,
-            (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, CS, B, drop_p, drop_seed, drop_offset);
+            (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, CS, B, drop_p, drop_seed, drop_offset, xadd,
+            xadd_stride);
     } else if (dtype == GMK_F32) {
         const int CS = gn_slab_channels(gn_mode, C, groups, HW, 4, true);
         gn_silu_bwd_kernel<float><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const float*)dy, (const float*)x, gamma, beta, mean, rstd, (const float*)dadd1, (const float*)dadd2,
-            (float*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, CS, B, drop_p, drop_seed, drop_offset);
+            (float*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, CS, B, drop_p, drop_seed, drop_offset, xadd,
+            xadd_stride);
     }
     else
         GMK_REQUIRE(false, "gmk_gn_silu_bwd: bad dtype %d", dtype);

@@ -146,6 +146,7 @@ class SimpleUnet(nn.Module):
             self._pv[n] = p.data
             self._gv[n] = p.grad
         self._packs = None
+        self._conv1_bias_idx = None
         self._side = None          # side stream of the weight gradients (backward_hip)
         self._packs_stale = True
         self._freqs = {}
@@ -248,9 +249,17 @@ class SimpleUnet(nn.Module):
         wcat = self.flat_params[o0:o0 + 12 * C * 2 * C].view(12 * C, 2 * C)
         b0 = self._offsets[f"{RES_BLOCKS[0]}.emb_layers.1.bias"]
         bcat = self.flat_params[b0:b0 + 12 * C]
-        emb_all = ops.gemm(emb, wcat.t(), bias=bcat, silu_a=True)
+        # conv1's bias rides with the embedding: h = conv1(a) + bias + emb_out[..., None, None] (simple_unet.py:183) is a
+        # per-(sample, channel) addend, applied by the GroupNorm that consumes h (gmk_gn_silu_fwd xadd) instead of by the
+        # MFMA kernel's epilogue, where its loads cost 25 % of a tile
+        if self._conv1_bias_idx is None or self._conv1_bias_idx.device != dev:
+            idx = [torch.arange(self._offsets[f"{b}.in_layers.2.bias"], self._offsets[f"{b}.in_layers.2.bias"] + C) for b in RES_BLOCKS]
+            self._conv1_bias_idx = torch.cat(idx).to(dev)
+        bias_all = bcat + self.flat_params[self._conv1_bias_idx]
+        emb_all = ops.gemm(emb, wcat.t(), bias=bias_all, silu_a=True)
         if ctx is not None:
             ctx["emb"] = emb
+            ctx["emb_all"] = emb_all
         return emb_all
 
     def _embed_bwd(self, ctx, demb_all):
@@ -283,13 +292,14 @@ class SimpleUnet(nn.Module):
             y, mean, rstd = ops.gn_silu_fwd(s, g, b, gpc)
             a.append(y); stats1.append((mean, rstd))
         wf1, _ = self._packs[f"{name}.in_layers.2"]
-        h = ops.conv_igemm(a, wf1, C, 3, ops.NORMAL, (H, W), bias=P[f"{name}.in_layers.2.bias"],
-                           emb=emb_all[:, blk * C:(blk + 1) * C], gn_stats=True)
+        h = ops.conv_igemm(a, wf1, C, 3, ops.NORMAL, (H, W))      # bias + embedding enter through `xadd` below
+        eadd = emb_all[:, blk * C:(blk + 1) * C]
         drop = None
         if self.dropout > 0.0 and self.training:              # mask = Philox uniform >= p, regenerated by the backward kernel
             drop = (self.dropout, self.drop_seed, self._drop_counter)
             self._drop_counter += (h.numel() + 3) // 4
-        a2, mean2, rstd2 = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], 32, dropout=drop)
+        a2, mean2, rstd2 = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], 32, dropout=drop,
+                                           xadd=eadd)
         if len(srcs) == 2:
             wfs, _ = self._packs[f"{name}.skip_connection"]
             res = ops.conv_igemm(srcs, wfs, C, 1, ops.NORMAL, (H, W), bias=P[f"{name}.skip_connection.bias"])
@@ -336,7 +346,8 @@ class SimpleUnet(nn.Module):
         _, wd2 = self._packs[f"{name}.out_layers.3"]
         da2 = ops.conv_igemm([dout], wd2, C, 3, ops.NORMAL, (H, W))
         dh, dgp, dbp = ops.gn_silu_bwd(da2, h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], mean2,
-                                       rstd2, dxsum=demb_all[:, blk * C:(blk + 1) * C], dropout=ctx.pop(name + ".dropout", None))
+                                       rstd2, dxsum=demb_all[:, blk * C:(blk + 1) * C], dropout=ctx.pop(name + ".dropout", None),
+                                       xadd=ctx["emb_all"][:, blk * C:(blk + 1) * C])
         ops.colsum(dgp, G[f"{name}.out_layers.0.weight"], defer=True); ops.colsum(dbp, G[f"{name}.out_layers.0.bias"], defer=True)
         # conv1 (in_layers.2): bias gradient = column sum of the embedding gradient slice (both are sum_hw dh)
         ops.colsum(demb_all[:, blk * C:(blk + 1) * C], G[f"{name}.in_layers.2.bias"], defer=True)

@@ -98,7 +98,15 @@ GN_STATS = False
 WGRAD_STREAM = os.environ.get("GMK_WGRAD_STREAM", "1") != "0"    # weight gradients on a side stream beside the data-gradient chain (simple_unet._wgrad)
 
 
-def gn_silu_fwd(x, gamma, beta, groups, eps=1e-5, dropout=None):
+def _xadd_stride(xadd, B, C):
+    """xadd: optional fp32 [B, C] view (unit column stride, any row stride) added to x per (sample, channel) on load."""
+    if xadd is None:
+        return 0
+    assert xadd.dtype == torch.float32 and xadd.shape == (B, C) and xadd.stride(1) == 1 and xadd.is_cuda
+    return xadd.stride(0)
+
+
+def gn_silu_fwd(x, gamma, beta, groups, eps=1e-5, dropout=None, xadd=None):
     """x NHWC [B,H,W,C] -> (y, mean[B,G], rstd[B,G]).  If the convolution that produced x attached its partial
     GroupNorm statistics (x._gn_stats), the statistics pass over x is skipped.  dropout = (p, seed, offset): nn.Dropout(p)
     behind the SiLU with the mask `rng_uniform(x.shape, seed, offset) >= p` (pass the same triple to gn_silu_bwd)."""
@@ -111,12 +119,13 @@ def gn_silu_fwd(x, gamma, beta, groups, eps=1e-5, dropout=None):
     st = getattr(x, "_gn_stats", None)
     part, tp, nt = st if st is not None else (None, 0, 0)
     dp, dseed, doff = dropout if dropout is not None else (0.0, 0, 0)
+    xs = _xadd_stride(xadd, B, C)
     check(lib.gmk_gn_silu_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), B, H * W, C, groups, eps, _p(part), tp, nt,
-                              float(dp), int(dseed), int(doff), _DT[x.dtype], _s()), "gn_silu_fwd")
+                              float(dp), int(dseed), int(doff), _p(xadd), xs, _DT[x.dtype], _s()), "gn_silu_fwd")
     return y, mean, rstd
 
 
-def gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=None, dadd2=None, dxsum=None, dropout=None):
+def gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=None, dadd2=None, dxsum=None, dropout=None, xadd=None):
     """-> (dx, dgamma_part[B,C], dbeta_part[B,C]); dxsum (optional fp32 [B, >=C] view with row stride) is filled."""
     _chk(x, name="x"); _chk(dy, x.dtype, "dy")
     assert dy.shape == x.shape
@@ -133,9 +142,10 @@ def gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=None, dadd2=None, dxsum=No
         assert dxsum.dtype == torch.float32 and dxsum.shape == (B, C) and dxsum.stride(1) == 1
         stride = dxsum.stride(0)
     dp, dseed, doff = dropout if dropout is not None else (0.0, 0, 0)
+    xs = _xadd_stride(xadd, B, C)
     check(lib.gmk_gn_silu_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dadd1), _p(dadd2), _p(dx),
                               _p(dgp), _p(dbp), _p(dxsum), stride, B, H * W, C, G, float(dp), int(dseed), int(doff),
-                              _DT[x.dtype], _s()), "gn_silu_bwd")
+                              _p(xadd), xs, _DT[x.dtype], _s()), "gn_silu_bwd")
     return dx, dgp, dbp
 
 

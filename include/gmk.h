@@ -57,8 +57,12 @@ int gmk_pack_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int cout, i
  * two calls of 16 groups each, simple_unet.py:150,161); mean/rstd: fp32 [B][groups] (written). */
 int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                     int B, int HW, int C, int groups, float eps, const float* stats_part, int tile_pixels, int ntiles,
-                    float drop_p, uint64_t drop_seed, uint64_t drop_offset, int dtype, void* stream);
-/* stats_part (optional): partial sums emitted by the producing convolution (see gmk_conv_igemm gn_stats); when given,
+                    float drop_p, uint64_t drop_seed, uint64_t drop_offset, const float* xadd, int xadd_stride, int dtype,
+                    void* stream);
+/* xadd (optional, fp32 [B][xadd_stride]): x enters as x[b][p][c] + xadd[b][c] — the producing convolution's bias and the
+ * embedding broadcast-add of simple_unet.py:183 (`h + emb_out[..., None, None]`) are applied here, in the HBM-bound kernel,
+ * instead of in the MFMA kernel's epilogue; pass the same pointer to gmk_gn_silu_bwd.
+ * stats_part (optional): partial sums emitted by the producing convolution (see gmk_conv_igemm gn_stats); when given,
  * the statistics pass over x is skipped (x is read once).
  * drop_p > 0: nn.Dropout(p) behind the SiLU (simple_unet.py:171, training mode): element e of y (NHWC order) is kept and
  * scaled by 1/(1-p) iff gmk_rng_uniform(seed = drop_seed, offset = drop_offset)[e] >= drop_p, else zeroed; pass the same
@@ -69,7 +73,8 @@ int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const float* bet
 int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                     const float* rstd, const void* dadd1, const void* dadd2, void* dx, float* dgamma_part,
                     float* dbeta_part, float* dxsum, int dxsum_stride, int B, int HW, int C, int groups,
-                    float drop_p, uint64_t drop_seed, uint64_t drop_offset, int dtype, void* stream);
+                    float drop_p, uint64_t drop_seed, uint64_t drop_offset, const float* xadd, int xadd_stride, int dtype,
+                    void* stream);
 /* out[b][c] = sum over pixels of x[b][:, c]  (NHWC, fp32 result [B][out_stride]) */
 int gmk_chansum(const void* x, float* out, int out_stride, int B, int HW, int C, int dtype, void* stream);
 /* out[c] (+)= sum_r part[r*stride + c], r < R, c < C  (fp32) */

@@ -20,9 +20,13 @@ for nsrc in (1, 2):
     nt = (B * S + r - 1) // r
     part = torch.zeros(nt * 8 * 2 * (C // 4) * 2, device="cuda", dtype=torch.float32)
     out = torch.empty((B, S, S, C), device="cuda", dtype=T)
+    EPI = os.environ.get("EPI", "plain")
+    bias = torch.randn(C, device="cuda") if EPI != "plain" else None
+    emb = torch.randn(B, C, device="cuda") if "emb" in EPI else None
+    res = torch.randn(B, S, S, C, device="cuda").to(T) if "res" in EPI else None
     ops.check(lib.gmk_conv_igemm(ops._p(srcs[0]), ops._p(srcs[1]) if nsrc > 1 else None, C, C if nsrc > 1 else 0, B, S, S, S, S, 3,
-                                 ops.NORMAL, ops._p(wf), C, 0, C, None, None, 0, None, ops._p(out), C, ops._p(part), part.numel() * 4,
-                                 ops._DT[T], ops._s()), "conv")
+                                 ops.NORMAL, ops._p(wf), C, 0, C, ops._p(bias), ops._p(emb), C if emb is not None else 0, ops._p(res),
+                                 ops._p(out), C, ops._p(part), part.numel() * 4, ops._DT[T], ops._s()), "conv")
     torch.cuda.synchronize()
     lib.gmk_set_dev_variant(0)
     st = part.view(torch.int64)[: 256 * 16 * 4].view(256, 16, 4).cpu().double()
@@ -34,7 +38,7 @@ for nsrc in (1, 2):
     gap = (st[:, 1:, 0] - st[:, :-1, 3])
     whole = (st[:, 1:, 0] - st[:, :-1, 0])
     med = lambda t: float(t.median())
-    print(f"variant {VAR & 255} cin={cin}: per tile (cycles, median over 256 WGs x {ntile} tiles): phase0 {med(first):.0f}  other phases {med(rest):.0f}  "
+    print(f"{os.environ.get('EPI', 'plain'):9s} variant {VAR & 255} cin={cin}: per tile (cycles, median over 256 WGs x {ntile} tiles): phase0 {med(first):.0f}  other phases {med(rest):.0f}  "
           f"epilogue {med(epi):.0f}  gap {med(gap):.0f}  tile-to-tile {med(whole):.0f}")
     print("  tile 0 of each WG: phase0 %.0f (prologue excluded), kernel span %.0f cycles" %
           (med(first[:, 0]), float(st[:, :, 3].max() - st[:, 0, 0].min())))
