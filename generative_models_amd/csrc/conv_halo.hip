@@ -682,25 +682,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
     };
 
     auto epilogue = [&](int tile) {
-        u32x2_t resv[4][2][4];
-        if (p.residual) {
+        // every global load of the epilogue is issued up front, in as few and as wide instructions as possible: the bias once
+        // per tile (not once per accumulator), the residual as 16-B loads at the addresses the stores use (the lane layout after
+        // v_permlane32_swap) and swapped back into the accumulator layout — half the instructions of 8-B loads in that layout
+        float bz[2][16];
+        if (p.bias) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ml = cm * 128 + i * 32 + r;
-                const int m = tile * p.TP + ml;
-                const bool live = ml < p.TP && m < p.M;
-                const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int cb = nblk + cw * 64 + j * 32;
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    float t[4];
+                    load4(p.bias + nblk + cw * 64 + j * 32 + 8 * q4 + 4 * h, t);
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const unsigned off = live ? row_b + (unsigned)(cb + 8 * q4 + 4 * h) * ES : kBadOff;
-                        resv[i][j][q4] = __builtin_amdgcn_raw_buffer_load_b64(rsr, off, 0, 0);
-                    }
+                    for (int e = 0; e < 4; ++e) bz[j][4 * q4 + e] = t[e];
+                }
+        }
+        u32x4 rres[2][2][2];            // residual of pixel block i (set i & 1), loaded one block ahead
+        auto load_res = [&](int i) {
+            const int ml = cm * 128 + i * 32 + r;
+            const int m = tile * p.TP + ml;
+            const bool live = ml < p.TP && m < p.M;
+            const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cb = nblk + cw * 64 + j * 32;
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const unsigned off = live ? row_b + (unsigned)(cb + 8 * (2 * qq + h)) * ES : kBadOff;
+                    rres[i & 1][j][qq] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, off, 0, 0));
                 }
             }
-        }
+        };
+        if (p.residual) load_res(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ml = cm * 128 + i * 32 + r;
@@ -709,6 +722,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
             const float* embp = nullptr;
             if (p.emb) embp = p.emb + (int64_t)((live ? m : 0) / (H * W)) * p.emb_stride;
+            if (p.residual && i < 3) load_res(i + 1);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int cb = nblk + cw * 64 + j * 32;
@@ -717,12 +731,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 for (int e = 0; e < 16; ++e) { v[e] = acc[j][i][e]; acc[j][i][e] = 0.f; }
                 if (p.bias) {
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        float t[4];
-                        load4(p.bias + cb + 8 * q4 + 4 * h, t);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[4 * q4 + e] += t[e];
-                    }
+                    for (int e = 0; e < 16; ++e) v[e] += bz[j][e];
                 }
                 if (p.emb) {
 #pragma unroll
@@ -735,10 +744,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 }
                 if (p.residual) {
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const bf16x4 rb = __builtin_bit_cast(bf16x4, resv[i][j][q4]);
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const u32x4 R = rres[i & 1][j][qq];
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(R[0], R[2], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(R[1], R[3], false, false);
+                        const bf16x4 ra = __builtin_bit_cast(bf16x4, (u32x2_t){s0[0], s1[0]});      // block q4 = 2qq
+                        const bf16x4 rb = __builtin_bit_cast(bf16x4, (u32x2_t){s0[1], s1[1]});      // block q4 = 2qq + 1
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[4 * q4 + e] += (float)rb[e];
+                        for (int e = 0; e < 4; ++e) {
+                            v[8 * qq + e] += (float)ra[e];
+                            v[8 * qq + 4 + e] += (float)rb[e];
+                        }
                     }
                 }
                 unsigned pk[4][2];
