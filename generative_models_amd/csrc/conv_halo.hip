@@ -521,6 +521,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(dst + u * 1024), 16, w_off[u] + wk, 0, 0, 0);
         };
 
+        const __amdgpu_buffer_rsrc_t rsr =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
+        unsigned pf0 = 0, pf1 = 0;
         int sq = 2, hbuf = 0;
         int tile = blockIdx.x;
 #pragma unroll
@@ -538,15 +541,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     // at barrier q the weight tile of step q+1 (the first 4 ops of step q-1) must have landed — the consumers read its
                     // first fragments before barrier q+1; only the 2 halo pieces issued behind it may still fly.  Tap 0 also needs
                     // the phase's whole halo (all older).
+                    const bool warmed = last_ph && p.residual != nullptr && p.variant != 5;     // tap 7 carried 2 extra (L2 warm-up) loads
                     if (kPrefetchW) {
-                        if ((p.variant >= 20 && p.variant <= 22) || tap == 0 || tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if ((p.variant >= 20 && p.variant <= 22) || tap == 0 || (tap == 8 && !warmed)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                     } else {      // only the weight tile of THIS step (issued two steps ago) has to be there
                         if (p.variant >= 20 && p.variant <= 22) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         else if (tap == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                        else if (tap == 1 || tap == 8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                        else if (tap == 1 || (tap == 8 && !warmed)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     }
+                    if (tap == 0) asm volatile("" :: "v"(pf0), "v"(pf1));         // the warm-up loads' registers stay reserved until here
                     __builtin_amdgcn_s_barrier();
                     const bool no_w = p.variant == 20 || p.variant == 22, no_f = p.variant == 21 || p.variant == 22;   // timing ablations
                     if (!no_w) {
@@ -556,6 +561,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     if (tap < 7 && !no_f) {
                         if (last_ph) resolve_piece(tile + gridDim.x, tap);      // the next fills belong to the next tile (or are zeros)
                         issue_fill(hbuf ^ 1, ph_next, tap);
+                    }
+                    if (tap == 7 && warmed) {
+                        // pull the residual tile (TP pixels x 256 B, one dword per 128-B line) into L2 two K-steps before the
+                        // consumers' epilogue reads it: their loads then see an L2 hit instead of an HBM miss per pixel block
+                        const int ml = pw * 64 + lane;
+                        const int m = tile * p.TP + ml;
+                        const unsigned off = (ml < p.TP && m < p.M) ? (unsigned)m * (unsigned)p.out_cstride * ES + (unsigned)nblk * ES : kBadOff;
+                        pf0 = __builtin_amdgcn_raw_buffer_load_b32(rsr, off, 0, 0);
+                        pf1 = __builtin_amdgcn_raw_buffer_load_b32(rsr, off + 128u, 0, 0);
                     }
                     sq = sq == 2 ? 0 : sq + 1;
                 }
