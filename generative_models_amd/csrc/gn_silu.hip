@@ -372,6 +372,165 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
 // 30-60 % SLOWER than the streaming backward: it needs 188 VGPRs at 8 pixels per thread (one workgroup per CU) or spills at
 // 128, and it recomputes the sigmoid in both sweeps.  Removed; the streaming kernel with 32-channel slabs stays.)
 
+// Backward with the tensor read once: one workgroup (256 threads) = one (sample, 32-channel slab); dy stays PACKED in
+// registers (ITER x 16 B per thread), x is parked in LDS (HW x 64 B) on its way through the first sweep, and the second sweep
+// reads x from LDS and dy from registers.  HBM: x, dy, addends once + dx once (the streaming kernel reads x and dy twice).
+// 3 workgroups per CU (LDS), thread = (vec = tid & 3, plane = tid >> 2), pixel p = plane + 64 i.
+template <int ITER>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void gn_silu_bwd_hybrid_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ dadd1,
+    const bf16_t* __restrict__ dadd2, bf16_t* __restrict__ dx, float* __restrict__ dgp, float* __restrict__ dbp,
+    float* __restrict__ dxsum, int dxsum_stride, int HW, int C, int G, int B, float drop_p, uint64_t drop_seed,
+    uint64_t drop_off, const float* __restrict__ xadd, int xadd_stride) {
+    constexpr int NVEC = 4, CS = 32;
+    extern __shared__ __attribute__((aligned(16))) char xs_lds[];        // [HW][4] x 16 B
+    __shared__ float red[4][NVEC][16];
+    __shared__ float chg[CS], chb[CS];
+    __shared__ float sA[8], sB[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int vec = tid & 3, pl = tid >> 2;
+    int b, slab;
+    slab_of_block(blockIdx.x, C / CS, B, b, slab);
+    const int cpg = C / G, c0 = slab * CS, g0 = c0 / cpg, gps = CS / cpg;
+    const size_t base = (size_t)b * HW * C + c0 + vec * 8;
+    const int glo = (vec * 8) / cpg, ghi = (vec * 8 + 4) / cpg;
+    const float rs0 = rstd[b * G + g0 + glo], rs1 = rstd[b * G + g0 + ghi];
+    float gam[8], gb[8], mu[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = c0 + vec * 8 + k;
+        gam[k] = gamma[c];
+        gb[k] = beta[c];
+        // x enters as x + xadd[b][c]: fold the addend into the mean that is subtracted
+        mu[k] = mean[b * G + g0 + (k < 4 ? glo : ghi)] - (xadd ? xadd[(size_t)b * xadd_stride + c] : 0.f);
+    }
+    u32x4_t dr[ITER];
+    float ag[8], ab[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ag[k] = 0.f; ab[k] = 0.f; }
+    // chunks of 2 pixels: 4 independent 16-B loads in flight per thread, then their arithmetic; the fence keeps the
+    // scheduler from hoisting every load of the sweep to the top (26 x 4 VGPRs)
+#pragma unroll
+    for (int i0 = 0; i0 < ITER; i0 += 2) {
+        u32x4_t xr[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + u;
+            if (i >= ITER) continue;
+            const int p = pl + 64 * i;
+            const bool ok = p < HW;
+            xr[u] = ok ? *reinterpret_cast<const u32x4_t*>(x + base + (size_t)p * C) : u32x4_t{0u, 0u, 0u, 0u};
+            dr[i] = ok ? *reinterpret_cast<const u32x4_t*>(dy + base + (size_t)p * C) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + u;
+            if (i >= ITER) continue;
+            const int p = pl + 64 * i;
+            const bool ok = p < HW;
+            if (ok) *reinterpret_cast<u32x4_t*>(xs_lds + ((size_t)p * 4 + vec) * 16) = xr[u];
+            float xv[8], dv[8];
+            unpack8(xr[u], xv); unpack8(dr[i], dv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xh = (xv[k] - mu[k]) * (k < 4 ? rs0 : rs1);
+                const float g = fmaf(xh, gam[k], gb[k]);
+                const float sg = sigmoidf_(g);
+                const float dg = ok ? dv[k] * sg * (1.f + g * (1.f - sg)) : 0.f;
+                ag[k] = fmaf(dg, xh, ag[k]);
+                ab[k] += dg;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) asm volatile("" : "+v"(dr[i]));          // stay packed across the reduction
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ag[k] = vec_lane_sum<NVEC>(ag[k]); ab[k] = vec_lane_sum<NVEC>(ab[k]); }
+    if (lane < NVEC) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { red[wave][lane][k] = ag[k]; red[wave][lane][8 + k] = ab[k]; }
+    }
+    __syncthreads();
+    if (tid < CS) {
+        const int vv = tid >> 3, k = tid & 7;
+        float a = 0.f, bb = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += red[w][vv][k]; bb += red[w][vv][8 + k]; }
+        chg[tid] = a; chb[tid] = bb;
+        dgp[(size_t)b * C + c0 + tid] = a;
+        dbp[(size_t)b * C + c0 + tid] = bb;
+    }
+    __syncthreads();
+    if (tid < gps) {
+        float A = 0.f, Bq = 0.f;
+        for (int j = 0; j < cpg; ++j) {
+            const int cl = tid * cpg + j;
+            A = fmaf(gamma[c0 + cl], chb[cl], A);
+            Bq = fmaf(gamma[c0 + cl], chg[cl], Bq);
+        }
+        const float inv_n = 1.f / ((float)cpg * (float)HW);
+        sA[tid] = A * inv_n; sB[tid] = Bq * inv_n;
+    }
+    __syncthreads();
+    const float cA0 = sA[glo], cA1 = sA[ghi], cB0 = sB[glo], cB1 = sB[ghi];
+    float xs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xs[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int p = pl + 64 * i;
+        if (p >= HW) continue;
+        const size_t off = base + (size_t)p * C;
+        const u32x4_t xr = *reinterpret_cast<const u32x4_t*>(xs_lds + ((size_t)p * 4 + vec) * 16);
+        float xv[8], dv[8], o[8];
+        unpack8(xr, xv); unpack8(dr[i], dv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float rsk = k < 4 ? rs0 : rs1;
+            const float xh = (xv[k] - mu[k]) * rsk;
+            const float g = fmaf(xh, gam[k], gb[k]);
+            const float sg = sigmoidf_(g);
+            const float dg = dv[k] * sg * (1.f + g * (1.f - sg));
+            o[k] = rsk * (dg * gam[k] - (k < 4 ? cA0 : cA1) - xh * (k < 4 ? cB0 : cB1));
+        }
+        if (dadd1) {
+            float t[8];
+            load8(dadd1 + off, t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] += t[k];
+        }
+        if (dadd2) {
+            float t[8];
+            load8(dadd2 + off, t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] += t[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xs[k] += o[k];
+        store8(dx + off, o);
+        if (i & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (dxsum) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xs[k] = vec_lane_sum<NVEC>(xs[k]);
+        __syncthreads();   // red is re-used
+        if (lane < NVEC) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[wave][lane][k] = xs[k];
+        }
+        __syncthreads();
+        if (tid < CS) {
+            const int vv = tid >> 3, k = tid & 7;
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += red[w][vv][k];
+            dxsum[(size_t)b * dxsum_stride + c0 + tid] = a;
+        }
+    }
+}
+
 // pixels per thread of the register-resident kernels: the smallest of 1, 2, 4, 8 that fits the slab into <= 512 threads
 int gn_reg_iter(int HW, int nvec) {
     for (int it = 1; it <= 16; it <<= 1)
@@ -789,6 +948,15 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
             gn_silu_bwd_lds_kernel<1024><<<grid, kThreads, 0, gmk_stream(stream)>>>(
                 (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2,
                 (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, (unsigned)nbytes);
+    } else if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 32 == 0 && 32 % (C / groups) == 0 && HW >= 512 &&
+               HW <= 832 && drop_p == 0.f) {     // measured: -10 % at 28x28; the 16-pixel variant (32x32) spills and is slower
+        const size_t lds = (size_t)HW * 64;
+#define GMK_GN_BWD_HYB(IT)                                                                                                          \
+    gn_silu_bwd_hybrid_kernel<IT><<<B * (C / 32), 256, lds, gmk_stream(stream)>>>(                                                   \
+        (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,       \
+        dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride)
+        GMK_GN_BWD_HYB(13);
+#undef GMK_GN_BWD_HYB
     } else if (dtype == GMK_BF16) {
         const int CS = gn_slab_channels(gn_mode, C, groups, HW, 2, true);
         gn_silu_bwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
