@@ -863,7 +863,7 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     const int R = 256 / W;
     if (R < 1) return 0;
     const int TP = R * W;
-    const int crossings = (R - 1 + H - 1) / H;               // image boundaries a tile of R rows can span
+    const int crossings = H % R == 0 ? 0 : (R - 1 + H - 1) / H;   // image boundaries a tile of R rows can span (none if tiles align)
     const int ner = R + 2 + 2 * crossings;
     if (ner * (W + 2) > kHaloSlots) return 0;
     const int64_t rows_total = (int64_t)B * H;

@@ -99,7 +99,8 @@ def conv_ref(mode, srcs, w, bias):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("mode,two,ks,S,B", [(0, False, 3, 28, 2), (0, True, 3, 14, 3), (0, True, 1, 7, 5), (1, False, 3, 28, 2),
                                              (1, False, 3, 14, 3), (2, False, 3, 7, 3), (2, False, 3, 14, 2),
-                                             (0, False, 3, 7, 1), (0, False, 3, 8, 37)])
+                                             (0, False, 3, 7, 1), (0, False, 3, 8, 37), (0, True, 3, 64, 2), (0, False, 3, 32, 3),
+                                             (2, False, 3, 32, 2)])
 def test_conv_fwd_dgrad_wgrad(ops, dtype, mode, two, ks, S, B):
     C = 128
     cin = 2 * C if two else C
