@@ -6,8 +6,8 @@
 // All five kernels move the C-channel tensor exactly once (16 B per lane, a wave covers whole 256-B pixel rows) and
 // take the 1-channel image through L1/L2; a thread is (8-channel vector, pixel lane) and walks the flat pixel range of
 // its block with 32-bit counters (one division per thread, then increments — per-pixel 64-bit div/mod had made the
-// first version of these kernels 5x slower than their HBM time).  With one image channel the thread's 9x8 weights
-// live in registers; with more (CIFAR-shape configs) they are re-read from LDS.
+// first version of these kernels 5x slower than their HBM time).  A thread's weights / accumulators for ALL image channels live in
+// registers: 8 network channels per thread for 1-2 image channels, 4 for 3-4 (CIFAR-shape configs).
 #include "gmk_common.h"
 
 namespace {
@@ -35,34 +35,41 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+template <int VW> struct VecIO;
+template <> struct VecIO<8> {
+    template <typename T> static __device__ __forceinline__ void load(const T* p, float (&v)[8]) { load8(p, v); }
+    template <typename T> static __device__ __forceinline__ void store(T* p, const float (&v)[8]) { store8(p, v); }
+};
+template <> struct VecIO<4> {
+    template <typename T> static __device__ __forceinline__ void load(const T* p, float (&v)[4]) { load4(p, v); }
+    template <typename T> static __device__ __forceinline__ void store(T* p, const float (&v)[4]) { store4(p, v); }
+};
+
 // ---- 1 -> C "expand" convolution: stem forward (FLIP = false) and head data gradient (FLIP = true) ---------
 //   stem:  y[b,p,c]  = bias[c] + sum_{s,t} x[b,s,p + off(t)]    * w[c][s][t]        w: [C][cs][3][3]
 //   head:  da[b,p,c] =           sum_{s,t} dout[b,s,p - off(t)] * w[s][c][t]        w: [cs][C][3][3]
-template <typename T, bool REGW, bool FLIP>
+// CSN image channels, VW network channels per thread (8 for 1-2 image channels, 4 for 3-4: the CSN x 9 x VW weights of a
+// thread always live in registers)
+template <typename T, int CSN, int VW, bool FLIP>
 __global__ __launch_bounds__(256) void expand3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, T* __restrict__ out, int cs, int H,
-                                                       int W, int C, float inv_w, unsigned npix, int ppb) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [cs][9][C] (only when !REGW)
+                                                       const float* __restrict__ bias, T* __restrict__ out, int H, int W, int C,
+                                                       float inv_w, unsigned npix, int ppb) {
     const int tid = threadIdx.x;
-    const int nvec = C >> 3, planes = 256 / nvec;
+    const int nvec = C / VW, planes = 256 / nvec;
     const int vec = tid % nvec, pl = tid / nvec;
     const int HW = H * W;
-    auto widx = [&](int c, int s, int t) { return FLIP ? (s * C + c) * 9 + t : (c * cs + s) * 9 + t; };
-    float wr[9][8], bs[8];
-    if (REGW) {
+    float wr[CSN][9][VW], bs[VW];
+#pragma unroll
+    for (int s = 0; s < CSN; ++s)
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wr[t][i] = w[widx(vec * 8 + i, 0, t)];
-    } else {
-        for (int i = tid; i < cs * 9 * C; i += 256) {
-            const int c = i % C, t = (i / C) % 9, s = i / (9 * C);
-            wl[i] = w[widx(c, s, t)];
-        }
-        __syncthreads();
-    }
+            for (int i = 0; i < VW; ++i) {
+                const int c = vec * VW + i;
+                wr[s][t][i] = w[FLIP ? (s * C + c) * 9 + t : (c * CSN + s) * 9 + t];
+            }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bs[i] = bias ? bias[vec * 8 + i] : 0.f;
+    for (int i = 0; i < VW; ++i) bs[i] = bias ? bias[vec * VW + i] : 0.f;
 
     const unsigned g0 = blockIdx.x * (unsigned)ppb;
     const unsigned g1 = min(g0 + (unsigned)ppb, npix);
@@ -70,11 +77,12 @@ __global__ __launch_bounds__(256) void expand3x3_kernel(const float* __restrict_
     PixWalk pw(g0 + pl, HW);
     for (unsigned g = g0 + pl; g < g1; g += planes) {
         const int oy = div_small(pw.p, inv_w), ox = pw.p - oy * W;
-        float acc[8];
+        float acc[VW];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = bs[i];
-        for (int s = 0; s < (REGW ? 1 : cs); ++s) {
-            const float* ip = in + (size_t)(pw.b * cs + s) * HW;
+        for (int i = 0; i < VW; ++i) acc[i] = bs[i];
+#pragma unroll
+        for (int s = 0; s < CSN; ++s) {
+            const float* ip = in + (size_t)(pw.b * CSN + s) * HW;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = FLIP ? oy + 1 - ky : oy + ky - 1;
@@ -83,53 +91,54 @@ __global__ __launch_bounds__(256) void expand3x3_kernel(const float* __restrict_
                     const int ix = FLIP ? ox + 1 - kx : ox + kx - 1;
                     const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                     const float xv = ok ? ip[iy * W + ix] : 0.f;
-                    if (REGW) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[i] = fmaf(xv, wr[ky * 3 + kx][i], acc[i]);
-                    } else {
-                        const float* wp = wl + (s * 9 + ky * 3 + kx) * C + vec * 8;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[i] = fmaf(xv, wp[i], acc[i]);
-                    }
+                    for (int i = 0; i < VW; ++i) acc[i] = fmaf(xv, wr[s][ky * 3 + kx][i], acc[i]);
                 }
             }
         }
-        store8(out + (size_t)g * C + vec * 8, acc);
+        VecIO<VW>::store(out + (size_t)g * C + vec * VW, acc);
         pw.advance(planes, HW);
     }
 }
 
-// ---- weight gradients of both: the C-channel tensor is read once per image channel, the image through L1 --------
+// ---- weight gradients of both: the C-channel tensor is read ONCE (all image channels accumulate together), the image
+// through L1 -----------------------------------------------------------------------------------------------------------
 //   stem (FLIP = false): dw[c][s][t] = sum_{b,p} x[b,s,p + off(t)]    * dy[b,p,c]
 //   head (FLIP = true):  dw[s][c][t] = sum_{b,p} dout[b,s,p - off(t)] * a[b,p,c];  db[s] = sum dout[b,s,p]
 // part: [nblk][cs*C*9 (+ cs bias sums when FLIP)] per-block partials in the reference's weight layout.
-template <typename T, bool FLIP>
+template <typename T, int CSN, int VW, bool FLIP>
 __global__ __launch_bounds__(256) void wgrad3x3_kernel(const float* __restrict__ small, const T* __restrict__ big,
-                                                      float* __restrict__ part, int cs, int H, int W, int C, float inv_w,
-                                                      unsigned npix, int ppb) {
-    __shared__ float red[256 * 8];
+                                                      float* __restrict__ part, int H, int W, int C, float inv_w, unsigned npix,
+                                                      int ppb, int cs, int s0) {
+    __shared__ float red[256 * VW];
     const int tid = threadIdx.x;
-    const int nvec = C >> 3, planes = 256 / nvec;
+    const int nvec = C / VW, planes = 256 / nvec;
     const int vec = tid % nvec, pl = tid / nvec;
     const int HW = H * W;
     const unsigned g0 = blockIdx.x * (unsigned)ppb;
     const unsigned g1 = min(g0 + (unsigned)ppb, npix);
+    // this launch covers image channels s0 .. s0+CSN-1 of cs
     float* out = part + (size_t)blockIdx.x * ((size_t)cs * C * 9 + (FLIP ? cs : 0));
-    for (int s = 0; s < cs; ++s) {
-        float acc[9][8];
-        float bsum = 0.f;
+    float acc[CSN][9][VW];
+    float bsum[CSN];
+#pragma unroll
+    for (int s = 0; s < CSN; ++s) {
+        bsum[s] = 0.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
-        if (g0 + pl < g1) {
-            PixWalk pw(g0 + pl, HW);
-            for (unsigned g = g0 + pl; g < g1; g += planes) {
-                const int oy = div_small(pw.p, inv_w), ox = pw.p - oy * W;
-                float v[8];
-                load8(big + (size_t)g * C + vec * 8, v);
-                const float* sp = small + (size_t)(pw.b * cs + s) * HW;
-                if (FLIP) bsum += sp[pw.p];
+            for (int i = 0; i < VW; ++i) acc[s][t][i] = 0.f;
+    }
+    if (g0 + pl < g1) {
+        PixWalk pw(g0 + pl, HW);
+        for (unsigned g = g0 + pl; g < g1; g += planes) {
+            const int oy = div_small(pw.p, inv_w), ox = pw.p - oy * W;
+            float v[VW];
+            VecIO<VW>::load(big + (size_t)g * C + vec * VW, v);
+#pragma unroll
+            for (int s = 0; s < CSN; ++s) {
+                const float* sp = small + (size_t)(pw.b * cs + s0 + s) * HW;
+                if (FLIP) bsum[s] += sp[pw.p];
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int iy = FLIP ? oy + 1 - ky : oy + ky - 1;
@@ -139,33 +148,36 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const float* __restrict__
                         const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                         const float sv = ok ? sp[iy * W + ix] : 0.f;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[ky * 3 + kx][i] = fmaf(sv, v[i], acc[ky * 3 + kx][i]);
+                        for (int i = 0; i < VW; ++i) acc[s][ky * 3 + kx][i] = fmaf(sv, v[i], acc[s][ky * 3 + kx][i]);
                     }
                 }
-                pw.advance(planes, HW);
             }
+            pw.advance(planes, HW);
         }
+    }
+#pragma unroll
+    for (int s = 0; s < CSN; ++s) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 8; ++i) red[tid * 8 + i] = acc[t][i];
+            for (int i = 0; i < VW; ++i) red[tid * VW + i] = acc[s][t][i];
             __syncthreads();
             if (tid < C) {
-                const int vv = tid >> 3, i = tid & 7;
+                const int vv = tid / VW, i = tid % VW;
                 float sum = 0.f;
-                for (int q = 0; q < planes; ++q) sum += red[(q * nvec + vv) * 8 + i];
-                out[FLIP ? ((size_t)s * C + tid) * 9 + t : ((size_t)tid * cs + s) * 9 + t] = sum;
+                for (int q = 0; q < planes; ++q) sum += red[(q * nvec + vv) * VW + i];
+                out[FLIP ? ((size_t)(s0 + s) * C + tid) * 9 + t : ((size_t)tid * cs + s0 + s) * 9 + t] = sum;
             }
         }
         if (FLIP) {     // bias partial: only vec == 0 lanes hold distinct pixels' dout
             __syncthreads();
-            red[tid] = vec == 0 ? bsum : 0.f;
+            red[tid] = vec == 0 ? bsum[s] : 0.f;
             __syncthreads();
             if (tid == 0) {
                 float sum = 0.f;
                 for (int i = 0; i < 256; ++i) sum += red[i];
-                out[(size_t)cs * C * 9 + s] = sum;
+                out[(size_t)cs * C * 9 + s0 + s] = sum;
             }
         }
     }
@@ -261,11 +273,12 @@ static void launch_expand(const float* in, const float* w, const float* bias, T*
     const int64_t npix = (int64_t)B * H * W;
     const int ppb = small_ppb(npix), nb = small_blocks(npix);
     const float inv_w = 1.0f / (float)W;
-    if (cs == 1)
-        expand3x3_kernel<T, true, FLIP><<<nb, 256, 0, stream>>>(in, w, bias, out, cs, H, W, C, inv_w, (unsigned)npix, ppb);
-    else
-        expand3x3_kernel<T, false, FLIP><<<nb, 256, (size_t)cs * 9 * C * 4, stream>>>(in, w, bias, out, cs, H, W, C, inv_w,
-                                                                                      (unsigned)npix, ppb);
+#define GMK_EXPAND(CSN, VW) expand3x3_kernel<T, CSN, VW, FLIP><<<nb, 256, 0, stream>>>(in, w, bias, out, H, W, C, inv_w, (unsigned)npix, ppb)
+    if (cs == 1) GMK_EXPAND(1, 8);
+    else if (cs == 2) GMK_EXPAND(2, 8);
+    else if (cs == 3) GMK_EXPAND(3, 4);
+    else GMK_EXPAND(4, 4);
+#undef GMK_EXPAND
 }
 
 extern "C" int gmk_stem_fwd(const float* x, const float* w, const float* bias, void* y, int B, int cin, int H, int W, int C,
@@ -291,8 +304,12 @@ extern "C" int gmk_head_dgrad(const float* dout, const float* w, void* da, int B
 template <typename T, bool FLIP>
 static void launch_wgrad(const float* small, const T* big, float* part, int B, int cs, int H, int W, int C, hipStream_t stream) {
     const int64_t npix = (int64_t)B * H * W;
-    wgrad3x3_kernel<T, FLIP><<<small_blocks(npix), 256, 0, stream>>>(small, big, part, cs, H, W, C, 1.0f / (float)W,
-                                                                     (unsigned)npix, small_ppb(npix));
+    const int nb = small_blocks(npix), ppb = small_ppb(npix);
+    const float inv_w = 1.0f / (float)W;
+    // measured (B=1024, 28x28, 3 image channels): one launch per image channel with 8-channel vectors (the C-channel tensor is
+    // read cs times, 204 us) beats all channels at once with 4-channel vectors (one read, but 27 reduction rounds per block: 279 us)
+    for (int s0 = 0; s0 < cs; ++s0)
+        wgrad3x3_kernel<T, 1, 8, FLIP><<<nb, 256, 0, stream>>>(small, big, part, H, W, C, inv_w, (unsigned)npix, ppb, cs, s0);
 }
 
 extern "C" int gmk_stem_wgrad(const float* x, const void* dy, float* dw_part, int B, int cin, int H, int W, int C, int dtype,
