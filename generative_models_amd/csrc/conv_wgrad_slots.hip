@@ -24,9 +24,14 @@
 namespace {
 
 constexpr int kDyBase = 0;                  // 3 x 16 KiB
-constexpr int kXBase = 49152;               // 640 slots x 128 B = 80 KiB (512 ring + 128 mirror)
-constexpr int kScratch = kXBase + 81920;    // 8 x 1 KiB sink for the dummy DMA of steps without a mirror copy
-constexpr int kLdsBytes = kScratch + 8192;  // 139264
+constexpr int kXBase = 49152;               // 512-slot ring + mirror of its first LOOK*128 slots, 128 B per slot
+// LOOK = 1: taps reach at most 64 slots (W <= 61): X chunks c-1..c+1 are live, 128 mirrored slots (136 KiB of LDS).
+// LOOK = 2: taps reach up to 128 slots (W <= 125, e.g. 64x64 images): chunks c-2..c+2, 256 mirrored slots (152 KiB).
+template <int LOOK> struct SlotLds {
+    static constexpr int kMirrorSlots = LOOK * 128;
+    static constexpr int kScratch = kXBase + (512 + kMirrorSlots) * 128;    // 8 x 1 KiB sink for the dummy DMA of steps without a mirror copy
+    static constexpr int kBytes = kScratch + 8192;
+};
 
 struct SlotParams {
     const void* dy; int dy_cstride;
@@ -55,8 +60,10 @@ __device__ __forceinline__ void slot_advance(SlotPos& p, int dxe, int dye, int H
     if (p.ye >= H + 2) { p.ye -= H + 2; ++p.b; }
 }
 
+template <int LOOK>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_kernel(const SlotParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
+    __shared__ __attribute__((aligned(16))) char smem[SlotLds<LOOK>::kBytes];
+    constexpr int kScratch = SlotLds<LOOK>::kScratch;
     constexpr unsigned kBadPix = 0x00FFFFFFu;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_kernel(const SlotPara
     };
 
     // trackers: slot of this lane in the next X chunk / dY chunk to be issued
-    int xc = c_begin - 1;                         // next X chunk index to issue
+    int xc = c_begin - LOOK;                      // next X chunk index to issue
     int yc = c_begin;                             // next dY chunk index to issue
     SlotPos xpos = slot_decode(64 * max(xc, 0) + 8 * wave + (lane >> 3), H, WE);
     SlotPos ypos = slot_decode(64 * yc + 8 * wave + (lane >> 4), H, WE);
@@ -112,11 +119,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_kernel(const SlotPara
         const int rp = xc & 7;
         GMK_LDS char* dst = (GMK_LDS char*)(smem + kXBase + rp * 8192 + wave * 1024);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (GMK_LDS void*)dst, 16, voff, 0, 0, 0);
-        // mirror of ring slots 0..127 behind the end; other steps send a dummy (zero-fill) to the scratch sink so
+        // mirror of the first ring chunks behind the end; other steps send a dummy (zero-fill) to the scratch sink so
         // that every step issues the same number of DMA instructions
-        GMK_LDS char* dst2 = rp < 2 ? (GMK_LDS char*)(smem + kXBase + 65536 + rp * 8192 + wave * 1024)
-                                    : (GMK_LDS char*)(smem + kScratch + wave * 1024);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (GMK_LDS void*)dst2, 16, rp < 2 ? voff : 0xFFFFFF00u, 0, 0, 0);
+        GMK_LDS char* dst2 = rp < 2 * LOOK ? (GMK_LDS char*)(smem + kXBase + 65536 + rp * 8192 + wave * 1024)
+                                           : (GMK_LDS char*)(smem + kScratch + wave * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (GMK_LDS void*)dst2, 16, rp < 2 * LOOK ? voff : 0xFFFFFF00u, 0, 0, 0);
         ++xc;
     };
     int yslot3 = 0;                               // yc % 3 of the next dY chunk to issue
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_kernel(const SlotPara
     for (int t = 0; t < 9; ++t) {
         const int off = (t / 3 - 1) * WE + (t % 3 - 1);
         const int cls = (off + 64) & 3;
-        x_tap[t] = kXBase + (8 * hh + q + 64 + off) * 128 + ((wi ^ (((q + cls) >> 1) & 1)) << 6) + cblk * 32 + pp * 8;
+        x_tap[t] = kXBase + (8 * hh + q + 64 * LOOK + off) * 128 + ((wi ^ (((q + cls) >> 1) & 1)) << 6) + cblk * 32 + pp * 8;
     }
 
     f32x16 acc[9];
@@ -154,8 +161,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_kernel(const SlotPara
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-    // ---- prologue: X chunks c-1, c, c+1, dY chunk c, then the "previous step" issue (X c+2, dY c+1)
-    issue_x(); issue_x(); issue_x();
+    // ---- prologue: X chunks c-LOOK .. c+LOOK, dY chunk c, then the "previous step" issue (X c+LOOK+1, dY c+1)
+#pragma unroll
+    for (int k = 0; k < 2 * LOOK + 1; ++k) issue_x();
     issue_y();
     issue_x();
     issue_y();
@@ -164,10 +172,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_kernel(const SlotPara
     for (int c = c_begin; c < c_end; ++c) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        issue_x();                                // X chunk c+3 (+ mirror / dummy)
+        issue_x();                                // X chunk c+LOOK+2 (+ mirror / dummy)
         issue_y();                                // dY chunk c+2
         const char* ybase = smem + ycons3 * 16384 + dy_lane;
-        const int xrot = ((c - 1) & 7) << 13;     // ring position of chunk c-1
+        const int xrot = ((c - LOOK) & 7) << 13;  // ring position of chunk c-LOOK
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -213,7 +221,8 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
                              int W, int cout, float* slab, int64_t slab_bytes, int forced, int upsample, hipStream_t stream) {
     if (c0 % 64 || c1 % 64 || cout % 128) return 0;
     const int WE = W + 2;
-    if (WE + 1 > 64 || W < 4 || H < 2) return 0;
+    if (WE + 1 > 128 || W < 4 || H < 2) return 0;
+    const bool wide = WE + 1 > 64;
     if (64 / WE >= H + 2) return 0;                         // slot_advance assumes at most one image wrap per 64 slots
     const int64_t M = (int64_t)B * H * W;
     const int64_t total = (int64_t)B * (H + 2) * WE;
@@ -239,6 +248,7 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
     p.B = B; p.H = H; p.W = W; p.WE = WE; p.slab = slab; p.nchunks = nchunks; p.chunks_per_split = cps;
     p.nbdy = (unsigned)nbdy; p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1;
     dim3 grid(ns, ktot / 64, cout / 128);
-    conv_wgrad_slots_kernel<<<grid, 512, 0, stream>>>(p);
+    if (wide) conv_wgrad_slots_kernel<2><<<grid, 512, 0, stream>>>(p);
+    else conv_wgrad_slots_kernel<1><<<grid, 512, 0, stream>>>(p);
     return ns;
 }

@@ -295,6 +295,40 @@ def test_rng_and_adam(ops):
         assert float((pd.cpu() - p.detach()).abs().max()) < 1e-6 * step + 1e-7
 
 
+@pytest.mark.parametrize("two,S,B,mode", [(False, 28, 2, 0), (True, 14, 3, 0), (False, 64, 2, 0), (True, 64, 1, 0), (False, 32, 2, 2),
+                                          (False, 8, 5, 0)])
+def test_forced_kernel_variants_agree_with_torch(ops, two, S, B, mode):
+    """Small problems pick the im2col kernels automatically: force the slot weight-gradient kernel (both window widths: W <= 61
+    and the wide one for 64-pixel rows) and both LDS-halo convolution kernels on them and hold them to the same parity bar."""
+    from generative_models_amd._lib import lib
+    dtype, C = torch.bfloat16, 128
+    cin = 2 * C if two else C
+    srcs = [q(rnd(B, C, S, S, seed=110 + i), dtype).requires_grad_(True) for i in range(2 if two else 1)]
+    w = q(rnd(C, cin, 3, 3, seed=120) / math.sqrt(cin * 9), dtype).requires_grad_(True)
+    out_ref = conv_ref(mode, srcs, w, torch.zeros(C))
+    ho, wo = out_ref.shape[2:]
+    dy = q(rnd(B, C, ho, wo, seed=130), dtype)
+    out_ref.backward(dy)
+    sd = [nhwc(t.detach(), dtype) for t in srcs]
+    wf = torch.empty(w.numel(), device="cuda", dtype=dtype); wd = torch.empty_like(wf)
+    ops.pack_conv_weight(w.detach().cuda(), wf, wd)
+    try:
+        lib.gmk_set_kernel_choice(-1, 2, -1)                       # slot weight-gradient kernel
+        dw = torch.empty_like(w.detach()).cuda()
+        ops.conv_wgrad(nhwc(dy, dtype), sd, 3, mode, dw)
+        assert lib.gmk_last_kernel() == 12
+        assert rel_err(dw, w.grad) < TOL[dtype], "slot wgrad"
+        for variant, kid in ((0, 4), (3, 3)):                      # wave-specialised / 8-compute-wave halo kernel
+            lib.gmk_set_kernel_choice(3, -1, -1)
+            lib.gmk_set_dev_variant(variant)
+            out = ops.conv_igemm(sd, wf, C, 3, mode, (ho, wo))
+            assert lib.gmk_last_kernel() == kid
+            assert rel_err(nchw(out), out_ref) < TOL[dtype], f"halo forward variant {variant}"
+    finally:
+        lib.gmk_set_kernel_choice(-1, -1, -1)
+        lib.gmk_set_dev_variant(0)
+
+
 @pytest.mark.parametrize("S,B,G", [(28, 3, 32), (14, 5, 32), (14, 5, 16), (8, 37, 32), (7, 9, 32)])
 def test_conv_emits_groupnorm_statistics(ops, S, B, G):
     """The halo convolution's epilogue statistics == statistics of the tensor it stored (tiles spanning samples,
