@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--size", type=int, default=28)
     ap.add_argument("--in_channels", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--attention", type=int, default=0, help="1: self-attention block at the S/4 level (BASELINE config 5 shape)")
     ap.add_argument("--sampler_steps", type=int, default=20)
     ap.add_argument("--cpu_seconds", type=float, default=15.0)
     ap.add_argument("--no_cpu", action="store_true")
@@ -109,7 +110,7 @@ def main():
     Model = common.discover_models()["diffusion"]
     G = common.AttrDict(dict(Model.DG))
     G.update(lr=3e-4, pad32=0, device=str(dev), timesteps=1000, bs=a.batch, compute_dtype=a.dtype,
-             in_channels=a.in_channels, seed=0)
+             in_channels=a.in_channels, seed=0, attention=a.attention)
     model = Model(G).to(dev)
     model.size = a.size
     if world > 1:
@@ -210,8 +211,9 @@ def main():
             "metric": "ddpm_train_images_per_sec", "value": round(images_per_s, 1), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"DDPM train step, MNIST-shape {a.in_channels}x{a.size}x{a.size}, SimpleUnet C=128, "
-                                   f"per-GPU batch {a.batch}, T=1000 (BASELINE.json configs[1])",
+            "config": {"workload": f"DDPM train step, {a.in_channels}x{a.size}x{a.size} images, SimpleUnet C=128"
+                                   f"{' + self-attention' if a.attention else ''}, per-GPU batch {a.batch}, T=1000"
+                                   f"{' (BASELINE.json configs[1])' if (a.in_channels, a.size, a.batch, a.attention) == (1, 28, 1024, 0) else ''}",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}",
                        "optimizer": "fused Adam lr=3e-4", "mean_type": "v"},
             "sampler": sampler,

@@ -47,7 +47,7 @@ RES_BLOCKS = ["down.seq.1", "down.seq.2", "down.seq.4", "down.seq.5", "turn", "u
               "up.seq.3.0", "up.seq.4", "up.seq.5", "up.seq.6"]
 
 
-def param_inventory(C, in_channels=1):
+def param_inventory(C, in_channels=1, attention=False):
     E = 2 * C
     inv = []
     for name, fan_in in (("time_embed", 64), ("cond_w_embed", 64), ("guide_embed", 10)):
@@ -59,6 +59,9 @@ def param_inventory(C, in_channels=1):
     inv += _res_names("down.seq.4", C, C, E) + _res_names("down.seq.5", C, C, E)
     inv += [("down.seq.6.conv.weight", (C, C, 3, 3)), ("down.seq.6.conv.bias", (C,))]
     inv += _res_names("turn", C, C, E)
+    if attention:        # self-attention extension behind `turn` (no reference counterpart; defined by the tests' CPU restatement `attention_block`)
+        inv += [("attn.norm.weight", (C,)), ("attn.norm.bias", (C,)), ("attn.qkv.weight", (3 * C, C, 1, 1)),
+                ("attn.qkv.bias", (3 * C,)), ("attn.proj.weight", (C, C, 1, 1)), ("attn.proj.bias", (C,))]
     for i in range(7):
         if i in (0, 3):
             inv += _res_names(f"up.seq.{i}.0", 2 * C, C, E)
@@ -82,7 +85,7 @@ def _attach(root, dotted, param):
 
 
 class SimpleUnet(nn.Module):
-    def __init__(self, channels, dropout=0.0, in_channels=1, compute_dtype=torch.bfloat16):
+    def __init__(self, channels, dropout=0.0, in_channels=1, compute_dtype=torch.bfloat16, attention=False):
         super().__init__()
         if channels % 128 != 0 or channels > 256:
             raise ValueError(f"the HIP path supports hidden_size 128 or 256 (MFMA tile width 128); got {channels}")
@@ -95,7 +98,8 @@ class SimpleUnet(nn.Module):
         self.channels, self.in_channels, self.compute_dtype = channels, in_channels, compute_dtype
         self.dropout = float(dropout)      # nn.Dropout(p) of every ResBlock's out_layers (simple_unet.py:171); training mode only
         self.drop_seed, self._drop_counter = 0x5EEDD0, 0
-        self._inventory = param_inventory(channels, in_channels)
+        self.attention = bool(attention)
+        self._inventory = param_inventory(channels, in_channels, self.attention)
         # arena order: the 12 emb_layers Linear weights, then their biases (one batched GEMM serves all 12
         # ResBlocks), then everything else in reference order; every tensor starts on a 16-byte boundary.
         emb_w = [f"{b}.emb_layers.1.weight" for b in RES_BLOCKS]
@@ -125,7 +129,7 @@ class SimpleUnet(nn.Module):
             wshape = shapes.get(base + ".weight")
             if len(wshape) >= 2:                      # Linear / Conv2d: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
                 bound = 1.0 / math.sqrt(math.prod(wshape[1:]))
-                if ".out_layers.3" in n:
+                if ".out_layers.3" in n or n.startswith("attn.proj"):
                     view.zero_()
                 else:
                     view.uniform_(-bound, bound)
@@ -185,6 +189,8 @@ class SimpleUnet(nn.Module):
             names += [f"{b}.in_layers.2", f"{b}.out_layers.3"]
             if f"{b}.skip_connection.weight" in self._shapes:
                 names.append(f"{b}.skip_connection")
+        if self.attention:
+            names += ["attn.qkv", "attn.proj"]
         return names
 
     def _repack(self):
@@ -313,6 +319,57 @@ class SimpleUnet(nn.Module):
             ctx[name + ".dropout"] = drop
         return out
 
+    # ---- self-attention extension (north_star; no reference counterpart — defined by the tests' CPU restatement `attention_block`) ------------
+    def _attn_fwd(self, x, ctx):
+        """x NHWC [B,H,W,C] -> x + proj(softmax(q k^T / sqrt(C)) v), (q,k,v) = conv1x1(SiLU(GN(x))); single head over C."""
+        P, C, T = self._pv, self.channels, self.compute_dtype
+        B, H, W, _ = x.shape
+        N = H * W
+        if N % 8 or N > 1024:
+            raise ValueError(f"the attention level has {N} tokens: the HIP path needs a multiple of 8, at most 1024 "
+                             f"(input sizes 32 / 64: 64 / 256 tokens)")
+        a, mean, rstd = ops.gn_silu_fwd(x, P["attn.norm.weight"], P["attn.norm.bias"], 32)
+        qkv = ops.conv_igemm([a], self._packs["attn.qkv"][0], 3 * C, 1, ops.NORMAL, (H, W), cout=3 * C, bias=P["attn.qkv.bias"])
+        t = qkv.view(B, N, 3 * C)
+        q, k, v = t[:, :, :C], t[:, :, C:2 * C], t[:, :, 2 * C:]
+        S = ops.bgemm_nt(q, k, out_dtype=torch.float32)
+        Pm = ops.softmax_fwd(S, C ** -0.5, T)
+        o = ops.bgemm_nt(Pm, ops.transpose_last2(v)).view(B, H, W, C)
+        out = ops.conv_igemm([o], self._packs["attn.proj"][0], C, 1, ops.NORMAL, (H, W), bias=P["attn.proj.bias"], residual=x)
+        if ctx is not None:
+            ctx["attn"] = (x, a, mean, rstd, qkv, Pm, o)
+        return out
+
+    def _attn_bwd(self, ctx, dout):
+        """-> (dx, per-sample channel sums of dx)."""
+        P, G, C = self._pv, self._gv, self.channels
+        x, a, mean, rstd, qkv, Pm, o = ctx.pop("attn")
+        B, H, W, _ = x.shape
+        N = H * W
+        scale = C ** -0.5
+        t = qkv.view(B, N, 3 * C)
+        q, k, v = t[:, :, :C], t[:, :, C:2 * C], t[:, :, 2 * C:]
+        # out = x + proj(o)
+        ops.colsum(ops.chansum(dout), G["attn.proj.bias"], defer=True)
+        self._wgrad(dout, [o], 1, ops.NORMAL, G["attn.proj.weight"])
+        do = ops.conv_igemm([dout], self._packs["attn.proj"][1], C, 1, ops.NORMAL, (H, W)).view(B, N, C)
+        # o = P v,  P = softmax(scale * q k^T)
+        dP = ops.bgemm_nt(do, v, out_dtype=torch.float32)
+        dS = ops.softmax_bwd(Pm, dP, scale)
+        dqkv = torch.empty_like(qkv)
+        d3 = dqkv.view(B, N, 3 * C)
+        ops.bgemm_nt(ops.transpose_last2(Pm), ops.transpose_last2(do), out=d3[:, :, 2 * C:])     # dv = P^T do
+        ops.bgemm_nt(dS, ops.transpose_last2(k), out=d3[:, :, :C])                               # dq = dS k
+        ops.bgemm_nt(ops.transpose_last2(dS), ops.transpose_last2(q), out=d3[:, :, C:2 * C])     # dk = dS^T q
+        # (q, k, v) = conv1x1(a)
+        G["attn.qkv.bias"].copy_(dqkv.float().sum((0, 1, 2)))        # 3C-channel bias gradient: tiny, off the hot path
+        self._wgrad(dqkv, [a], 1, ops.NORMAL, G["attn.qkv.weight"])
+        da = ops.conv_igemm([dqkv], self._packs["attn.qkv"][1], C, 1, ops.NORMAL, (H, W))
+        s = torch.empty((B, C), device=x.device, dtype=torch.float32)
+        dx, dgp, dbp = ops.gn_silu_bwd(da, x, P["attn.norm.weight"], P["attn.norm.bias"], mean, rstd, dadd1=dout, dxsum=s)
+        ops.colsum(dgp, G["attn.norm.weight"], defer=True); ops.colsum(dbp, G["attn.norm.bias"], defer=True)
+        return dx, s
+
     def _wgrad(self, dy, srcs, ksize, mode, dw):
         """Weight gradient on the side stream (ops.WGRAD_STREAM): it depends only on dy and the saved activations, so it
         runs beside the data-gradient chain and fills the CUs the persistent kernels' tails leave idle."""
@@ -397,6 +454,8 @@ class SimpleUnet(nn.Module):
         t6 = ops.conv_igemm([t5], self._packs["down.seq.6.conv"][0], C, 3, ops.STRIDE2, (H4, W4),
                             bias=P["down.seq.6.conv.bias"])
         t7 = self._res_fwd("turn", [t6], emb_all, 4, ctx)
+        if self.attention:
+            t7 = self._attn_fwd(t7, ctx)
         u0r = self._res_fwd("up.seq.0.0", [t7, t6], emb_all, 5, ctx)
         u0 = ops.conv_igemm([u0r], self._packs["up.seq.0.1.conv"][0], C, 3, ops.UPSAMPLE2, (H2, W2),
                             bias=P["up.seq.0.1.conv.bias"], gn_stats=True)
@@ -427,7 +486,7 @@ class SimpleUnet(nn.Module):
         is_emb = lambda n: n.startswith(emb) or ".emb_layers." in n
         b0 = rng(lambda n: n.startswith(late) and not is_emb(n))
         b1 = rng(lambda n: n.startswith(mid) and not is_emb(n))
-        b2 = rng(lambda n: (n.startswith("down.") or n.startswith("turn.")) and not is_emb(n))
+        b2 = rng(lambda n: (n.startswith("down.") or n.startswith("turn.") or n.startswith("attn.")) and not is_emb(n))
         b3 = rng(is_emb)
         buckets = [b0, b1, b2, b3]
         assert sorted(buckets)[0][0] == 0 and sorted(buckets)[-1][1] == self._arena_size
@@ -479,6 +538,8 @@ class SimpleUnet(nn.Module):
         du0r = ops.sumpool2x2(dU)
         s0r = ops.chansum(du0r)
         (dt7, s7), (dt6a, _) = self._res_bwd("up.seq.0.0", ctx, du0r, s0r, demb_all, 5)
+        if self.attention:
+            dt7, s7 = self._attn_bwd(ctx, dt7)
         ops.flush_colsums(); join()
         ready(1)
         ((dt6, s6t),) = self._res_bwd("turn", ctx, dt7, s7, demb_all, 4, extra_add=[dt6a])

@@ -495,3 +495,50 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
         _f32(t, nm)
     assert p.numel() == g.numel() == m.numel() == v.numel()
     check(lib.gmk_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _s()), "adam_step")
+
+
+# ---- self-attention core (north_star extension; no reference call site) -----------------------------------------
+def bgemm_nt(A, B, out=None, alpha=1.0, out_dtype=None):
+    """C[b] = alpha * A[b] @ B[b]^T for batches of K-contiguous matrices (row / batch strides free): A [batch, M, K],
+    B [batch, N, K] -> C [batch, M, N].  bf16 operands run on the matrix cores (fp32 accumulation), fp32 operands on FMAs."""
+    assert A.dim() == 3 and B.dim() == 3 and A.shape[0] == B.shape[0] and A.shape[2] == B.shape[2] and A.dtype == B.dtype
+    assert A.stride(2) == 1 and B.stride(2) == 1 and A.is_cuda and A.dtype in _DT
+    batch, M, K = A.shape
+    N = B.shape[1]
+    od = out_dtype or (out.dtype if out is not None else A.dtype)
+    if out is None:
+        out = torch.empty((batch, M, N), device=A.device, dtype=od)
+    assert out.shape == (batch, M, N) and out.stride(2) == 1 and out.dtype == od
+    check(lib.gmk_bgemm_nt(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(out), out.stride(0), out.stride(1),
+                           batch, M, N, K, float(alpha), _DT[A.dtype], _DT[od], _s()), "bgemm_nt")
+    return out
+
+
+def transpose_last2(x, out=None):
+    """[batch, R, C] (unit last stride, free row / batch strides) -> contiguous [batch, C, R]."""
+    assert x.dim() == 3 and x.stride(2) == 1 and x.is_cuda and x.dtype in _DT
+    batch, R, C = x.shape
+    if out is None:
+        out = torch.empty((batch, C, R), device=x.device, dtype=x.dtype)
+    check(lib.gmk_transpose(_p(x), x.stride(0), x.stride(1), _p(out), out.stride(0), out.stride(1), batch, R, C, _DT[x.dtype], _s()),
+          "transpose")
+    return out
+
+
+def softmax_fwd(S, scale, dtype):
+    """softmax(scale * S) over the last dimension; S fp32 contiguous -> P in `dtype`."""
+    _f32(S, "S")
+    N = S.shape[-1]
+    P = torch.empty(S.shape, device=S.device, dtype=dtype)
+    check(lib.gmk_softmax_fwd(_p(S), _p(P), S.numel() // N, N, float(scale), _DT[dtype], _s()), "softmax_fwd")
+    return P
+
+
+def softmax_bwd(P, dP, scale):
+    """dS = scale * P * (dP - sum(dP * P)) per row; dP fp32, P / dS in P.dtype."""
+    _chk(P, name="P"); _f32(dP, "dP")
+    assert P.shape == dP.shape
+    N = P.shape[-1]
+    dS = torch.empty_like(P)
+    check(lib.gmk_softmax_bwd(_p(P), _p(dP), _p(dS), P.numel() // N, N, float(scale), _DT[P.dtype], _s()), "softmax_bwd")
+    return dS

@@ -177,6 +177,22 @@ int gmk_sampler_step(const float* v, const float* v_uncond, const float* cond_w,
                      float logsnr_t, float logsnr_s, int is_last, float* z_next, float* x_pred, float* eps_pred,
                      int mean_type, int B, int64_t n, void* stream);
 
+/* ---- self-attention core (north_star "optional self-attention block", BASELINE config 5) -------------
+ * The reference SimpleUnet has no attention block: these have NO reference call site (parity unpinned; their definition is the
+ * CPU restatement `attention_block` the tests check them against).  QK^T / PV and their gradients are one batched GEMM on the matrix cores:
+ *   C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k]      (both operands K-contiguous; leading dimensions and batch
+ *   strides in elements; bf16 operands: K and all strides multiples of 8; out_dtype GMK_F32 or GMK_BF16) */
+int gmk_bgemm_nt(const void* A, int64_t a_batch, int64_t lda, const void* B, int64_t b_batch, int64_t ldb, void* C,
+                 int64_t c_batch, int64_t ldc, int batch, int M, int N, int K, float alpha, int in_dtype, int out_dtype,
+                 void* stream);
+/* out[b][c][r] = in[b][r][c]  (R x Cc matrices, leading dimensions / batch strides in elements) */
+int gmk_transpose(const void* in, int64_t in_batch, int64_t ld_in, void* out, int64_t out_batch, int64_t ld_out, int batch,
+                  int R, int Cc, int dtype, void* stream);
+/* P[r][:] = softmax(scale * S[r][:]) over rows of N <= 1024 fp32 scores; P in out_dtype */
+int gmk_softmax_fwd(const float* S, void* P, int64_t rows, int N, float scale, int out_dtype, void* stream);
+/* dS = scale * P * (dP - sum_j dP_j P_j)  (P, dS in dtype; dP fp32) */
+int gmk_softmax_bwd(const void* P, const float* dP, void* dS, int64_t rows, int N, float scale, int dtype, void* stream);
+
 /* ---- progressive distillation (gaussian_diffusion.py:87-91,105-154) ------------------------------------------ */
 /* logsnr[b] = schedule(u[b] - shift) with u given, or u = fp32(i_times[b] + 1) / num_steps (discrete time, :90-91);
  * u_out (optional) receives the shifted u */

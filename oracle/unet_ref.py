@@ -41,8 +41,13 @@ def _res_spec(prefix, cin, cout, emb):
     return spec
 
 
-def param_spec(channels, in_channels=1):
-    """[(name, shape)] in the order `SimpleUnet(channels, p).state_dict()` yields them."""
+ATTN_SPEC = lambda C: [("attn.norm.weight", (C,)), ("attn.norm.bias", (C,)), ("attn.qkv.weight", (3 * C, C, 1, 1)),
+                       ("attn.qkv.bias", (3 * C,)), ("attn.proj.weight", (C, C, 1, 1)), ("attn.proj.bias", (C,))]
+
+
+def param_spec(channels, in_channels=1, attention=False):
+    """[(name, shape)] in the order `SimpleUnet(channels, p).state_dict()` yields them.  attention=True appends the
+    parameters of the self-attention extension (no counterpart in the reference) behind `turn`."""
     C, E = channels, 2 * channels
     spec = []
     for name, fan_in in (("time_embed", 64), ("cond_w_embed", 64), ("guide_embed", 10)):
@@ -60,6 +65,8 @@ def param_spec(channels, in_channels=1):
         spec += _res_spec(f"down.seq.{i}", C, C, E)
     spec += [("down.seq.6.conv.weight", (C, C, 3, 3)), ("down.seq.6.conv.bias", (C,))]
     spec += _res_spec("turn", C, C, E)
+    if attention:
+        spec += ATTN_SPEC(C)
     for i in range(7):
         if i in (0, 3):
             spec += _res_spec(f"up.seq.{i}.0", 2 * C, C, E)
@@ -75,7 +82,7 @@ def param_spec(channels, in_channels=1):
     return spec
 
 
-def closed_form_params(channels, in_channels=1, dtype=torch.float32):
+def closed_form_params(channels, in_channels=1, dtype=torch.float32, attention=False):
     """Deterministic parameter fill both the golden generator and every test can regenerate.
 
     Every tensor gets a distinct phase; the reference's zero-initialised `out_layers.3`
@@ -84,7 +91,7 @@ def closed_form_params(channels, in_channels=1, dtype=torch.float32):
     GroupNorm weights: 1 + 0.1*sin; biases: 0.1*sin.
     """
     params = OrderedDict()
-    for tid, (name, shape) in enumerate(param_spec(channels, in_channels)):
+    for tid, (name, shape) in enumerate(param_spec(channels, in_channels, attention)):
         n = 1
         for s in shape:
             n *= s
@@ -101,25 +108,25 @@ def closed_form_params(channels, in_channels=1, dtype=torch.float32):
     return params
 
 
-def reference_init_params(channels, in_channels=1, seed=0, dtype=torch.float32, zero_out_layers=True):
+def reference_init_params(channels, in_channels=1, seed=0, dtype=torch.float32, zero_out_layers=True, attention=False):
     """PyTorch-default-style init (kaiming-uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for
     weights and biases, GroupNorm 1/0, `out_layers.3` zeroed as simple_unet.py:172 does unless
     zero_out_layers=False, which keeps every convolution live at its default-init scale)."""
     g = torch.Generator().manual_seed(seed)
     params = OrderedDict()
     fan = {}
-    for name, shape in param_spec(channels, in_channels):
+    for name, shape in param_spec(channels, in_channels, attention):
         if len(shape) >= 2:
             n = 1
             for s in shape[1:]:
                 n *= s
             fan[name[: -len(".weight")]] = n
-    for name, shape in param_spec(channels, in_channels):
+    for name, shape in param_spec(channels, in_channels, attention):
         base, kind = name.rsplit(".", 1)
         if base in fan:
             bound = 1.0 / math.sqrt(fan[base])
             v = (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * bound
-            if ".out_layers.3" in name and zero_out_layers:
+            if (".out_layers.3" in name or name.startswith("attn.proj")) and zero_out_layers:
                 v = torch.zeros(shape, dtype=torch.float64)
         else:  # GroupNorm affine
             v = torch.ones(shape, dtype=torch.float64) if kind == "weight" else torch.zeros(shape, dtype=torch.float64)
@@ -181,6 +188,19 @@ def resblock(p, prefix, x, emb, drop=None):
     return x + h
 
 
+def attention_block(p, x):
+    """The self-attention extension (north_star "optional self-attention block", BASELINE config 5).  NO reference counterpart:
+    this function IS the definition.  Single head over all C channels at the lowest resolution, pre-activation:
+        a = SiLU(GroupNorm32(x));  q, k, v = split(conv1x1(a), 3);  out = x + conv1x1(softmax(q k^T / sqrt(C)) v)."""
+    B, C, H, W = x.shape
+    a = gn_silu(x, p["attn.norm.weight"], p["attn.norm.bias"])
+    qkv = F.conv2d(a, p["attn.qkv.weight"], p["attn.qkv.bias"]).reshape(B, 3, C, H * W)
+    q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]                       # [B, C, N]
+    w = torch.softmax(torch.einsum("bci,bcj->bij", q, k) * (C ** -0.5), dim=-1)
+    o = torch.einsum("bij,bcj->bci", w, v).reshape(B, C, H, W)
+    return x + F.conv2d(o, p["attn.proj.weight"], p["attn.proj.bias"])
+
+
 def unet_forward(p, x, logsnr, guide=None, cond_w=None, taps=None, dropout=None):
     """v_hat = net(z, logsnr, guide, cond_w) — simple_unet.py:44-72.
 
@@ -208,6 +228,8 @@ def unet_forward(p, x, logsnr, guide=None, cond_w=None, taps=None, dropout=None)
         t[f"down.{i}"] = c
     # turn (:68)
     h = resblock(p, "turn", h, emb, dm("turn"))
+    if "attn.qkv.weight" in p:
+        h = attention_block(p, h)
     t["turn"] = h
     # Up (:146-152): cat with the reversed cache, ResBlock(2C->C), nearest x2 + conv at idx 0 and 3
     for i in range(7):

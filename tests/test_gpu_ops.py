@@ -354,3 +354,35 @@ def test_conv_emits_groupnorm_statistics(ops, S, B, G):
     y2, m2, r2 = ops.gn_silu_fwd(plain, gamma, beta, G)
     assert rel_err(m1, m2) < 1e-4 and rel_err(r1, r2) < 1e-4
     assert rel_err(y1.float(), y2.float()) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_core_ops(ops, dtype):
+    """Batched K-contiguous GEMM (strided operands, ragged M/N), transpose, row softmax forward/backward vs torch."""
+    g = torch.Generator().manual_seed(7)
+    Bn, N, C = 3, 200, 128
+    qkv = q(torch.randn((Bn, N, 3 * C), generator=g) * 0.5, dtype)
+    d = nhwc if False else None
+    t = qkv.cuda().to(dtype)
+    qv, kv, vv = t[:, :, :C], t[:, :, C:2 * C], t[:, :, 2 * C:]
+    S = ops.bgemm_nt(qv, kv, out_dtype=torch.float32)
+    S_ref = torch.einsum("bik,bjk->bij", qkv[:, :, :C], qkv[:, :, C:2 * C])
+    assert rel_err(S, S_ref) < TOL[dtype]
+    scale = C ** -0.5
+    P = ops.softmax_fwd(S, scale, dtype)
+    P_ref = torch.softmax(S_ref * scale, -1)
+    assert rel_err(P.float(), P_ref) < TOL[dtype]
+    vT = ops.transpose_last2(vv)
+    assert torch.equal(vT, vv.transpose(1, 2).contiguous())
+    o = ops.bgemm_nt(P, vT)
+    assert rel_err(o.float(), torch.einsum("bij,bjc->bic", P_ref, qkv[:, :, 2 * C:])) < 2 * TOL[dtype]
+    # strided output: write into a column block of a wider tensor
+    wide = torch.zeros((Bn, N, 3 * C), device="cuda", dtype=dtype)
+    ops.bgemm_nt(P, vT, out=wide[:, :, C:2 * C], alpha=0.5)
+    assert rel_err(wide[:, :, C:2 * C].float(), 0.5 * o.float()) < 1e-2 and float(wide[:, :, :C].abs().max()) == 0.0
+    dP = torch.randn((Bn, N, N), generator=g)
+    dS = ops.softmax_bwd(P, dP.cuda(), scale)
+    Pr = P_ref.clone().requires_grad_(True)
+    Sr = (S_ref.clone()).requires_grad_(True)
+    torch.softmax(Sr * scale, -1).backward(dP)
+    assert rel_err(dS.float(), Sr.grad) < 2 * TOL[dtype]

@@ -357,3 +357,34 @@ def test_dropout_training_mode_vs_oracle(dtype):
     l2 = float((out_eval.cpu().double() - ref_eval.double()).norm() / ref_eval.double().norm())
     # bf16: relative-L2 bar with the worst element at 1.5x (bf16 storage noise of an all-layers-live net, see the ragged-shape test)
     assert l2 < tol and rel_err(out_eval, ref_eval) < (tol if dtype == torch.float32 else 1.5 * tol), (l2, rel_err(out_eval, ref_eval))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_extension_vs_oracle(dtype):
+    """The self-attention block (north_star / BASELINE config 5; NO reference counterpart, so the oracle's attention_block is its
+    definition — parity unpinned): whole net with attention at the 8x8 = 64-token level of a 32x32 input, forward + gradients."""
+    from generative_models_amd.diffusion.simple_unet import SimpleUnet
+    from oracle import unet_ref as U
+    B, S = 3, 32
+    params = U.reference_init_params(128, zero_out_layers=False, attention=True)
+    net = SimpleUnet(128, 0.0, compute_dtype=dtype, attention=True); net.load_state_dict(params); net = net.cuda()
+    assert len(net.state_dict()) == 166 and "attn.qkv.weight" in net.state_dict()
+    g = torch.Generator().manual_seed(21)
+    z = torch.randn((B, 1, S, S), generator=g); l = torch.tensor([-5.0, 0.0, 4.0]); y = torch.tensor([3, -1, 7])
+    dout = torch.randn((B, 1, S, S), generator=g)
+    pr = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = U.unet_forward(pr, z, l, guide=y)
+    ref.backward(dout)
+    plain = U.unet_forward({k: v for k, v in params.items() if not k.startswith("attn.")}, z, l, guide=y)
+    assert rel_err(plain, ref) > 1e-2                                  # the block is live in this test
+    ctx = {}
+    out = net.forward_hip(z.cuda(), l.cuda(), y.cuda(), None, ctx=ctx)
+    tol = TOL[dtype]
+    l2 = float((out.cpu().double() - ref.detach().double()).norm() / ref.detach().double().norm())
+    assert l2 < tol and rel_err(out, ref) < (tol if dtype == torch.float32 else 1.5 * tol), (l2, rel_err(out, ref))
+    net.backward_hip(ctx, dout.cuda())
+    for name in ("attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "attn.norm.weight", "attn.norm.bias",
+                 "turn.out_layers.3.weight", "down.seq.1.in_layers.2.weight", "up.seq.0.0.in_layers.2.weight", "time_embed.0.weight"):
+        assert rel_err(net.grad(name), pr[name].grad) < 6 * tol, name
+    # without the flag nothing changes: 160 tensors, reference names only
+    assert len(SimpleUnet(128, 0.0).state_dict()) == 160
