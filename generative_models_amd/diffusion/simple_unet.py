@@ -87,8 +87,9 @@ def _attach(root, dotted, param):
 class SimpleUnet(nn.Module):
     def __init__(self, channels, dropout=0.0, in_channels=1, compute_dtype=torch.bfloat16, attention=False):
         super().__init__()
-        if channels % 128 != 0 or channels > 256:
-            raise ValueError(f"the HIP path supports hidden_size 128 or 256 (MFMA tile width 128); got {channels}")
+        if channels != 128:
+            raise ValueError(f"the HIP path is built for hidden_size 128 (the reference default, every BASELINE config; the MFMA "
+                             f"tiles are 128 output channels wide); got {channels}")
         if not 0.0 <= dropout < 1.0:
             raise ValueError(f"dropout probability has to be in [0, 1), got {dropout}")
         if not 1 <= in_channels <= 4:
