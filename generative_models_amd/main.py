@@ -58,16 +58,27 @@ class SyntheticMNIST:
     def __init__(self, bs, n_batches, pad32, binarize, device, seed):
         self.bs, self.n, self.pad32, self.binarize, self.device = bs, n_batches, pad32, binarize, device
         self.gen = torch.Generator().manual_seed(seed)
+        self._seed, self._ctr = int(seed), 0
 
     def __iter__(self):
+        on_gpu = str(self.device).startswith("cuda")
         for _ in range(self.n):
-            raw = torch.rand((self.bs, 1, 28, 28), generator=self.gen)
-            ink = torch.rand((self.bs, 1, 28, 28), generator=self.gen) < 0.15
+            if on_gpu:      # drawn on the device (Philox kernels): the host generator costs 20+ ms per batch and would bound the loop
+                from . import ops
+                shape = (self.bs, 1, 28, 28)
+                nq = (self.bs * 784 + 3) // 4
+                raw = ops.rng_uniform(shape, self._seed, self._ctr, self.device)
+                ink = ops.rng_uniform(shape, self._seed, self._ctr + nq, self.device) < 0.15
+                y = (ops.rng_uniform((self.bs,), self._seed, self._ctr + 2 * nq, self.device) * 10).long().clamp_(0, 9)
+                self._ctr += 2 * nq + (self.bs + 3) // 4
+            else:
+                raw = torch.rand((self.bs, 1, 28, 28), generator=self.gen)
+                ink = torch.rand((self.bs, 1, 28, 28), generator=self.gen) < 0.15
+                y = torch.randint(0, 10, (self.bs,), generator=self.gen)
             x = torch.where(ink, raw, torch.zeros_like(raw))
             x = (x > 0.5).float() if self.binarize else 2 * x - 1          # gms/common.py:105-109
             if self.pad32:
                 x = torch.nn.functional.pad(x, (2, 2, 2, 2))                # :110-111 pads with 0
-            y = torch.randint(0, 10, (self.bs,), generator=self.gen)
             yield x, y
 
     def __len__(self):
