@@ -3,6 +3,7 @@
 scale (north_star), bf16 path 1e-2 of the output scale with inputs pre-rounded to bf16; integer / index work
 (one-hot, masks, sampler select) bit-exact."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -386,3 +387,13 @@ def test_attention_core_ops(ops, dtype):
     Sr = (S_ref.clone()).requires_grad_(True)
     torch.softmax(Sr * scale, -1).backward(dP)
     assert rel_err(dS.float(), Sr.grad) < 2 * TOL[dtype]
+
+
+def test_halo_and_slot_kernels_agree_with_im2col_on_random_shapes():
+    """tools/conv_stress.py: 30 random (B, H, W, cin, upsample, epilogue) problems — tiles spanning images, partial last
+    tiles, single images — run through both LDS-halo kernels, the slot weight-gradient kernel and the im2col kernels."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_stress.py"), "1", "30"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0 and "failures: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
