@@ -397,3 +397,13 @@ def test_halo_and_slot_kernels_agree_with_im2col_on_random_shapes():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_stress.py"), "1", "30"], capture_output=True, text=True,
                        timeout=600, cwd=root)
     assert r.returncode == 0 and "failures: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_groupnorm_kernel_variants_agree_on_random_shapes():
+    """tools/gn_stress.py: 30 random shapes through the register-resident forward / hybrid backward / slab kernels vs the
+    whole-sample streaming kernels, with gradient addends, input addends (xadd) and dropout masks."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gn_stress.py"), "1", "30"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0 and "failures: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
