@@ -126,14 +126,14 @@ def main():
     for _ in range(a.warmup):
         model.train_step(x, y.clone())
     barrier()
-    # per-launch HIP events are taken on every 4th step of the timed region only: each event pair costs the command
+    # per-launch HIP events are taken on every 5th step of the timed region only: each event pair costs the command
     # processor its launch overlap (~3 % of the step when every launch of every step carries one)
     prof = None if a.no_profile else []
     nprof = 0
     t0 = time.perf_counter()
     side = ops.WGRAD_STREAM
     for i in range(a.steps):
-        ops.PROFILE = prof if (prof is not None and i % 4 == 0) else None
+        ops.PROFILE = prof if (prof is not None and i % 5 == 0) else None
         nprof += ops.PROFILE is not None
         # a launch's HIP-event duration is only that kernel's own time if nothing else shares the chip: the profiled steps keep
         # the weight gradients on the main stream (they run ~4 % slower than the other steps, which is inside `value`)
