@@ -179,3 +179,27 @@ def test_mean_types(golden, mt):
         close(zs, g[f"{mt}_ddim_zs"], 5e-5); close(xs, g[f"{mt}_ddim_xs"], 5e-5)
         zs, _, _ = D.sample(q, T(g["init"]), T(g["y"]), 4, "ddim", cond_w=T(g[f"{mt}_cfg_w"]), mean_type=mt)
         close(zs, g[f"{mt}_cfg_zs"], 1e-4)
+
+
+def test_attention_block_definition_matches_sdpa():
+    """The self-attention extension has no reference counterpart: pin the oracle's definition against an independent formulation
+    (torch's scaled_dot_product_attention, single head over all channels) and check that a zero-initialised projection makes the
+    block the identity."""
+    import torch.nn.functional as F
+    C, B, H, W = 128, 2, 8, 8
+    p = U.closed_form_params(C, attention=True)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((B, C, H, W), generator=g)
+    out = U.attention_block(p, x)
+    a = U.gn_silu(x, p["attn.norm.weight"], p["attn.norm.bias"])
+    qkv = F.conv2d(a, p["attn.qkv.weight"], p["attn.qkv.bias"])
+    q, k, v = (t.reshape(B, 1, C, H * W).transpose(2, 3) for t in qkv.chunk(3, dim=1))        # [B, heads=1, N, C]
+    o = F.scaled_dot_product_attention(q, k, v).transpose(2, 3).reshape(B, C, H, W)
+    ref = x + F.conv2d(o, p["attn.proj.weight"], p["attn.proj.bias"])
+    close(out, ref, 2e-5)
+    p0 = dict(p); p0["attn.proj.weight"] = torch.zeros_like(p["attn.proj.weight"]); p0["attn.proj.bias"] = torch.zeros_like(p["attn.proj.bias"])
+    assert torch.equal(U.attention_block(p0, x), x)
+    # the inventory with the extension: 6 more tensors behind `turn`, none without it
+    names = [n for n, _ in U.param_spec(C, attention=True)]
+    assert len(names) == 166 and names.index("attn.norm.weight") == names.index("turn.out_layers.3.bias") + 1
+    assert len(U.param_spec(C)) == 160
