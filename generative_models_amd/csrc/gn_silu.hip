@@ -376,8 +376,8 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
 // registers (ITER x 16 B per thread), x is parked in LDS (HW x 64 B) on its way through the first sweep, and the second sweep
 // reads x from LDS and dy from registers.  HBM: x, dy, addends once + dx once (the streaming kernel reads x and dy twice).
 // 3 workgroups per CU (LDS), thread = (vec = tid & 3, plane = tid >> 2), pixel p = plane + 64 i.
-template <int ITER>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void gn_silu_bwd_hybrid_kernel(
+template <int ITER, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? 3 : 4, 4))) void gn_silu_bwd_hybrid_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ dadd1,
     const bf16_t* __restrict__ dadd2, bf16_t* __restrict__ dx, float* __restrict__ dgp, float* __restrict__ dbp,
@@ -385,7 +385,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     uint64_t drop_off, const float* __restrict__ xadd, int xadd_stride) {
     constexpr int NVEC = 4, CS = 32;
     extern __shared__ __attribute__((aligned(16))) char xs_lds[];        // [HW][4] x 16 B
-    __shared__ float red[4][NVEC][16];
+    constexpr int NW = THREADS / 64, PL = THREADS / 4;      // waves, pixel planes
+    __shared__ float red[NW][NVEC][16];
     __shared__ float chg[CS], chb[CS];
     __shared__ float sA[8], sB[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         for (int u = 0; u < 2; ++u) {
             const int i = i0 + u;
             if (i >= ITER) continue;
-            const int p = pl + 64 * i;
+            const int p = pl + PL * i;
             const bool ok = p < HW;
             xr[u] = ok ? *reinterpret_cast<const u32x4_t*>(x + base + (size_t)p * C) : u32x4_t{0u, 0u, 0u, 0u};
             dr[i] = ok ? *reinterpret_cast<const u32x4_t*>(dy + base + (size_t)p * C) : u32x4_t{0u, 0u, 0u, 0u};
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         for (int u = 0; u < 2; ++u) {
             const int i = i0 + u;
             if (i >= ITER) continue;
-            const int p = pl + 64 * i;
+            const int p = pl + PL * i;
             const bool ok = p < HW;
             if (ok) *reinterpret_cast<u32x4_t*>(xs_lds + ((size_t)p * 4 + vec) * 16) = xr[u];
             float xv[8], dv[8];
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         const int vv = tid >> 3, k = tid & 7;
         float a = 0.f, bb = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { a += red[w][vv][k]; bb += red[w][vv][8 + k]; }
+        for (int w = 0; w < NW; ++w) { a += red[w][vv][k]; bb += red[w][vv][8 + k]; }
         chg[tid] = a; chb[tid] = bb;
         dgp[(size_t)b * C + c0 + tid] = a;
         dbp[(size_t)b * C + c0 + tid] = bb;
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     for (int k = 0; k < 8; ++k) xs[k] = 0.f;
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
-        const int p = pl + 64 * i;
+        const int p = pl + PL * i;
         if (p >= HW) continue;
         const size_t off = base + (size_t)p * C;
         const u32x4_t xr = *reinterpret_cast<const u32x4_t*>(xs_lds + ((size_t)p * 4 + vec) * 16);
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             const int vv = tid >> 3, k = tid & 7;
             float a = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) a += red[w][vv][k];
+            for (int w = 0; w < NW; ++w) a += red[w][vv][k];
             dxsum[(size_t)b * dxsum_stride + c0 + tid] = a;
         }
     }
@@ -949,13 +950,14 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
                 (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2,
                 (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, (unsigned)nbytes);
     } else if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 32 == 0 && 32 % (C / groups) == 0 && HW >= 512 &&
-               HW <= 832 && drop_p == 0.f) {     // measured: -10 % at 28x28; the 16-pixel variant (32x32) spills and is slower
+               HW <= 1024 && drop_p == 0.f) {
         const size_t lds = (size_t)HW * 64;
-#define GMK_GN_BWD_HYB(IT)                                                                                                          \
-    gn_silu_bwd_hybrid_kernel<IT><<<B * (C / 32), 256, lds, gmk_stream(stream)>>>(                                                   \
+#define GMK_GN_BWD_HYB(IT, TH)                                                                                                      \
+    gn_silu_bwd_hybrid_kernel<IT, TH><<<B * (C / 32), TH, lds, gmk_stream(stream)>>>(                                                \
         (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,       \
         dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride)
-        GMK_GN_BWD_HYB(13);
+        if (HW <= 832) GMK_GN_BWD_HYB(13, 256);      // 28x28: 3 workgroups of 4 waves per CU
+        else GMK_GN_BWD_HYB(8, 512);                 // 32x32: 2 workgroups of 8 waves (-13 % against the streaming kernel)
 #undef GMK_GN_BWD_HYB
     } else if (dtype == GMK_BF16) {
         const int CS = gn_slab_channels(gn_mode, C, groups, HW, 2, true);
