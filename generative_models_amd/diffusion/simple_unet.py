@@ -374,17 +374,21 @@ class SimpleUnet(nn.Module):
     def _wgrad(self, dy, srcs, ksize, mode, dw):
         """Weight gradient on the side stream (ops.WGRAD_STREAM): it depends only on dy and the saved activations, so it
         runs beside the data-gradient chain and fills the CUs the persistent kernels' tails leave idle."""
+        self._on_side(lambda: ops.conv_wgrad(dy, srcs, ksize, mode, dw), (dy, *srcs))
+        return dw
+
+    def _on_side(self, fn, tensors):
+        """Run fn() on the side stream, ordered behind everything enqueued so far; `tensors` are the inputs it reads."""
         if not ops.WGRAD_STREAM:
-            return ops.conv_wgrad(dy, srcs, ksize, mode, dw)
+            return fn()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=dy.device)
+            self._side = torch.cuda.Stream(device=tensors[0].device)
         side = self._side
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            ops.conv_wgrad(dy, srcs, ksize, mode, dw)
-        for t in (dy, *srcs):
+            fn()
+        for t in tensors:
             t.record_stream(side)
-        return dw
 
     def _join_side(self):
         if self._side is not None:
@@ -513,7 +517,7 @@ class SimpleUnet(nn.Module):
         o = self._offsets["out.2.weight"]
         nhead = self.in_channels * C * 9
         assert self._offsets["out.2.bias"] == o + (nhead + 3) // 4 * 4 == o + nhead
-        ops.head_wgrad(dout, ao, self.flat_grads[o:o + nhead + self.in_channels])
+        self._on_side(lambda: ops.head_wgrad(dout, ao, self.flat_grads[o:o + nhead + self.in_channels]), (dout, ao))
         dao = ops.head_dgrad(dout, P["out.2.weight"], T)
         s6 = torch.empty((B, C), device=dev, dtype=torch.float32)
         du6, dgp, dbp = ops.gn_silu_bwd(dao, u6, P["out.0.weight"], P["out.0.bias"], mo, ro, dxsum=s6)
@@ -558,7 +562,7 @@ class SimpleUnet(nn.Module):
         ((dt1, s1t),) = self._res_bwd("down.seq.2", ctx, dt2, s2t, demb_all, 1, extra_add=[dt1a])
         ((dt0, s0t),) = self._res_bwd("down.seq.1", ctx, dt1, s1t, demb_all, 0, extra_add=[dt0a])
         ops.colsum(s0t, G["down.seq.0.conv.bias"], defer=True)
-        ops.stem_wgrad(x, dt0, G["down.seq.0.conv.weight"])
+        self._on_side(lambda: ops.stem_wgrad(x, dt0, G["down.seq.0.conv.weight"]), (x, dt0))
         ops.flush_colsums(); self._join_side()
         ready(2)
         self._embed_bwd(ctx, demb_all)
