@@ -754,6 +754,29 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     if (wd) wd[((int64_t)(taps - 1 - tap) * cin + ci) * cout + co] = v;
 }
 
+// every convolution of the net in one launch: entry e packs arena[w_off ..] into packs[f_off ..] / packs[d_off ..]
+struct PackTable {
+    int n;
+    int w_off[40], f_off[40], cout[40], cin[40], taps[40];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const float* __restrict__ arena, T* __restrict__ packs, const PackTable t) {
+    const int e = blockIdx.y;
+    const int cout = t.cout[e], cin = t.cin[e], taps = t.taps[e];
+    const int n = cout * cin * taps;
+    const float* w = arena + t.w_off[e];
+    T* wf = packs + t.f_off[e];
+    T* wd = wf + n;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+        const int tap = idx % taps;
+        const int t2 = idx / taps;
+        const int ci = t2 % cin, co = t2 / cin;
+        const T v = (T)w[idx];
+        wf[(tap * cout + co) * cin + ci] = v;
+        wd[((taps - 1 - tap) * cin + ci) * cout + co] = v;
+    }
+}
+
 int wgrad_nsplit(int64_t n_pixels, int taps, int cout, int ktot, int* chunk) {
     const int64_t tiles = (int64_t)taps * (cout / 128) * (ktot / 128);
     int64_t ns = (1024 + tiles - 1) / tiles;
@@ -796,6 +819,29 @@ extern "C" int gmk_pack_conv_weight(const float* w, void* w_fwd, void* w_dgrad, 
     else
         GMK_REQUIRE(false, "gmk_pack_conv_weight: bad dtype %d", dtype);
     return gmk_check_launch("gmk_pack_conv_weight");
+}
+
+extern "C" int gmk_pack_conv_weights_multi(const float* arena, void* packs, int count, const int* w_off, const int* pack_off,
+                                           const int* cout, const int* cin, const int* ksize, int dtype, void* stream) {
+    GMK_REQUIRE(arena && packs && w_off && pack_off && cout && cin && ksize, "gmk_pack_conv_weights_multi: null pointer");
+    GMK_REQUIRE(count > 0 && count <= 40, "gmk_pack_conv_weights_multi: 1..40 tensors per call, got %d", count);
+    PackTable t;
+    t.n = count;
+    int nmax = 0;
+    for (int e = 0; e < count; ++e) {
+        GMK_REQUIRE(cout[e] > 0 && cin[e] > 0 && (ksize[e] == 1 || ksize[e] == 3) && w_off[e] >= 0 && pack_off[e] >= 0,
+                    "gmk_pack_conv_weights_multi: bad entry %d", e);
+        t.w_off[e] = w_off[e]; t.f_off[e] = pack_off[e]; t.cout[e] = cout[e]; t.cin[e] = cin[e]; t.taps[e] = ksize[e] * ksize[e];
+        const int n = cout[e] * cin[e] * t.taps[e];
+        nmax = n > nmax ? n : nmax;
+    }
+    int bx = (nmax + 255) / 256;
+    if (bx > 256) bx = 256;
+    const dim3 grid(bx, count);
+    if (dtype == GMK_BF16) pack_weights_multi_kernel<bf16_t><<<grid, 256, 0, gmk_stream(stream)>>>(arena, (bf16_t*)packs, t);
+    else if (dtype == GMK_F32) pack_weights_multi_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(arena, (float*)packs, t);
+    else GMK_REQUIRE(false, "gmk_pack_conv_weights_multi: bad dtype %d", dtype);
+    return gmk_check_launch("gmk_pack_conv_weights_multi");
 }
 
 extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1, int B, int hs, int ws, int ho, int wo,

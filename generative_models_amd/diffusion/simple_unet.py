@@ -204,13 +204,16 @@ class SimpleUnet(nn.Module):
             self._pack_buf = torch.empty(total, device=dev, dtype=self.compute_dtype)
             self._packs = {}
             off = 0
+            table = ([], [], [], [], [])
             for n in names:
-                k = math.prod(self._shapes[n + ".weight"])
+                shp = self._shapes[n + ".weight"]
+                k = math.prod(shp)
                 self._packs[n] = (self._pack_buf[off:off + k], self._pack_buf[off + k:off + 2 * k])
+                for col, v in zip(table, (self._offsets[n + ".weight"], off, shp[0], shp[1], shp[2])):
+                    col.append(v)
                 off += 2 * k
-        for n in names:
-            wf, wd = self._packs[n]
-            ops.pack_conv_weight(self._pv[n + ".weight"], wf, wd)
+            self._pack_table = table
+        ops.pack_conv_weights_multi(self.flat_params, self._pack_buf, self._pack_table)      # all convolutions, one launch
         self._packs_stale = False
 
     # ---- embedding path (simple_unet.py:45-64 + the 12 emb_layers of :166) --------------------------------

@@ -90,6 +90,16 @@ def pack_conv_weight(w, w_fwd, w_dgrad):
     check(lib.gmk_pack_conv_weight(_p(w), _p(w_fwd), _p(w_dgrad), cout, cin, k, _DT[ref.dtype], _s()), "pack_conv_weight")
 
 
+def pack_conv_weights_multi(arena, packs, table):
+    """One launch for every convolution of the net.  table = (w_off, pack_off, cout, cin, ksize) host int lists: tensor e is
+    arena[w_off[e]:...] (fp32 [cout][cin][k][k]) -> packs[pack_off[e]:...] = [w_fwd | w_dgrad]."""
+    import ctypes
+    _f32(arena, "arena"); _chk(packs, name="packs")
+    n = len(table[0])
+    arrs = [(ctypes.c_int * n)(*[int(v) for v in col]) for col in table]
+    check(lib.gmk_pack_conv_weights_multi(_p(arena), _p(packs), n, *arrs, _DT[packs.dtype], _s()), "pack_conv_weights_multi")
+
+
 # ---- GroupNorm + SiLU ------------------------------------------------------------------------------------
 # Let producing convolutions emit GroupNorm statistics from their epilogue (gmk_conv_igemm gn_stats).  OFF by default:
 # measured on MI355X the DPP reductions in the conv epilogue cost as much as the statistics pass they save (27.25 vs

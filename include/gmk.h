@@ -51,6 +51,11 @@ int64_t gmk_conv_wgrad_workspace_bytes(int64_t n_pixels, int taps, int cout, int
  * either output may be NULL. */
 int gmk_pack_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int cout, int cin, int ksize, int dtype,
                          void* stream);
+/* the same for up to 40 convolutions in ONE launch (the re-pack after every optimiser step): tensor e is the fp32
+ * weight at arena + w_off[e] (elements) and is written as [w_fwd | w_dgrad], n = cout*cin*ksize^2 elements each, at
+ * packs + pack_off[e] (elements of `dtype`).  The five tables are HOST arrays of `count` ints. */
+int gmk_pack_conv_weights_multi(const float* arena, void* packs, int count, const int* w_off, const int* pack_off,
+                                const int* cout, const int* cin, const int* ksize, int dtype, void* stream);
 
 /* ---- GroupNorm + SiLU (simple_unet.py:39-40,161-162,169-170; always adjacent in the reference) ---------
  * x,y: NHWC [B][HW][C]; `groups` groups over these C channels (a 2C-channel concatenated input is handled as
