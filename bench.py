@@ -99,11 +99,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("GMK_DIST_BACKEND", "nccl") != "nccl":
+        local = local % max(1, torch.cuda.device_count())              # rehearsal: several ranks may share a GPU
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GMK_DIST_BACKEND", "nccl")       # "gloo": rehearsal of the N > 1 path on one GPU (tests)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from generative_models_amd import common, ops, parallel

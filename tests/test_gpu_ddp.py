@@ -68,3 +68,21 @@ def test_two_rank_step_equals_single_rank(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="2"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_two_ranks_rehearsal():
+    """The driver's scaling command line (torch.distributed.run ... bench.py --gpus N) with N = 2 ranks sharing this GPU over
+    gloo (RCCL refuses two ranks on one device): barrier, bucketed all-reduce from inside backward, max-over-ranks timing,
+    one JSON line from rank 0 with the whole-job rate."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64",
+           "--sampler_steps", "2", "--no_cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, GMK_DIST_BACKEND="gloo", OMP_NUM_THREADS="2"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["value"] > 0 and "cpu_baseline" not in d and d["roofline"]["kernel"].startswith("conv")
