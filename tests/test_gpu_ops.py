@@ -407,3 +407,25 @@ def test_groupnorm_kernel_variants_agree_on_random_shapes():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gn_stress.py"), "1", "30"], capture_output=True, text=True,
                        timeout=600, cwd=root)
     assert r.returncode == 0 and "failures: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_pack_multi_equals_single(ops):
+    """gmk_pack_conv_weights_multi (one launch for a table of convolutions) == gmk_pack_conv_weight per tensor, both dtypes."""
+    g = torch.Generator().manual_seed(3)
+    shapes = [(128, 128, 3, 3), (128, 256, 1, 1), (384, 128, 1, 1), (128, 256, 3, 3)]
+    sizes = [math.prod(s) for s in shapes]
+    pad = lambda n: (n + 3) // 4 * 4
+    offs, o = [], 5 * 4
+    for n in sizes:
+        offs.append(o); o += pad(n) + 8
+    arena = torch.randn(o, generator=g).cuda()
+    for dtype in DTYPES:
+        packs = torch.zeros(2 * sum(sizes), device="cuda", dtype=dtype)
+        poffs, po = [], 0
+        for n in sizes:
+            poffs.append(po); po += 2 * n
+        ops.pack_conv_weights_multi(arena, packs, (offs, poffs, [s[0] for s in shapes], [s[1] for s in shapes], [s[2] for s in shapes]))
+        for shp, n, wo, pofs in zip(shapes, sizes, offs, poffs):
+            wf = torch.empty(n, device="cuda", dtype=dtype); wd = torch.empty_like(wf)
+            ops.pack_conv_weight(arena[wo:wo + n].view(shp), wf, wd)
+            assert torch.equal(packs[pofs:pofs + n], wf) and torch.equal(packs[pofs + n:pofs + 2 * n], wd)
