@@ -146,8 +146,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
         v[i] = j < N ? s[j] * scale : -INFINITY;
         mx = fmaxf(mx, v[i]);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    mx = wave_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {

@@ -117,9 +117,48 @@ __device__ __forceinline__ void philox4x32(uint64_t ctr, uint64_t seed, uint32_t
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // [0, 1)
 
 
-// 64-lane wave sum (butterfly; every lane ends with the total)
-__device__ __forceinline__ float wave_sum(float v) {
+// Cross-lane steps WITHOUT ds_bpermute.  `__shfl_xor` lowers to ds_bpermute_b32, which runs through the LDS crossbar; on MI355X
+// a wave reduction built on it returned wrong partial sums (about once per few thousand workgroups) whenever workgroups of a
+// second kernel with heavy ds_write_b128 traffic were resident on the same CU from another HIP stream (tools/side_stream_det.py
+// is the reproducer).  DPP inside a 16-lane row and v_permlane{16,32}_swap across rows never touch the
+// LDS pipeline, pair the same lanes as the xor butterfly (bit-identical sums), and are faster.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// a <- [r0 r0 r2 r2], b <- [r1 r1 r3 r3] for a == b == [r0 r1 r2 r3] (16-lane rows): (a, b) is the lane's {own, lane^16} pair in
+// some order.  Inline asm: given the same value for both operands the builtin's two results are folded into one register.
+__device__ __forceinline__ void rows_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+// a <- [lo lo], b <- [hi hi] for a == b == [lo hi] (32-lane halves)
+__device__ __forceinline__ void halves_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+
+// sum over the lanes whose index differs in bits >= log2(FROM) (FROM = 1: whole wave; FROM = 8: lanes sharing lane & 7); every
+// lane ends with its total.  Same pairing as the butterfly `for off = 32 .. FROM: v += shfl_xor(v, off)`.
+template <int FROM>
+__device__ __forceinline__ float lanes_sum_from(float v) {
+#ifdef GMK_SHFL_BPERMUTE          // the ds_bpermute butterfly, kept only to reproduce the fault described above
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    for (int off = 32; off >= FROM; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+#endif
+    float a = v, b = v;
+    halves_swap32(a, b); v = a + b;
+    a = v; b = v;
+    rows_swap16(a, b); v = a + b;
+    if (FROM <= 8) v += dpp_f32<0x128>(v);      // row_ror:8   (lane ^ 8)
+    if (FROM <= 4) v += dpp_f32<0x124>(v);      // row_ror:4   (lane ^ 4 up to the halves made equal by the step before)
+    if (FROM <= 2) v += dpp_f32<0x4E>(v);       // quad_perm [2,3,0,1]
+    if (FROM <= 1) v += dpp_f32<0xB1>(v);       // quad_perm [1,0,3,2]
+    return v;
+}
+// 64-lane wave sum / max (every lane ends with the result)
+__device__ __forceinline__ float wave_sum(float v) { return lanes_sum_from<1>(v); }
+__device__ __forceinline__ float wave_max(float v) {
+    float a = v, b = v;
+    halves_swap32(a, b); v = fmaxf(a, b);
+    a = v; b = v;
+    rows_swap16(a, b); v = fmaxf(a, b);
+    v = fmaxf(v, dpp_f32<0x128>(v)); v = fmaxf(v, dpp_f32<0x124>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v)); v = fmaxf(v, dpp_f32<0xB1>(v));
     return v;
 }

@@ -281,11 +281,7 @@ __device__ __forceinline__ void unpack8(const u32x4_t r, float (&v)[8]) {
 
 // sum over the lanes of a wave that share (lane & (NVEC-1)); every such lane ends with the total
 template <int NVEC>
-__device__ __forceinline__ float vec_lane_sum(float v) {
-#pragma unroll
-    for (int off = NVEC; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float vec_lane_sum(float v) { return lanes_sum_from<NVEC>(v); }
 
 template <int ITER, int NVEC>
 __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,

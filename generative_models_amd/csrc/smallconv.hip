@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a, 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) d = fmaf(v[i], wr[t][i], d);
                 d = row16_sum(d);
-                if (nvec == 32) d += __shfl_xor(d, 16, 64);
+                if (nvec == 32) { float d2 = d; rows_swap16(d, d2); d += d2; }      // lane ^ 16, off the LDS crossbar
                 if (vec == t) mine = d;
             }
             if (vec < 9 && q < next) tapl[vec * plane + q] = mine;

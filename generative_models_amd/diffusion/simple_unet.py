@@ -295,6 +295,11 @@ class SimpleUnet(nn.Module):
         P, C = self._pv, self.channels
         B, H, W, _ = srcs[0].shape
         gpc = 32 // len(srcs)                                    # GroupNorm(32, cin): 16 groups per 128-ch source
+        skip = {}
+        if len(srcs) == 2:      # the 1x1 skip convolution (HBM-bound) only needs the block input: it runs on the side stream beside
+            wfs, _ = self._packs[f"{name}.skip_connection"]      # GroupNorm / conv1 / GroupNorm and is joined in front of conv2
+            self._on_side(lambda: skip.__setitem__("res", ops.conv_igemm(srcs, wfs, C, 1, ops.NORMAL, (H, W),
+                                                                           bias=P[f"{name}.skip_connection.bias"])), tuple(srcs))
         a, stats1 = [], []
         for i, s in enumerate(srcs):
             g = P[f"{name}.in_layers.0.weight"][i * C:(i + 1) * C]
@@ -311,8 +316,9 @@ class SimpleUnet(nn.Module):
         a2, mean2, rstd2 = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], 32, dropout=drop,
                                            xadd=eadd)
         if len(srcs) == 2:
-            wfs, _ = self._packs[f"{name}.skip_connection"]
-            res = ops.conv_igemm(srcs, wfs, C, 1, ops.NORMAL, (H, W), bias=P[f"{name}.skip_connection.bias"])
+            self._join_side()
+            res = skip["res"]
+            res.record_stream(torch.cuda.current_stream())      # allocated on the side stream, consumed here
         else:
             res = srcs[0]
         wf2, _ = self._packs[f"{name}.out_layers.3"]
