@@ -207,6 +207,27 @@ def main():
                "batch_per_gpu": a.batch, "mode": "ddim, guidance off, 1 U-Net forward per step",
                "timed_steps": a.sampler_steps}
 
+    def time_sampler(kind, cond_w):              # the other two modes of SURVEY M1(ii), same batch and step count
+        model.diffusion.sampler = kind
+        run = lambda: model.diffusion.sample(net=partial(model.net, guide=y), init_x=init, cond_w=cond_w, record=False)
+        run()
+        barrier()
+        t0 = time.perf_counter()
+        run()
+        barrier()
+        t = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([t], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt)
+        return round(a.sampler_steps / t, 2)
+
+    if a.sampler_steps > 0:
+        sampler["other_modes_steps_per_sec"] = {
+            "ddim, guidance on (the `sample` path: conditional + unconditional forward per step)": time_sampler("ddim", 0.5),
+            "noisy (ancestral), guidance off": time_sampler("noisy", None)}
+        model.diffusion.sampler = "ddim"
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         cpu = cpu_baseline(a.cpu_seconds, a.size, a.in_channels)

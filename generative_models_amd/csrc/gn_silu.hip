@@ -368,6 +368,21 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
 // 30-60 % SLOWER than the streaming backward: it needs 188 VGPRs at 8 pixels per thread (one workgroup per CU) or spills at
 // 128, and it recomputes the sigmoid in both sweeps.  Removed; the streaming kernel with 32-channel slabs stays.)
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// the two bf16 of one dword as a float pair (low half first)
+__device__ __forceinline__ f32x2_t unpack2(unsigned r) {
+    return f32x2_t{__builtin_bit_cast(float, r << 16), __builtin_bit_cast(float, r & 0xFFFF0000u)};
+}
+// d/dg [g * sigmoid(g)] * dy for a channel pair, g = fma(x, s, t): 6 packed ops + 2 x (v_exp_f32, v_rcp_f32)
+__device__ __forceinline__ f32x2_t silu_grad2(f32x2_t x, f32x2_t dy, f32x2_t s, f32x2_t t, float neg_log2e) {
+    const f32x2_t g = __builtin_elementwise_fma(x, s, t);
+    const f32x2_t g2 = g * neg_log2e;
+    const f32x2_t den = f32x2_t{__builtin_amdgcn_exp2f(g2[0]), __builtin_amdgcn_exp2f(g2[1])} + 1.0f;
+    const f32x2_t sg = f32x2_t{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const f32x2_t u = dy * sg;
+    return __builtin_elementwise_fma(u, __builtin_elementwise_fma(-g, sg, g), u);
+}
+
 // Backward with the tensor read once: one workgroup (256 threads) = one (sample, 32-channel slab); dy stays PACKED in
 // registers (ITER x 16 B per thread), x is parked in LDS (HW x 64 B) on its way through the first sweep, and the second sweep
 // reads x from LDS and dy from registers.  HBM: x, dy, addends once + dx once (the streaming kernel reads x and dy twice).
@@ -393,19 +408,29 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
     const size_t base = (size_t)b * HW * C + c0 + vec * 8;
     const int glo = (vec * 8) / cpg, ghi = (vec * 8 + 4) / cpg;
     const float rs0 = rstd[b * G + g0 + glo], rs1 = rstd[b * G + g0 + ghi];
-    float gam[8], gb[8], mu[8];
+    // Per-channel constants that turn both sweeps into chains of (packed) FMAs:
+    //   g  = gamma * (x - mu) * rstd + beta        = fma(x, s, t)          s = rstd * gamma, t = beta - mu * s
+    //   dg = dy * sig(g) * (1 + g * (1 - sig(g)))  = fma(u, fma(-g, sg, g), u),  u = dy * sg
+    //   sum_x dg * xhat                            = rstd * (sum dg * x - mu * sum dg)   (accumulated as sum dg * x)
+    //   dx = rstd * (dg * gamma - cA - xhat * cB)  = fma(dg, s, fma(x, nP, q)),   nP = -rstd^2 cB, q = mu rstd^2 cB - rstd cA
+    // the channel pairs (2j, 2j+1) of a thread's 16-byte vector are carried as float2 so the compiler emits v_pk_*_f32.
+    f32x2_t sv[4], tv[4], muv[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int c = c0 + vec * 8 + k;
-        gam[k] = gamma[c];
-        gb[k] = beta[c];
-        // x enters as x + xadd[b][c]: fold the addend into the mean that is subtracted
-        mu[k] = mean[b * G + g0 + (k < 4 ? glo : ghi)] - (xadd ? xadd[(size_t)b * xadd_stride + c] : 0.f);
+    for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = 2 * jj + e, c = c0 + vec * 8 + k;
+            // x enters as x + xadd[b][c]: fold the addend into the mean that is subtracted
+            const float m = mean[b * G + g0 + (k < 4 ? glo : ghi)] - (xadd ? xadd[(size_t)b * xadd_stride + c] : 0.f);
+            const float sc = (k < 4 ? rs0 : rs1) * gamma[c];
+            muv[jj][e] = m; sv[jj][e] = sc; tv[jj][e] = beta[c] - m * sc;
+        }
     }
+    constexpr float kNegLog2e = -1.4426950408889634f;
     u32x4_t dr[ITER];
-    float ag[8], ab[8];
+    f32x2_t ax[4], ab[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { ag[k] = 0.f; ab[k] = 0.f; }
+    for (int jj = 0; jj < 4; ++jj) { ax[jj] = f32x2_t{0.f, 0.f}; ab[jj] = f32x2_t{0.f, 0.f}; }
     // chunks of 2 pixels: 4 independent 16-B loads in flight per thread, then their arithmetic; the fence keeps the
     // scheduler from hoisting every load of the sweep to the top (26 x 4 VGPRs)
 #pragma unroll
@@ -418,36 +443,41 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
             const int p = pl + PL * i;
             const bool ok = p < HW;
             xr[u] = ok ? *reinterpret_cast<const u32x4_t*>(x + base + (size_t)p * C) : u32x4_t{0u, 0u, 0u, 0u};
-            dr[i] = ok ? *reinterpret_cast<const u32x4_t*>(dy + base + (size_t)p * C) : u32x4_t{0u, 0u, 0u, 0u};
+            dr[i] = ok ? *reinterpret_cast<const u32x4_t*>(dy + base + (size_t)p * C) : u32x4_t{0u, 0u, 0u, 0u};     // dy = 0 masks the pixel
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = i0 + u;
             if (i >= ITER) continue;
             const int p = pl + PL * i;
-            const bool ok = p < HW;
-            if (ok) *reinterpret_cast<u32x4_t*>(xs_lds + ((size_t)p * 4 + vec) * 16) = xr[u];
-            float xv[8], dv[8];
-            unpack8(xr[u], xv); unpack8(dr[i], dv);
+            if (p < HW) *reinterpret_cast<u32x4_t*>(xs_lds + ((size_t)p * 4 + vec) * 16) = xr[u];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float xh = (xv[k] - mu[k]) * (k < 4 ? rs0 : rs1);
-                const float g = fmaf(xh, gam[k], gb[k]);
-                const float sg = sigmoidf_(g);
-                const float dg = ok ? dv[k] * sg * (1.f + g * (1.f - sg)) : 0.f;
-                ag[k] = fmaf(dg, xh, ag[k]);
-                ab[k] += dg;
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x2_t xv = unpack2(xr[u][jj]), dv = unpack2(dr[i][jj]);
+                const f32x2_t dg = silu_grad2(xv, dv, sv[jj], tv[jj], kNegLog2e);
+                ax[jj] = __builtin_elementwise_fma(dg, xv, ax[jj]);
+                ab[jj] += dg;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < ITER; ++i) asm volatile("" : "+v"(dr[i]));          // stay packed across the reduction
+    float ag[8], abk[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { ag[k] = vec_lane_sum<NVEC>(ag[k]); ab[k] = vec_lane_sum<NVEC>(ab[k]); }
+    for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = 2 * jj + e;
+            abk[k] = ab[jj][e];
+            ag[k] = (ax[jj][e] - muv[jj][e] * ab[jj][e]) * (k < 4 ? rs0 : rs1);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ag[k] = vec_lane_sum<NVEC>(ag[k]); abk[k] = vec_lane_sum<NVEC>(abk[k]); }
     if (lane < NVEC) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { red[wave][lane][k] = ag[k]; red[wave][lane][8 + k] = ab[k]; }
+        for (int k = 0; k < 8; ++k) { red[wave][lane][k] = ag[k]; red[wave][lane][8 + k] = abk[k]; }
     }
     __syncthreads();
     if (tid < CS) {
@@ -471,7 +501,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
         sA[tid] = A * inv_n; sB[tid] = Bq * inv_n;
     }
     __syncthreads();
-    const float cA0 = sA[glo], cA1 = sA[ghi], cB0 = sB[glo], cB1 = sB[ghi];
+    f32x2_t npv[4], qv[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const float rsk = jj < 2 ? rs0 : rs1, cA = jj < 2 ? sA[glo] : sA[ghi], cB = jj < 2 ? sB[glo] : sB[ghi];
+        const float r2b = rsk * rsk * cB;
+        npv[jj] = f32x2_t{-r2b, -r2b};
+        qv[jj] = muv[jj] * r2b - rsk * cA;
+    }
     float xs[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) xs[k] = 0.f;
@@ -481,16 +518,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
         if (p >= HW) continue;
         const size_t off = base + (size_t)p * C;
         const u32x4_t xr = *reinterpret_cast<const u32x4_t*>(xs_lds + ((size_t)p * 4 + vec) * 16);
-        float xv[8], dv[8], o[8];
-        unpack8(xr, xv); unpack8(dr[i], dv);
+        float o[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float rsk = k < 4 ? rs0 : rs1;
-            const float xh = (xv[k] - mu[k]) * rsk;
-            const float g = fmaf(xh, gam[k], gb[k]);
-            const float sg = sigmoidf_(g);
-            const float dg = dv[k] * sg * (1.f + g * (1.f - sg));
-            o[k] = rsk * (dg * gam[k] - (k < 4 ? cA0 : cA1) - xh * (k < 4 ? cB0 : cB1));
+        for (int jj = 0; jj < 4; ++jj) {
+            const f32x2_t xv = unpack2(xr[jj]), dv = unpack2(dr[i][jj]);
+            const f32x2_t dg = silu_grad2(xv, dv, sv[jj], tv[jj], kNegLog2e);
+            const f32x2_t ov = __builtin_elementwise_fma(dg, sv[jj], __builtin_elementwise_fma(xv, npv[jj], qv[jj]));
+            o[2 * jj] = ov[0]; o[2 * jj + 1] = ov[1];
         }
         if (dadd1) {
             float t[8];
