@@ -1,8 +1,11 @@
 // Weight gradient of the 3x3 stride-1 convolutions as a 1-D correlation over padded "slots" (bf16, MFMA).
 // Reference: the autograd backward of nn.Conv2d(C, C, 3, padding=1) at gms/diffusion/simple_unet.py:163,172,117.
 //
-// Every image is viewed with its zero border: (H+2) x (W+2) slots, slot S = (b*(H+2) + ye)*(W+2) + xe.  With that
-// padding a filter tap is a CONSTANT slot offset off = (ky-1)*(W+2) + (kx-1), and
+// Every image is viewed with a zero border above and to its left: (H+1) x (W+1) slots, slot S = (b*(H+1) + ye)*(W+1) + xe,
+// pixel (y, x) at (ye, xe) = (y+1, x+1).  The border is SHARED: the slot right of a row's last pixel is the next row's
+// border slot, the row below an image is the next image's border row (beyond the last image: out of range = zero) - 841
+// instead of 900 slots per 28x28 image, 225 instead of 256 at 14x14, 64 instead of 81 at 7x7.  With that padding a filter
+// tap is a CONSTANT slot offset off = (ky-1)*(W+1) + (kx-1), and
 //     dW[tap][co][ci] = sum_S dY[S][co] * X[S + off][ci]          (dY and X read 0 in border slots)
 // i.e. one long GEMM-like reduction over S in which the 9 taps reuse the same streamed data: each dY / X slot
 // enters LDS exactly once per workgroup (the im2col formulation re-gathers X once per tap and is bound by the
@@ -25,8 +28,8 @@ namespace {
 
 constexpr int kDyBase = 0;                  // 3 x 16 KiB
 constexpr int kXBase = 49152;               // 512-slot ring + mirror of its first LOOK*128 slots, 128 B per slot
-// LOOK = 1: taps reach at most 64 slots (W <= 61): X chunks c-1..c+1 are live, 128 mirrored slots (136 KiB of LDS).
-// LOOK = 2: taps reach up to 128 slots (W <= 125, e.g. 64x64 images): chunks c-2..c+2, 256 mirrored slots (152 KiB).
+// LOOK = 1: taps reach at most 64 slots (W <= 62): X chunks c-1..c+1 are live, 128 mirrored slots (136 KiB of LDS).
+// LOOK = 2: taps reach up to 128 slots (W <= 126, e.g. 64x64 images): chunks c-2..c+2, 256 mirrored slots (152 KiB).
 template <int LOOK> struct SlotLds {
     static constexpr int kMirrorSlots = LOOK * 128;
     static constexpr int kScratch = kXBase + (512 + kMirrorSlots) * 128;    // 8 x 1 KiB sink for the dummy DMA of steps without a mirror copy
@@ -37,7 +40,7 @@ struct SlotParams {
     const void* dy; int dy_cstride;
     const void* src0; const void* src1;
     int c0, c1, ktot, cout;
-    int B, H, W, WE;
+    int B, H, W, WE, RE;         // WE = W + 1 slots per row, RE = H + 1 rows per image (borders shared, see the header)
     int xshift;                  // 1: X is the half-resolution tensor (nearest x2 upsample folded into the gather)
     float* slab;                 // [nsplit][9][cout][ktot]
     int nchunks, chunks_per_split;
@@ -46,18 +49,18 @@ struct SlotParams {
 
 struct SlotPos { int b, ye, xe; };
 
-__device__ __forceinline__ SlotPos slot_decode(int S, int H, int WE) {
+__device__ __forceinline__ SlotPos slot_decode(int S, int RE, int WE) {
     SlotPos p;
     const int rowi = S / WE;
     p.xe = S - rowi * WE;
-    p.b = rowi / (H + 2);
-    p.ye = rowi - p.b * (H + 2);
+    p.b = rowi / RE;
+    p.ye = rowi - p.b * RE;
     return p;
 }
-__device__ __forceinline__ void slot_advance(SlotPos& p, int dxe, int dye, int H, int WE) {   // by a fixed slot count
+__device__ __forceinline__ void slot_advance(SlotPos& p, int dxe, int dye, int RE, int WE) {   // by a fixed slot count, dxe < WE
     p.xe += dxe; p.ye += dye;
     if (p.xe >= WE) { p.xe -= WE; ++p.ye; }
-    if (p.ye >= H + 2) { p.ye -= H + 2; ++p.b; }
+    while (p.ye >= RE) { p.ye -= RE; ++p.b; }      // small images: 64 slots can span more than one image
 }
 
 template <int LOOK>
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_kernel(const SlotPara
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wc = wave >> 1, wi = wave & 1;
-    const int H = p.H, W = p.W, WE = p.WE;
+    const int H = p.H, W = p.W, WE = p.WE, RE = p.RE;
     const int cis = blockIdx.y, cob = blockIdx.z;
     const int c_begin = blockIdx.x * p.chunks_per_split;
     const int c_end = min(c_begin + p.chunks_per_split, p.nchunks);
@@ -106,14 +109,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_kernel(const SlotPara
     // trackers: slot of this lane in the next X chunk / dY chunk to be issued
     int xc = c_begin - LOOK;                      // next X chunk index to issue
     int yc = c_begin;                             // next dY chunk index to issue
-    SlotPos xpos = slot_decode(64 * max(xc, 0) + 8 * wave + (lane >> 3), H, WE);
-    SlotPos ypos = slot_decode(64 * yc + 8 * wave + (lane >> 4), H, WE);
+    SlotPos xpos = slot_decode(64 * max(xc, 0) + 8 * wave + (lane >> 3), RE, WE);
+    SlotPos ypos = slot_decode(64 * yc + 8 * wave + (lane >> 4), RE, WE);
 
     auto issue_x = [&]() {
         unsigned pix = kBadPix;
         if (xc >= 0) {
             pix = xpix_of(xpos);
-            slot_advance(xpos, dxe64, dye64, H, WE);
+            slot_advance(xpos, dxe64, dye64, RE, WE);
         }
         const unsigned voff = __umul24(pix, xs_b) + xoff_b + x_lc;
         const int rp = xc & 7;
@@ -129,9 +132,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_kernel(const SlotPara
     int yslot3 = 0;                               // yc % 3 of the next dY chunk to issue
     auto issue_y = [&]() {
         SlotPos s1 = ypos;                        // the lane's slot of instruction i = 1 is 4 slots further
-        slot_advance(s1, 4, 0, H, WE);
+        slot_advance(s1, 4, 0, RE, WE);
         const unsigned p0 = pix_of(ypos), p1 = pix_of(s1);
-        slot_advance(ypos, dxe64, dye64, H, WE);
+        slot_advance(ypos, dxe64, dye64, RE, WE);
         GMK_LDS char* dst = (GMK_LDS char*)(smem + kDyBase + yslot3 * 16384 + wave * 2048);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (GMK_LDS void*)dst, 16, __umul24(p0, ys_b) + yoff_b + y_lc, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (GMK_LDS void*)(dst + 1024), 16, __umul24(p1, ys_b) + yoff_b + y_lc, 0, 0,
@@ -220,12 +223,11 @@ int gmk_wgrad_slots_nsplit(int cout, int ktot) {
 int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B, int H,
                              int W, int cout, float* slab, int64_t slab_bytes, int forced, int upsample, hipStream_t stream) {
     if (c0 % 64 || c1 % 64 || cout % 128) return 0;
-    const int WE = W + 2;
+    const int WE = W + 1, RE = H + 1;
     if (WE + 1 > 128 || W < 4 || H < 2) return 0;
     const bool wide = WE + 1 > 64;
-    if (64 / WE >= H + 2) return 0;                         // slot_advance assumes at most one image wrap per 64 slots
     const int64_t M = (int64_t)B * H * W;
-    const int64_t total = (int64_t)B * (H + 2) * WE;
+    const int64_t total = (int64_t)B * RE * WE;              // the last image's lower border lies beyond: b == B reads as zero
     if (M >= 0x00FFFFFF || total >= (1ll << 30)) return 0;
     if (upsample && ((H | W) & 1)) return 0;
     const int64_t Msrc = upsample ? M / 4 : M;
@@ -245,7 +247,7 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
     SlotParams p;
     p.dy = dy; p.dy_cstride = dy_cstride; p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.ktot = ktot; p.cout = cout;
     p.xshift = upsample ? 1 : 0;
-    p.B = B; p.H = H; p.W = W; p.WE = WE; p.slab = slab; p.nchunks = nchunks; p.chunks_per_split = cps;
+    p.B = B; p.H = H; p.W = W; p.WE = WE; p.RE = RE; p.slab = slab; p.nchunks = nchunks; p.chunks_per_split = cps;
     p.nbdy = (unsigned)nbdy; p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1;
     dim3 grid(ns, ktot / 64, cout / 128);
     if (wide) conv_wgrad_slots_kernel<2><<<grid, 512, 0, stream>>>(p);
