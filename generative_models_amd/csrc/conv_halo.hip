@@ -44,6 +44,7 @@ struct HaloParams {
     int c0, c1, ktot;
     int B, H, W, WE, R, TP, ntiles, rows_total;
     int shift;                                 // 1: the source is the half-resolution tensor (nearest x2 upsample folded in)
+    int pmask;                                 // 1 (with shift = 1): only even (y, x) exist - the zero-stuffed source of a transposed conv
     const void* w; unsigned w_tap_stride_b; int n0;
     const float* bias; const float* emb; int emb_stride;
     const void* residual; void* out; int out_cstride; int M;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
             const int x = xe - 1;
             const int b = b0 + k;
             const bool ok = exists && y >= 0 && y < H && x >= 0 && x < W && b < p.B;
-            hpix[j] = ok ? (unsigned)((b * (H >> p.shift) + (y >> p.shift)) * (W >> p.shift) + (x >> p.shift)) : kBadPix;
+            hpix[j] = ok && !((y | x) & p.pmask) ? (unsigned)((b * (H >> p.shift) + (y >> p.shift)) * (W >> p.shift) + (x >> p.shift)) : kBadPix;
             er += f_der; xe += f_dxe;
             if (xe >= WE) { xe -= WE; ++er; }
         }
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 const int x = xe - 1;
                 const int b = b0 + k;
                 const bool ok = exists && y >= 0 && y < H && x >= 0 && x < W && b < p.B;
-                const unsigned pix = ok ? (unsigned)((b * (H >> p.shift) + (y >> p.shift)) * (W >> p.shift) + (x >> p.shift)) : kBadPix;
+                const unsigned pix = ok && !((y | x) & p.pmask) ? (unsigned)((b * (H >> p.shift) + (y >> p.shift)) * (W >> p.shift) + (x >> p.shift)) : kBadPix;
                 hpix[j][u] = pix | ((unsigned)(lch ^ ((n >> 1) & 7)) << 24);
             }
         };
@@ -878,7 +879,7 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     if (ntiles < min_tiles) return 0;                         // not enough tiles to fill the chip: im2col kernels
     HaloParams p;
     p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.ktot = c0 + c1;
-    p.shift = upsample ? 1 : 0;
+    p.shift = upsample ? 1 : 0; p.pmask = upsample == 2 ? 1 : 0;      // upsample: 1 nearest x2, 2 zero-stuffed x2 (transposed conv)
     p.B = B; p.H = H; p.W = W; p.WE = W + 2; p.R = R; p.TP = TP; p.ntiles = (int)ntiles; p.rows_total = (int)rows_total;
     p.w = w; p.w_tap_stride_b = (unsigned)w_rows * (unsigned)(c0 + c1) * 2u; p.n0 = n0;
     p.bias = bias; p.emb = emb; p.emb_stride = emb_stride; p.residual = residual; p.out = out; p.out_cstride = out_cstride;
