@@ -167,6 +167,7 @@ def main():
         dom = max(by, key=lambda k: by[k][0])          # dominant kernel = largest total HIP-event time
         desc = {"conv3x3_halo_ws_kernel": "3x3 stride-1 bf16 convolution, LDS-resident halo, wave-specialised (forward + data gradients)",
                 "conv3x3_halo_kernel": "3x3 stride-1 bf16 convolution, LDS-resident halo (forward + data gradients)",
+                "conv3x3_halo_ws_kernel[zero-stuffed transposed conv]": "data gradient of the stride-2 convs = the same kernel on the zero-stuffed gradient (2 launches/step; algorithmic FLOPs are 1/4 of its MFMA work)",
                 "conv_igemm_dma_kernel": "im2col LDS-DMA convolution (1x1, strided, upsampled, fp32)",
                 "conv_igemm_kernel": "im2col register-staged convolution (small problems)",
                 "conv_wgrad_slots_kernel": "3x3 weight gradient over padded slots (+ slab reduce)",

@@ -890,7 +890,7 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
                                             out, out_cstride, force == 3 ? 1 : 32, stuffed ? 2 : mode == GMK_CONV_UPSAMPLE2, gn_stats,
                                             gn_stats_bytes, gmk_stream(stream));
         if (rc == 1 || rc == 2) {
-            gmk_note_kernel(rc == 2 ? 4 : 3);
+            gmk_note_kernel(stuffed ? 5 : rc == 2 ? 4 : 3);       // 5: a halo kernel on the zero-stuffed source (transposed conv)
             return gmk_check_launch("gmk_conv_igemm(halo)");
         }
     }

@@ -330,6 +330,37 @@ def test_forced_kernel_variants_agree_with_torch(ops, two, S, B, mode):
         lib.gmk_set_dev_variant(0)
 
 
+@pytest.mark.parametrize("S,B", [(28, 3), (14, 5), (32, 2), (64, 1), (8, 37)])
+def test_transposed_dgrad_on_halo_kernels(ops, S, B):
+    """Data gradient of the stride-2 conv: at full size it runs on the halo kernels as a 3x3 conv of the zero-stuffed gradient
+    (kernel id 5).  Force that path on small problems (tiles spanning several images at 8x8 / 14x14) and compare with autograd
+    and with the im2col gather it replaces."""
+    from generative_models_amd._lib import lib
+    dtype, C = torch.bfloat16, 128
+    x = q(rnd(B, C, S, S, seed=140), dtype).requires_grad_(True)
+    w = q(rnd(C, C, 3, 3, seed=141) / math.sqrt(C * 9), dtype).requires_grad_(True)
+    out_ref = F.conv2d(x, w, None, stride=2, padding=1)
+    dy = q(rnd(*out_ref.shape, seed=142), dtype)
+    out_ref.backward(dy)
+    wf = torch.empty(w.numel(), device="cuda", dtype=dtype); wd = torch.empty_like(wf)
+    ops.pack_conv_weight(w.detach().cuda(), wf, wd)
+    dyd = nhwc(dy, dtype)
+    try:
+        lib.gmk_set_kernel_choice(1, -1, -1)                        # im2col gather (register-staged)
+        dx_im2col = ops.conv_igemm([dyd], wd, C, 3, ops.TRANSPOSED2, (S, S))
+        assert lib.gmk_last_kernel() == 1
+        for variant in (0, 3):                                      # wave-specialised / 8-compute-wave halo kernel
+            lib.gmk_set_kernel_choice(3, -1, -1)
+            lib.gmk_set_dev_variant(variant)
+            dx = ops.conv_igemm([dyd], wd, C, 3, ops.TRANSPOSED2, (S, S))
+            assert lib.gmk_last_kernel() == 5
+            assert rel_err(nchw(dx), x.grad) < TOL[dtype], f"variant {variant} vs autograd"
+            assert rel_err(nchw(dx), nchw(dx_im2col).cpu()) < 8e-3, f"variant {variant} vs im2col"   # same products, other summation order: <= 2 bf16 ulps
+    finally:
+        lib.gmk_set_kernel_choice(-1, -1, -1)
+        lib.gmk_set_dev_variant(0)
+
+
 @pytest.mark.parametrize("S,B,G", [(28, 3, 32), (14, 5, 32), (14, 5, 16), (8, 37, 32), (7, 9, 32)])
 def test_conv_emits_groupnorm_statistics(ops, S, B, G):
     """The halo convolution's epilogue statistics == statistics of the tensor it stored (tiles spanning samples,
