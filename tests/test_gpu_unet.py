@@ -8,6 +8,7 @@ from functools import partial
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -388,3 +389,33 @@ def test_attention_extension_vs_oracle(dtype):
         assert rel_err(net.grad(name), pr[name].grad) < 6 * tol, name
     # without the flag nothing changes: 160 tensors, reference names only
     assert len(SimpleUnet(128, 0.0).state_dict()) == 160
+
+
+@pytest.mark.parametrize("compute_dtype", ["bf16", "fp32"])
+def test_training_learns_class_conditional_templates(compute_dtype):
+    """End to end through the plugin surface only (train_step / sample): 200 steps on ten smooth class templates + noise.
+    The loss must fall several-fold and class-conditional samples (guided DDIM, 50 steps) must land on their own template:
+    a wrong gradient, optimiser, label path or sampler update cannot pass this, whatever the unit tests say."""
+    from generative_models_amd import common
+    from generative_models_amd.diffusion.diffusion_model import DiffusionModel
+    G = common.AttrDict(DiffusionModel.DG)
+    G.update(dict(lr=3e-4, timesteps=50, eval_heavy=0, seed=1, compute_dtype=compute_dtype))
+    model = DiffusionModel(G).cuda()
+    g = torch.Generator().manual_seed(3)
+    T = F.interpolate(torch.randn(10, 1, 7, 7, generator=g), size=28, mode="bicubic", align_corners=False).clamp(-1.5, 1.5) / 1.5
+    T = T.cuda()
+    B, losses = 256, []
+    for _ in range(200):
+        y = torch.randint(0, 10, (B,), generator=g).cuda()
+        x = (T[y] + 0.05 * torch.randn(B, 1, 28, 28, generator=g).cuda()).clamp(-1, 1)
+        losses.append(float(model.train_step(x, y.clone())["loss"]))
+    first, last = sum(losses[:5]) / 5, sum(losses[-20:]) / 20
+    assert last < 0.2 and last < 0.4 * first, (first, last)          # measured: 0.5 -> 0.08 (bf16), 0.09 (fp32)
+    model.eval()
+    y = torch.arange(20).cuda() % 10
+    s = model.sample(20, y)
+    d = ((s[:, None] - T[None]) ** 2).mean(dim=(2, 3, 4))            # [20, 10]: distance of every sample to every template
+    own = d[torch.arange(20), y]
+    assert int((d.argmin(1) == y).sum()) >= 19, d.argmin(1).tolist()
+    assert float(own.mean()) < 0.15 and float(own.mean()) * 4 < float(d.mean()), (float(own.mean()), float(d.mean()))
+
