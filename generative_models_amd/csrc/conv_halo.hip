@@ -43,6 +43,7 @@ struct HaloParams {
     const void* src0; const void* src1;
     int c0, c1, ktot;
     int B, H, W, WE, R, TP, ntiles, rows_total;
+    int nfull, nhalf;                          // wave-specialised kernel: tiles [0, nfull) are whole jobs, the rest run as nhalf half-channel jobs (see there)
     int shift;                                 // 1: the source is the half-resolution tensor (nearest x2 upsample folded in)
     int pmask;                                 // 1 (with shift = 1): only even (y, x) exist - the zero-stuffed source of a transposed conv
     const void* w; unsigned w_tap_stride_b; int n0;
@@ -425,6 +426,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
 }
 
 
+template <int N> struct IntTag { static constexpr int value = N; };
+
 // ---------------------------------------------------------------------------------------------------------------
 // Wave-specialised variant of the same convolution (same LDS map, same schedule): waves 4..7 only move data (every
 // LDS-DMA instruction of a K-step: 4 weight pieces + 2 halo pieces each), waves 0..3 only compute, each owning a
@@ -447,6 +450,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
     constexpr unsigned kBadPix = 0x00FFFFFFu;
     constexpr unsigned kBadOff = 0xFFFFFF00u;
     if ((int)blockIdx.x >= p.ntiles) return;
+    // Jobs of this workgroup, in order: the whole tiles g, g + G, ... below nfull, then - for the first nhalf workgroups - one
+    // HALF job: channel half (g & 1) of tile nfull + g/2, computed by all four consumers as 64 pixels x 64 channels each.
+    // The host sets nhalf = 2 x (ntiles mod G) when that remainder fits (<= G/2): the last, partly filled round of whole tiles
+    // (0.45 of a round at 28x28, 0.11 at 14x14 for B = 1024) then costs about half a tile time on all CUs instead of a whole one.
+    const int G = gridDim.x, g = blockIdx.x;
+    const int nk_full = (p.nfull - g + G - 1) / G;
+    const int njobs = nk_full + (g < p.nhalf ? 1 : 0);
+    auto job_tile = [&](int k) { return k < nk_full ? g + k * G : (k < njobs ? p.nfull + (g >> 1) : p.ntiles); };
+    auto job_half = [&](int k) { return k >= nk_full && k < njobs ? (g & 1) : -1; };
 
     if (wave >= 4) {
         // =========================================== producer waves ===========================================
@@ -475,6 +487,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         for (int u = 0; u < 4; ++u) {
             const int row = 32 * pw + 8 * u + lrow;
             w_off[u] = (unsigned)(p.n0 + nblk + row) * (unsigned)p.ktot * ES + (unsigned)((lch ^ ((row >> 1) & 7)) << 4);
+        }
+        // half jobs (channel half c of a tile) only need weight rows c*64 .. c*64+63: rows c*64 + 16*pw + 8*u + lrow, u < 2
+        unsigned wh_off0[2], wh_off1[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r0 = 16 * pw + 8 * u + lrow, r1 = 64 + r0;
+            wh_off0[u] = (unsigned)(p.n0 + nblk + r0) * (unsigned)p.ktot * ES + (unsigned)((lch ^ ((r0 >> 1) & 7)) << 4);
+            wh_off1[u] = (unsigned)(p.n0 + nblk + r1) * (unsigned)p.ktot * ES + (unsigned)((lch ^ ((r1 >> 1) & 7)) << 4);
         }
         // source pixel (24 bits) and swizzled chunk offset (bits 24..31, = f_ch >> 4) of this lane's slot in piece j of the
         // tile being filled; resolved one piece at a time, right before the piece is first needed
@@ -514,26 +534,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (GMK_LDS void*)dst, 16, voff, 0, 0, 0);
             }
         };
-        auto issue_w = [&](int stage, int tap, int ph) {
-            GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + pw * 4096);
+        auto issue_w = [&](int stage, int tap, int ph, int c) {      // c < 0: all 128 rows (4 instructions), else rows of channel half c (2)
             const unsigned wk = (unsigned)tap * p.w_tap_stride_b + ((unsigned)ph << 7);
+            if (c < 0) {
+                GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + pw * 4096);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(dst + u * 1024), 16, w_off[u] + wk, 0, 0, 0);
+                for (int u = 0; u < 4; ++u)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(dst + u * 1024), 16, w_off[u] + wk, 0, 0, 0);
+            } else {
+                GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + (c * 64 + 16 * pw) * 128);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(dst + u * 1024), 16, (c ? wh_off1[u] : wh_off0[u]) + wk, 0, 0, 0);
+            }
         };
 
         const __amdgpu_buffer_rsrc_t rsr =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
         unsigned pf0 = 0, pf1 = 0;
         int sq = 2, hbuf = 0;
-        int tile = blockIdx.x;
+        int tile = job_tile(0), ch = job_half(0);
 #pragma unroll
         for (int j = 0; j < 7; ++j) { resolve_piece(tile, j); issue_fill(0, 0, j); }
-        issue_w(0, 0, 0);
-        issue_w(1, 1, 0);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        issue_w(0, 0, 0, ch);
+        issue_w(1, 1, 0, ch);
+        if (ch < 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // start-up barrier: weight tile 0 is in LDS
-        for (; tile < p.ntiles; tile += gridDim.x) {
+        for (int k = 0; k < njobs; ++k) {
+            const int ntile = job_tile(k + 1), nch = job_half(k + 1);
             for (int ph = 0; ph < nph; ++ph) {
                 const bool last_ph = ph + 1 == nph;
                 const int ph_next = last_ph ? 0 : ph + 1;
@@ -556,11 +585,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     __builtin_amdgcn_s_barrier();
                     const bool no_w = p.variant == 20 || p.variant == 22, no_f = p.variant == 21 || p.variant == 22;   // timing ablations
                     if (!no_w) {
-                        if (tap < 7) issue_w(sq, tap + 2, ph);
-                        else issue_w(sq, tap - 7, ph_next);
+                        if (tap < 7) issue_w(sq, tap + 2, ph, ch);
+                        else issue_w(sq, tap - 7, ph_next, last_ph ? nch : ch);      // the first two weight tiles of the next job
                     }
                     if (tap < 7 && !no_f) {
-                        if (last_ph) resolve_piece(tile + gridDim.x, tap);      // the next fills belong to the next tile (or are zeros)
+                        if (last_ph) resolve_piece(ntile, tap);                  // the next fills belong to the next job's tile (or are zeros)
                         issue_fill(hbuf ^ 1, ph_next, tap);
                     }
                     if (tap == 7 && warmed) {
@@ -576,24 +605,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 }
                 hbuf ^= 1;
             }
+            tile = ntile; ch = nch;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the speculative DMA before the LDS is released
         return;
     }
 
     // =============================================== consumer waves ===============================================
-    const int cm = wave >> 1, cw = wave & 1;          // pixel half (128) / channel half (64) of the tile
+    // Whole job: wave = (cm, cw) owns pixel half cm (128 = 4 blocks of 32) x channel half cw (64).  Half job: all four waves share
+    // channel half `ch`, wave w owns pixels 64w .. 64w+63 (NI = 2 blocks): half the MFMAs of a whole job in every wave.
+    const int cm = wave >> 1, cw = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.nbo, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
+    int pxbase = cm * 128, cwe = cw;                  // first pixel / channel half of this wave in the current job
     int rit[4], px_x[4];
+    auto set_geometry = [&](int half_c) {
+        if (half_c >= 0) { pxbase = wave * 64; cwe = half_c; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ml = cm * 128 + i * 32 + r;
-        rit[i] = div_small(ml, p.inv_w);
-        px_x[i] = ml - rit[i] * W;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int ml = pxbase + i * 32 + r;
+            rit[i] = div_small(ml, p.inv_w);
+            px_x[i] = ml - rit[i] * W;
+        }
+    };
     int cslot[4], cn[4];
     auto resolve_centres = [&](int tile) {
         const int gr0 = tile * p.R;
@@ -615,7 +651,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 
     f32x16 acc[2][4];     // [j: channel tile][i: pixel tile]
     const int swz = (r >> 1) & 7;
-    const int b_off = kWOFF + (cw * 64 + r) * 128;
+    int b_off = 0;
 
     // Software pipeline of one K-step (tap): the pixel-fragment reads of group 0 and all address arithmetic of tap t+1 are
     // issued before the last MFMA group of tap t (the halo does not change inside a phase), so after the barrier only the two
@@ -626,187 +662,180 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 #define GMK_ABLATE 0
 #endif
     constexpr bool no_rd = GMK_ABLATE == 23, no_mm = GMK_ABLATE == 24;      // timing-only diagnostic builds (-DGMK_ABLATE=..)
-    auto pre = [&](int hbuf, int tap) {             // addresses of `tap` + its group-0 pixel fragments -> set 0
-        if (no_rd) return;
-        const char* Hb = smem + hbuf * kHB;
-        const int tapoff = (tap / 3 - 1) * WE + (tap % 3 - 1), tapoff_n = (tap / 3 - 1) * W + (tap % 3 - 1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int c = cslot[i], n = cn[i];
-            asm volatile("" : "+v"(c), "+v"(n));      // keep the per-tap addresses out of loop-invariant hoisting
-            rowb[i] = (c + tapoff) << 7;
-            sw[i] = ((n + tapoff_n) >> 1) & 7;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            px[0][i] = *reinterpret_cast<const bf16x8*>(Hb + rowb[i] + ((h ^ sw[i]) << 4));
-    };
-    auto load_px = [&](int hbuf, int kg, int set) {
-        if (no_rd) return;
-        const char* Hb = smem + hbuf * kHB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            px[set][i] = *reinterpret_cast<const bf16x8*>(Hb + rowb[i] + (((kg * 2 + h) ^ sw[i]) << 4));
-    };
-    auto load_wt = [&](int st, int kg, int set) {
-        if (no_rd) return;
-        const char* Wb = smem + st * kWST + b_off;
-        const int coff = ((kg * 2 + h) ^ swz) << 4;
-        wt[set][0] = *reinterpret_cast<const bf16x8*>(Wb + coff);
-        wt[set][1] = *reinterpret_cast<const bf16x8*>(Wb + 4096 + coff);
-    };
-    auto interleave_reads = [&]() {       // order of the enclosing scheduling region: (MFMA, 2 VALU, read) x 4, (MFMA, read) x 2, MFMA x 2
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-    };
-    auto interleave_pre = [&]() {         // (MFMA, 5 VALU) x 4, (MFMA, 2 VALU, read) x 4
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    };
-    auto mfma_group = [&](int set) {
-        if (no_mm) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(px[set][i]), "v"(wt[set][i & 1]));
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[set][j], px[set][i], acc[j][i], 0, 0, 0);
-    };
-
-    auto epilogue = [&](int tile) {
-        // every global load of the epilogue is issued up front, in as few and as wide instructions as possible: the bias once
-        // per tile (not once per accumulator), the residual as 16-B loads at the addresses the stores use (the lane layout after
-        // v_permlane32_swap) and swapped back into the accumulator layout — half the instructions of 8-B loads in that layout
-        float bz[2][16];
-        if (p.bias) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    float t[4];
-                    load4(p.bias + nblk + cw * 64 + j * 32 + 8 * q4 + 4 * h, t);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bz[j][4 * q4 + e] = t[e];
-                }
-        }
-        u32x4 rres[2][2][2];            // residual of pixel block i (set i & 1), loaded one block ahead
-        auto load_res = [&](int i) {
-            const int ml = cm * 128 + i * 32 + r;
-            const int m = tile * p.TP + ml;
-            const bool live = ml < p.TP && m < p.M;
-            const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int cb = nblk + cw * 64 + j * 32;
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    const unsigned off = live ? row_b + (unsigned)(cb + 8 * (2 * qq + h)) * ES : kBadOff;
-                    rres[i & 1][j][qq] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, off, 0, 0));
-                }
-            }
-        };
-        if (p.residual) load_res(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ml = cm * 128 + i * 32 + r;
-            const int m = tile * p.TP + ml;
-            const bool live = ml < p.TP && m < p.M;
-            const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
-            const float* embp = nullptr;
-            if (p.emb) embp = p.emb + (int64_t)((live ? m : 0) / (H * W)) * p.emb_stride;
-            if (p.residual && i < 3) load_res(i + 1);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int cb = nblk + cw * 64 + j * 32;
-                float v[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) { v[e] = acc[j][i][e]; acc[j][i][e] = 0.f; }
-                if (p.bias) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] += bz[j][e];
-                }
-                if (p.emb) {
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        float t[4];
-                        load4(embp + cb + 8 * q4 + 4 * h, t);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[4 * q4 + e] += t[e];
-                    }
-                }
-                if (p.residual) {
-#pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        const u32x4 R = rres[i & 1][j][qq];
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(R[0], R[2], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(R[1], R[3], false, false);
-                        const bf16x4 ra = __builtin_bit_cast(bf16x4, (u32x2_t){s0[0], s1[0]});      // block q4 = 2qq
-                        const bf16x4 rb = __builtin_bit_cast(bf16x4, (u32x2_t){s0[1], s1[1]});      // block q4 = 2qq + 1
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[8 * qq + e] += (float)ra[e];
-                            v[8 * qq + 4 + e] += (float)rb[e];
-                        }
-                    }
-                }
-                unsigned pk[4][2];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    bf16x4 t = {(bf16_t)v[4 * q4], (bf16_t)v[4 * q4 + 1], (bf16_t)v[4 * q4 + 2], (bf16_t)v[4 * q4 + 3]};
-                    const auto u = __builtin_bit_cast(u32x2_t, t);
-                    pk[q4][0] = u[0]; pk[q4][1] = u[1];
-                }
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4 += 2) {
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[q4][0], pk[q4 + 1][0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q4][1], pk[q4 + 1][1], false, false);
-                    u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                    const unsigned off = live ? row_b + (unsigned)(cb + 8 * (q4 + h)) * ES : kBadOff;
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rso, off, 0, 0);
-                }
-            }
-        }
-    };
-
     int st = 0, hbuf = 0;
     int tile_it = 0;
     auto stamp = [&](int k) {
         if (p.stamps && tid == 0 && tile_it < 16)
             p.stamps[((size_t)blockIdx.x * 16 + tile_it) * 4 + k] = __builtin_amdgcn_s_memtime();
     };
-    resolve_centres(blockIdx.x);
+    auto load_wt = [&](int stg, int kg, int set) {
+        if (no_rd) return;
+        const char* Wb = smem + stg * kWST + b_off;
+        const int coff = ((kg * 2 + h) ^ swz) << 4;
+        wt[set][0] = *reinterpret_cast<const bf16x8*>(Wb + coff);
+        wt[set][1] = *reinterpret_cast<const bf16x8*>(Wb + 4096 + coff);
+    };
+
+    // one job = nph phases x 9 taps + epilogue; NI = pixel blocks per wave (4: whole job, 2: half job)
+    auto run_job = [&](auto ni_tag, int tile, int next_boff) {
+        constexpr int NI = decltype(ni_tag)::value;
+        auto pre = [&](int hb, int tap) {             // addresses of `tap` + its group-0 pixel fragments -> set 0
+            if (no_rd) return;
+            const char* Hb = smem + hb * kHB;
+            const int tapoff = (tap / 3 - 1) * WE + (tap % 3 - 1), tapoff_n = (tap / 3 - 1) * W + (tap % 3 - 1);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < NI; ++i) {
+                int c = cslot[i], n = cn[i];
+                asm volatile("" : "+v"(c), "+v"(n));      // keep the per-tap addresses out of loop-invariant hoisting
+                rowb[i] = (c + tapoff) << 7;
+                sw[i] = ((n + tapoff_n) >> 1) & 7;
+            }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
+                px[0][i] = *reinterpret_cast<const bf16x8*>(Hb + rowb[i] + ((h ^ sw[i]) << 4));
+        };
+        auto load_px = [&](int hb, int kg, int set) {
+            if (no_rd) return;
+            const char* Hb = smem + hb * kHB;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
-    __builtin_amdgcn_s_barrier();                          // start-up barrier: weight tile 0 is in LDS
-    if (kPrefetchW) load_wt(0, 0, 0);
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+            for (int i = 0; i < NI; ++i)
+                px[set][i] = *reinterpret_cast<const bf16x8*>(Hb + rowb[i] + (((kg * 2 + h) ^ sw[i]) << 4));
+        };
+        auto interleave_reads = [&]() {       // whole job: (MFMA, 2 VALU, read) x 4, (MFMA, read) x 2, MFMA x 2;  half job: half of each
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (NI == 4) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        };
+        auto interleave_pre = [&]() {         // whole job: (MFMA, 5 VALU) x 4, (MFMA, 2 VALU, read) x 4, 2 reads
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        };
+        auto mfma_group = [&](int set) {
+            if (no_mm) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) asm volatile("" :: "v"(px[set][i]), "v"(wt[set][i & 1]));
+                return;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[set][j], px[set][i], acc[j][i], 0, 0, 0);
+        };
+        auto epilogue = [&]() {
+            // every global load of the epilogue is issued up front, in as few and as wide instructions as possible: the bias once
+            // per tile (not once per accumulator), the residual as 16-B loads at the addresses the stores use (the lane layout after
+            // v_permlane32_swap) and swapped back into the accumulator layout — half the instructions of 8-B loads in that layout
+            float bz[2][16];
+            if (p.bias) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        float t[4];
+                        load4(p.bias + nblk + cwe * 64 + j * 32 + 8 * q4 + 4 * h, t);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bz[j][4 * q4 + e] = t[e];
+                    }
+            }
+            u32x4 rres[2][2][2];            // residual of pixel block i (set i & 1), loaded one block ahead
+            auto load_res = [&](int i) {
+                const int ml = pxbase + i * 32 + r;
+                const int m = tile * p.TP + ml;
+                const bool live = ml < p.TP && m < p.M;
+                const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int cb = nblk + cwe * 64 + j * 32;
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const unsigned off = live ? row_b + (unsigned)(cb + 8 * (2 * qq + h)) * ES : kBadOff;
+                        rres[i & 1][j][qq] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, off, 0, 0));
+                    }
+                }
+            };
+            if (p.residual) load_res(0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int ml = pxbase + i * 32 + r;
+                const int m = tile * p.TP + ml;
+                const bool live = ml < p.TP && m < p.M;
+                const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
+                const float* embp = nullptr;
+                if (p.emb) embp = p.emb + (int64_t)((live ? m : 0) / (H * W)) * p.emb_stride;
+                if (p.residual && i < NI - 1) load_res(i + 1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int cb = nblk + cwe * 64 + j * 32;
+                    float v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { v[e] = acc[j][i][e]; acc[j][i][e] = 0.f; }
+                    if (p.bias) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] += bz[j][e];
+                    }
+                    if (p.emb) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            float t[4];
+                            load4(embp + cb + 8 * q4 + 4 * h, t);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[4 * q4 + e] += t[e];
+                        }
+                    }
+                    if (p.residual) {
+#pragma unroll
+                        for (int qq = 0; qq < 2; ++qq) {
+                            const u32x4 R = rres[i & 1][j][qq];
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(R[0], R[2], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(R[1], R[3], false, false);
+                            const bf16x4 ra = __builtin_bit_cast(bf16x4, (u32x2_t){s0[0], s1[0]});      // block q4 = 2qq
+                            const bf16x4 rb = __builtin_bit_cast(bf16x4, (u32x2_t){s0[1], s1[1]});      // block q4 = 2qq + 1
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[8 * qq + e] += (float)ra[e];
+                                v[8 * qq + 4 + e] += (float)rb[e];
+                            }
+                        }
+                    }
+                    unsigned pk[4][2];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        bf16x4 t = {(bf16_t)v[4 * q4], (bf16_t)v[4 * q4 + 1], (bf16_t)v[4 * q4 + 2], (bf16_t)v[4 * q4 + 3]};
+                        const auto u = __builtin_bit_cast(u32x2_t, t);
+                        pk[q4][0] = u[0]; pk[q4][1] = u[1];
+                    }
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4 += 2) {
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[q4][0], pk[q4 + 1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q4][1], pk[q4 + 1][1], false, false);
+                        u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                        const unsigned off = live ? row_b + (unsigned)(cb + 8 * (q4 + h)) * ES : kBadOff;
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rso, off, 0, 0);
+                    }
+                }
+            }
+        };
+
         stamp(0);
         for (int ph = 0; ph < nph; ++ph) {
 #pragma unroll
@@ -815,7 +844,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 if (tap == 0) pre(hbuf, 0);           // the phase's halo only became valid with this barrier
                 if (!kPrefetchW) load_wt(st, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                // each region = the 6 reads (+ address VALU) of group kg+1 and the 8 MFMAs of group kg, interleaved one read per
+                // each region = the reads (+ address VALU) of group kg+1 and the MFMAs of group kg, interleaved one read per
                 // MFMA so that read issue hides in the 24 free issue cycles of every MFMA; sched_barrier(0) keeps the stages apart
                 // (left alone the scheduler re-serialises read -> use, and reads issued in a block let the MFMA pipe drain)
                 load_px(hbuf, 1, 1); load_wt(st, 1, 1);
@@ -832,6 +861,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 __builtin_amdgcn_sched_barrier(0);
                 st = st == 2 ? 0 : st + 1;
                 if (tap < 8) pre(hbuf, tap + 1);      // next tap's addresses + group-0 pixels, under the last MFMA group
+                if (tap == 8 && ph + 1 == nph) b_off = next_boff;      // the next step belongs to the next job (other channel half?)
                 if (kPrefetchW) load_wt(st, 0, 0);    // ... and the next step's first weight fragments (tile landed at this step's barrier)
                 mfma_group(1);
                 if (tap < 8) interleave_pre();
@@ -842,10 +872,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         }
         asm volatile("" ::: "memory");
         stamp(2);
-        // the epilogue is bound by store issue: it also re-zeroes the accumulators and resolves the next tile's pixel rows in
-        // that shadow, so the next tile starts on its first barrier
-        epilogue(tile);
-        resolve_centres(tile + gridDim.x);
+        // the epilogue is bound by store issue: it also re-zeroes the accumulators (and the caller resolves the next tile's pixel
+        // rows) in that shadow, so the next tile starts on its first barrier
+        epilogue();
+    };
+
+    set_geometry(job_half(0));
+    b_off = kWOFF + (cwe * 64 + r) * 128;
+    resolve_centres(job_tile(0));
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+    __builtin_amdgcn_s_barrier();                          // start-up barrier: weight tile 0 is in LDS
+    if (kPrefetchW) load_wt(0, 0, 0);
+    for (int k = 0; k < njobs; ++k) {
+        const int tile = job_tile(k), hc = job_half(k), ntile = job_tile(k + 1), nhc = job_half(k + 1);
+        const int next_boff = kWOFF + ((nhc >= 0 ? nhc : cw) * 64 + r) * 128;
+        if (hc < 0) run_job(IntTag<4>{}, tile, next_boff);
+        else run_job(IntTag<2>{}, tile, next_boff);
+        if (nhc != hc) set_geometry(nhc);                  // whole -> half happens at most once, before the last job
+        resolve_centres(ntile);
         asm volatile("" ::: "memory");
         stamp(3);
         ++tile_it;
@@ -893,6 +942,12 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     if (stats && cout == out_cstride && stats_bytes >= ntiles * 8 * 2 * (int64_t)(out_cstride / 4) * 2 * 4 && H * W >= 32) p.stats = stats;
     p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 2); p.inv_w = 1.0f / (float)W;
     dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256), cout / 128);
+    p.nfull = (int)ntiles; p.nhalf = 0;
+    {   // tail balancing of the wave-specialised kernel: a last round of at most G/2 tiles runs as twice as many half jobs
+        const int G = (int)grid.x, rem = (int)(ntiles % G);
+        // not for variant 4 (its vmcnt waits count 4 weight DMAs per step); variant 6 is the A/B switch
+        if (ntiles > G && rem > 0 && 2 * rem <= G && p.variant != 4 && p.variant != 6) { p.nfull = (int)ntiles - rem; p.nhalf = 2 * rem; }
+    }
     if (p.variant == 4 && !p.stats) conv3x3_halo_ws_kernel<false><<<grid, 512, 0, stream>>>(p);
     else if (p.variant != 1 && p.variant != 3 && !p.stats) conv3x3_halo_ws_kernel<true><<<grid, 512, 0, stream>>>(p);     // 1, 3: the 8-compute-wave kernel
     else {

@@ -361,6 +361,47 @@ def test_transposed_dgrad_on_halo_kernels(ops, S, B):
         lib.gmk_set_dev_variant(0)
 
 
+@pytest.mark.parametrize("S,B,two,mode", [(14, 400, False, 0), (28, 90, False, 0), (14, 330, True, 0), (16, 300, False, 2), (28, 100, False, 3)])
+def test_halo_tail_runs_as_half_jobs(ops, S, B, two, mode):
+    """More tiles than CUs with a last round of <= 128 tiles: the wave-specialised kernel runs that round as half-channel jobs
+    (64 pixels x 64 channels per consumer wave).  Same dot products in the same order as whole jobs, so the result must equal
+    the 8-compute-wave kernel's (which has no such split) bit for bit, and agree with a float32 torch convolution."""
+    from generative_models_amd._lib import lib
+    dtype, C = torch.bfloat16, 128
+    cin = 2 * C if two else C
+    hs = S // 2 if mode in (2, 3) else S
+    g = torch.Generator(device="cpu").manual_seed(7)
+    srcs = [torch.randn(B, hs, hs, C, generator=g).to("cuda", dtype) for _ in range(2 if two else 1)]
+    w = (torch.randn(C, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).cuda()
+    wf = torch.empty(w.numel(), device="cuda", dtype=dtype); wd = torch.empty_like(wf)
+    ops.pack_conv_weight(w, wf, wd)
+    bias = 0.1 * torch.randn(C, generator=g).cuda()
+    res = torch.randn(B, S, S, C, generator=g).to("cuda", dtype)
+    R = 256 // S
+    ntiles = (B * S + R - 1) // R
+    assert ntiles > 256 and 0 < ntiles % 256 <= 128, ntiles           # the shape really has a splittable tail
+    outs = {}
+    try:
+        for variant in (0, 3):
+            lib.gmk_set_kernel_choice(3, -1, -1)
+            lib.gmk_set_dev_variant(variant)
+            outs[variant] = ops.conv_igemm(srcs, wf, C, 3, mode, (S, S), bias=bias, residual=res)
+            assert lib.gmk_last_kernel() == (5 if mode == 3 else 4 if variant == 0 else 3)
+    finally:
+        lib.gmk_set_kernel_choice(-1, -1, -1)
+        lib.gmk_set_dev_variant(0)
+    assert torch.equal(outs[0], outs[3])
+    x = torch.cat([t.float() for t in srcs], 3).permute(0, 3, 1, 2)
+    wq = w.to(dtype).float()
+    if mode == 2:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    if mode == 3:        # transposed: the packed weights are used as they are on the zero-stuffed input
+        z = torch.zeros(B, C, S, S, device="cuda"); z[:, :, ::2, ::2] = x; x = z
+    ref = F.conv2d(x, wq, bias, padding=1) + res.float().permute(0, 3, 1, 2)
+    got = outs[0].float().permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-2
+
+
 @pytest.mark.parametrize("S,B,G", [(28, 3, 32), (14, 5, 32), (14, 5, 16), (8, 37, 32), (7, 9, 32)])
 def test_conv_emits_groupnorm_statistics(ops, S, B, G):
     """The halo convolution's epilogue statistics == statistics of the tensor it stored (tiles spanning samples,
