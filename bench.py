@@ -194,11 +194,13 @@ def main():
     model.diffusion.num_steps = a.sampler_steps
     init = model._aux_rng.normal((a.batch, a.in_channels, a.size, a.size), dev)
     model.diffusion.sample(net=partial(model.net, guide=y), init_x=init, record=False)     # warm-up
-    barrier()
-    t0 = time.perf_counter()
-    model.diffusion.sample(net=partial(model.net, guide=y), init_x=init, record=False)
-    barrier()
-    ts = time.perf_counter() - t0
+    ts = float("inf")
+    for _ in range(2):                               # two timed passes, the faster one is reported (the chip re-clocks after the train loop)
+        barrier()
+        t0 = time.perf_counter()
+        model.diffusion.sample(net=partial(model.net, guide=y), init_x=init, record=False)
+        barrier()
+        ts = min(ts, time.perf_counter() - t0)
     if world > 1:
         t = torch.tensor([ts], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -206,17 +208,19 @@ def main():
     sampler = {"steps_per_sec": round(a.sampler_steps / ts, 2),
                "image_steps_per_sec": round(world * a.batch * a.sampler_steps / ts, 1),
                "batch_per_gpu": a.batch, "mode": "ddim, guidance off, 1 U-Net forward per step",
-               "timed_steps": a.sampler_steps}
+               "timed_steps": a.sampler_steps, "timing": "faster of two passes after one warm-up pass"}
 
     def time_sampler(kind, cond_w):              # the other two modes of SURVEY M1(ii), same batch and step count
         model.diffusion.sampler = kind
         run = lambda: model.diffusion.sample(net=partial(model.net, guide=y), init_x=init, cond_w=cond_w, record=False)
         run()
-        barrier()
-        t0 = time.perf_counter()
-        run()
-        barrier()
-        t = time.perf_counter() - t0
+        t = float("inf")
+        for _ in range(2):
+            barrier()
+            t0 = time.perf_counter()
+            run()
+            barrier()
+            t = min(t, time.perf_counter() - t0)
         if world > 1:
             tt = torch.tensor([t], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
