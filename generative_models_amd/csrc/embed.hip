@@ -1,6 +1,6 @@
 // Embedding path of the U-Net (reference gms/diffusion/simple_unet.py:20-34,45-64,166,205-224), fp32:
 // sinusoidal features, the one-hot label encoding with its -1 mask, and a small strided fp32 GEMM used for every
-// nn.Linear forward / backward of the path ([B,64..256] x [256,..]: ~1 MFLOP per image, launch-bound, not MFMA work).
+// nn.Linear forward / backward of the path ([B,64..256] x [256,..]: ~1 MFLOP per image; fp32 MFMA, exact fp32 products).
 #include "gmk_common.h"
 
 namespace {
@@ -37,13 +37,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     __shared__ float As[TK][TM + 4];
     __shared__ float Bs[TK][TN + 4];
     const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
+    // wave (wm, wn) owns the 32 x 32 quarter of the 64 x 64 tile: one fp32 MFMA accumulator (v_mfma_f32_32x32x2_f32 - true fp32
+    // multiply-adds, K = 2 per instruction: lane = (r, h) feeds A[row r][k + h] and B[k + h][col r])
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
     const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
-    float acc[4][4];
+    f32x16 acc;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     // split-K: slice blockIdx.z covers k in [z*kchunk, (z+1)*kchunk) and, when there is more than one slice, writes its
     // raw partial sums to ws[z][M][N]; gemm_splitk_reduce_kernel then applies bias / rowscale / accumulate
     const int kbeg = blockIdx.z * kchunk;
@@ -75,45 +76,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < TK; ++k) {
-            float a[4], b[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { a[e] = As[k][ty * 4 + e]; b[e] = Bs[k][tx * 4 + e]; }
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] = fmaf(a[x], b[y], acc[x][y]);
-        }
+        for (int k = 0; k < TK; k += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k + h][wm * 32 + r], Bs[k + h][wn * 32 + r], acc, 0, 0, 0);
         __syncthreads();
     }
+    // accumulator element e of lane (r, h): row (e & 3) + 8 (e >> 2) + 4 h, column r of the wave's quarter
+    const int j = j0 + wn * 32 + r;
     if (gridDim.z > 1) {
         float* w = ws + (int64_t)blockIdx.z * M * N;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const int i = i0 + ty * 4 + x;
-            if (i >= M) continue;
-#pragma unroll
-            for (int y = 0; y < 4; ++y) {
-                const int j = j0 + tx * 4 + y;
-                if (j < N) w[(int64_t)i * N + j] = acc[x][y];
-            }
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (i < M && j < N) w[(int64_t)i * N + j] = acc[e];
         }
         return;
     }
+    if (j >= N) return;
+    const float bj = bias ? bias[j] : 0.f;
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int i = i0 + ty * 4 + x;
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (i >= M) continue;
-        const float rsc = rowscale ? rowscale[i] : 1.f;
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            const int j = j0 + tx * 4 + y;
-            if (j >= N) continue;
-            float v = acc[x][y] + (bias ? bias[j] : 0.f);
-            v *= rsc;
-            float* c = C + (int64_t)i * ldc + j;
-            *c = accumulate ? *c + v : v;
-        }
+        const float v = (acc[e] + bj) * (rowscale ? rowscale[i] : 1.f);
+        float* c = C + (int64_t)i * ldc + j;
+        *c = accumulate ? *c + v : v;
     }
 }
 
