@@ -89,9 +89,19 @@ def cpu_baseline(seconds, S, in_channels):
             if n == 0:
                 n, t_total = 1, dt
             break
+    # reverse-diffusion beside it: DDIM, guidance off, B=32, a few steps of the T=1000 schedule
+    with torch.no_grad():
+        pd = {k: v.detach() for k, v in params.items()}
+        init = torch.randn(x.shape, generator=g)
+        D.sample(pd, init, y, 2, sampler="ddim", record=False)             # warm-up
+        ns = 8
+        t0 = time.perf_counter()
+        D.sample(pd, init, y, ns, sampler="ddim", record=False)
+        ts = time.perf_counter() - t0
     return {"value": round(B * n / t_total, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle (torch-CPU restatement) train step, B=32, {in_channels}x{S}x{S}, C=128, fp32, "
-                      f"{n} steps in {t_total:.1f} s after 1 warm-up"}
+                      f"{n} steps in {t_total:.1f} s after 1 warm-up",
+            "sampler_steps_per_sec": round(ns / ts, 2), "sampler_sample": f"oracle DDIM, guidance off, B=32, {ns} steps in {ts:.2f} s"}
 
 
 def main():
