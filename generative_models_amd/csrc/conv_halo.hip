@@ -729,17 +729,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             }
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         };
-        auto mfma_group = [&](int set) {
+        auto mfma_group = [&](int set, auto fresh_tag) __attribute__((always_inline)) {
+            constexpr bool kFresh = decltype(fresh_tag)::value != 0;      // first MFMAs of a job: C = 0, no accumulator re-zeroing anywhere
             if (no_mm) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) asm volatile("" :: "v"(px[set][i]), "v"(wt[set][i & 1]));
                 return;
             }
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[set][j], px[set][i], acc[j][i], 0, 0, 0);
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[set][j], px[set][i], kFresh ? z : acc[j][i], 0, 0, 0);
         };
         auto epilogue = [&]() {
             // every global load of the epilogue is issued up front, in as few and as wide instructions as possible: the bias once
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     const int cb = nblk + cwe * 64 + j * 32;
                     float v[16];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) { v[e] = acc[j][i][e]; acc[j][i][e] = 0.f; }
+                    for (int e = 0; e < 16; ++e) v[e] = acc[j][i][e];
                     if (p.bias) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) v[e] += bz[j][e];
@@ -837,7 +839,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         };
 
         stamp(0);
-        for (int ph = 0; ph < nph; ++ph) {
+        // phase 0 is peeled: its first MFMA group starts the accumulators from C = 0 (a compile-time property of the copy; a run-time
+        // select of the C operand costs a second set of accumulator registers)
+        auto phase = [&](auto first_tag, int ph) __attribute__((always_inline)) {
+            constexpr int kFirst = decltype(first_tag)::value;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 __builtin_amdgcn_s_barrier();
@@ -848,28 +853,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 // MFMA so that read issue hides in the 24 free issue cycles of every MFMA; sched_barrier(0) keeps the stages apart
                 // (left alone the scheduler re-serialises read -> use, and reads issued in a block let the MFMA pipe drain)
                 load_px(hbuf, 1, 1); load_wt(st, 1, 1);
-                mfma_group(0);
+                if (kFirst && tap == 0) mfma_group(0, IntTag<1>{}); else mfma_group(0, IntTag<0>{});
                 interleave_reads();
                 __builtin_amdgcn_sched_barrier(0);
                 load_px(hbuf, 2, 0); load_wt(st, 2, 0);
-                mfma_group(1);
+                mfma_group(1, IntTag<0>{});
                 interleave_reads();
                 __builtin_amdgcn_sched_barrier(0);
                 load_px(hbuf, 3, 1); load_wt(st, 3, 1);
-                mfma_group(0);
+                mfma_group(0, IntTag<0>{});
                 interleave_reads();
                 __builtin_amdgcn_sched_barrier(0);
                 st = st == 2 ? 0 : st + 1;
                 if (tap < 8) pre(hbuf, tap + 1);      // next tap's addresses + group-0 pixels, under the last MFMA group
                 if (tap == 8 && ph + 1 == nph) b_off = next_boff;      // the next step belongs to the next job (other channel half?)
                 if (kPrefetchW) load_wt(st, 0, 0);    // ... and the next step's first weight fragments (tile landed at this step's barrier)
-                mfma_group(1);
+                mfma_group(1, IntTag<0>{});
                 if (tap < 8) interleave_pre();
                 __builtin_amdgcn_sched_barrier(0);
             }
             hbuf ^= 1;
             if (ph == 0) stamp(1);
-        }
+        };
+        phase(IntTag<1>{}, 0);
+        for (int ph = 1; ph < nph; ++ph) phase(IntTag<0>{}, ph);
         asm volatile("" ::: "memory");
         stamp(2);
         // the epilogue is bound by store issue: it also re-zeroes the accumulators (and the caller resolves the next tile's pixel
