@@ -4,22 +4,31 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W            (one rank per GPU, RCCL)
 
-A "step" is one full training step of `DiffusionModel.train_step` (label drop, q_sample, U-Net forward, loss,
-backward, bucketed gradient all-reduce, fused Adam) on one batch of synthetic MNIST-shaped images that is already
-resident in HBM.  Workload = BASELINE.json configs[1]: 1x28x28, C=128, per-GPU batch 1024, bf16 compute with fp32
-master weights (weak scaling: the per-GPU batch is fixed).  Rank 0 prints ONE JSON line:
-  value            whole-job train images/s (all ranks), max-over-ranks wall time around exactly K steps
-  sampler          reverse-diffusion steps/s (DDIM, guidance off, batch 1024/GPU), timed separately
-  roofline         dominant kernel = the MFMA implicit-GEMM convolution (forward + data-gradient launches):
-                   algorithmic FLOPs of every launch in the timed region / their HIP-event durations, vs the dense
-                   bf16 MFMA peak
-  cpu_baseline     the oracle (CPU restatement) timed on the host cores on a bounded sample (rank 0, N=1 only)
+A "step" is one full training step of `DiffusionModel.train_step` (label drop, q_sample, U-Net forward, loss, backward,
+bucketed gradient all-reduce, fused Adam) on a batch of synthetic images already resident in HBM (4 distinct resident batches
+are cycled).  Workloads are BASELINE.json's configs (C=128, bf16 compute, fp32 master weights, weak scaling: the per-GPU batch
+is fixed):
+    N = 1   headline configs[2] (3x32x32, B=2048: the largest config that is quoted on one GPU), `other_configs` =
+            configs[1] (1x28x28, B=1024) and the per-GPU shard of configs[3] (3x64x64, B=1024)
+    N > 1   headline = the per-GPU shard of configs[3] (3x64x64, 1024 images per GPU); `other_configs` = the shard of
+            configs[4] (3x64x64 + self-attention, 512 per GPU)
+Rank 0 prints ONE JSON line:
+  value            whole-job train images/s over exactly K timed steps after W warm-up steps, max-over-ranks wall time
+  steady_state     the same loop again for >= 50 more steps (SURVEY §8d M1 asks for >= 50 steps after >= 10 warm-up)
+  sampler          reverse-diffusion steps/s: DDIM guidance off over the FULL T=1000 loop, guided DDIM and the ancestral
+                   sampler over shorter loops (their step count is stated), trajectories not recorded
+  roofline         dominant kernel (largest total HIP-event time): algorithmic FLOPs of its launches in the timed region /
+                   their HIP-event durations, against the dense bf16 MFMA peak; events are recorded on the stream each kernel
+                   runs on, on every 5th timed step
+  cpu_baseline     the oracle (CPU restatement) timed on the host cores on a bounded sample (rank 0, N = 1 only)
+  exchange         N > 1: what the gradient exchange saw (world, backend, RCCL version, bucket bytes, CUs left to RCCL)
 """
 import argparse
 import json
 import os
 import sys
 import time
+from functools import partial
 
 import torch
 import torch.distributed as dist
@@ -30,19 +39,38 @@ if ROOT not in sys.path:
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3
+FWD_GFLOP = {(1, 28): 4.3913, (3, 32): 5.7447, (3, 64): 22.9754}      # U-Net forward per image
+
+CONFIGS = {      # name -> (in_channels, size, per-GPU batch, attention, BASELINE.json entry)
+    "cfg1": (1, 28, 1024, 0, "configs[1]: DDPM MNIST 28x28x1, bs=1024, T=1000, bf16, 1xMI355X"),
+    "cfg2": (3, 32, 2048, 0, "configs[2]: DDPM 32x32x3, bs=2048, T=1000, 1xMI355X"),
+    "cfg3": (3, 64, 1024, 0, "configs[3]: DDPM 64x64x3, bs=8192 over 8 GPUs = 1024 per GPU"),
+    "cfg4": (3, 64, 512, 1, "configs[4]: DDPM 64x64x3 + self-attention, bs=4096 over 8 GPUs = 512 per GPU"),
+}
+KERNEL_DESC = {
+    "conv3x3_halo_ws_kernel": "3x3 stride-1 bf16 convolution, LDS-resident halo, wave-specialised (forward + data gradients)",
+    "conv3x3_halo_kernel": "3x3 stride-1 bf16 convolution, LDS-resident halo (forward + data gradients)",
+    "conv3x3_halo_ws_kernel[zero-stuffed transposed conv]": "data gradient of the stride-2 convs = the same kernel on the zero-stuffed gradient (algorithmic FLOPs are 1/4 of its MFMA work)",
+    "conv_igemm_dma_kernel": "im2col LDS-DMA convolution (1x1, strided, upsampled, fp32)",
+    "conv_igemm_kernel": "im2col register-staged convolution (small problems)",
+    "conv_wgrad_slots_kernel": "3x3 weight gradient over padded slots (+ slab reduce)",
+    "conv_wgrad_kernel": "im2col split-K weight gradient (+ slab reduce)"}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="auto", help="auto | cfg1 | cfg2 | cfg3 | cfg4 | custom (then --batch/--size/--in_channels/--attention)")
+    ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch (custom config)")
     ap.add_argument("--size", type=int, default=28)
     ap.add_argument("--in_channels", type=int, default=1)
+    ap.add_argument("--attention", type=int, default=0)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--attention", type=int, default=0, help="1: self-attention block at the S/4 level (BASELINE config 5 shape)")
-    ap.add_argument("--sampler_steps", type=int, default=20)
+    ap.add_argument("--sampler_steps", type=int, default=1000, help="T of the headline's guidance-off DDIM loop (0: skip the samplers)")
+    ap.add_argument("--sampler_steps_other", type=int, default=100, help="loop length of the other sampler modes / configs")
+    ap.add_argument("--others", type=int, default=1, help="0: headline only")
     ap.add_argument("--cpu_seconds", type=float, default=15.0)
     ap.add_argument("--no_cpu", action="store_true")
     ap.add_argument("--no_profile", action="store_true", help="skip the per-launch HIP events")
@@ -50,16 +78,17 @@ def parse():
 
 
 def synthetic_batch(B, C, S, device, seed):
+    """MNIST-like synthetic images: 85 % of the pixels exactly -1, the rest U(-1, 1); labels U{0..9}."""
     g = torch.Generator().manual_seed(seed)
     raw = torch.rand((B, C, S, S), generator=g) * 2 - 1
     ink = torch.rand((B, C, S, S), generator=g) < 0.15
-    x = torch.where(ink, raw, -torch.ones_like(raw))       # MNIST-like: 85 % of pixels exactly -1
+    x = torch.where(ink, raw, -torch.ones_like(raw))
     y = torch.randint(0, 10, (B,), generator=g)
     return x.to(device), y.to(device)
 
 
 def cpu_baseline(seconds, S, in_channels):
-    """Oracle train step (forward + autograd backward + Adam restatement) on the host cores, cfg1 shape B=32."""
+    """Oracle train step (forward + autograd backward + Adam restatement) on the host cores, B=32, the headline's image shape."""
     from oracle import diffusion_ref as D
     from oracle import unet_ref as U
     # the threads this process may actually run on (a GPU box gives one GPU's share of the host, 16 cores)
@@ -104,172 +133,193 @@ def cpu_baseline(seconds, S, in_channels):
             "sampler_steps_per_sec": round(ns / ts, 2), "sampler_sample": f"oracle DDIM, guidance off, B=32, {ns} steps in {ts:.2f} s"}
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("GMK_DIST_BACKEND", "nccl") != "nccl":
-        local = local % max(1, torch.cuda.device_count())              # rehearsal: several ranks may share a GPU
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        backend = os.environ.get("GMK_DIST_BACKEND", "nccl")       # "gloo": rehearsal of the N > 1 path on one GPU (tests)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+class Bench:
+    def __init__(self, a):
+        self.a = a
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = os.environ.get("GMK_DIST_BACKEND", "nccl")       # "gloo": rehearsal of the N > 1 path on one GPU (tests)
+        if self.backend != "nccl":
+            local = local % max(1, torch.cuda.device_count())           # rehearsal: several ranks may share a GPU
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
+        torch.cuda.set_device(local)
+        self.dev = torch.device("cuda", local)
+        if self.world > 1:
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+        assert self.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run"
 
-    from generative_models_amd import common, ops, parallel
-    Model = common.discover_models()["diffusion"]
-    G = common.AttrDict(dict(Model.DG))
-    G.update(lr=3e-4, pad32=0, device=str(dev), timesteps=1000, bs=a.batch, compute_dtype=a.dtype,
-             in_channels=a.in_channels, seed=0, attention=a.attention)
-    model = Model(G).to(dev)
-    model.size = a.size
-    if world > 1:
-        parallel.GradSync(model.net).broadcast_params(0)
-    x, y = synthetic_batch(a.batch, a.in_channels, a.size, dev, 1000 + rank)
-
-    def barrier():
-        if world > 1:
+    def barrier(self):
+        if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    model.train()
-    for _ in range(a.warmup):
-        model.train_step(x, y.clone())
-    barrier()
-    # per-launch HIP events are taken on every 5th step of the timed region only: each event pair costs the command
-    # processor its launch overlap (~3 % of the step when every launch of every step carries one)
-    prof = None if a.no_profile else []
-    nprof = 0
-    t0 = time.perf_counter()
-    side = ops.WGRAD_STREAM
-    for i in range(a.steps):
-        ops.PROFILE = prof if (prof is not None and i % 5 == 0) else None
-        nprof += ops.PROFILE is not None
-        # a launch's HIP-event duration is only that kernel's own time if nothing else shares the chip: the profiled steps keep
-        # the weight gradients on the main stream (they run ~4 % slower than the other steps, which is inside `value`)
-        ops.WGRAD_STREAM = side and ops.PROFILE is None
-        model.train_step(x, y.clone())
-    ops.WGRAD_STREAM = side
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ops.PROFILE = None
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-    images_per_s = world * a.batch * a.steps / elapsed
+    def max_over_ranks(self, seconds):
+        if self.world > 1:
+            t = torch.tensor([seconds], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t)
+        return seconds
 
-    # ---- roofline of the dominant kernel from the per-launch HIP events of the timed region (rank 0)
-    roofline = None
-    if prof:
+    def timed_steps(self, model, batches, steps, prof):
+        """Exactly `steps` train steps bracketed by barrier + synchronize; -> (max-over-ranks seconds, profiled steps)."""
+        from generative_models_amd import ops
+        side = ops.WGRAD_STREAM
+        nprof = 0
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ops.PROFILE = prof if (prof is not None and i % 5 == 0) else None
+            nprof += ops.PROFILE is not None
+            # a launch's HIP-event duration is that kernel's own time only if nothing else shares the chip: the profiled steps keep
+            # the weight gradients on the main stream (they run ~4 % slower than the other steps, which is inside `value`)
+            ops.WGRAD_STREAM = side and ops.PROFILE is None
+            x, y = batches[i % len(batches)]
+            model.train_step(x, y.clone())
+        ops.WGRAD_STREAM = side
+        self.barrier()
+        elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        ops.PROFILE = None
+        return elapsed, nprof
+
+    def roofline(self, prof, nprof, elapsed, steps, key):
+        if not prof:
+            return None
         torch.cuda.synchronize()
-        peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        peak = MFMA_BF16_PEAK_TFLOPS if self.a.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
         by = {}
         for name, s, e, f in prof:
             d = by.setdefault(name, [0.0, 0.0, 0])
             d[0] += s.elapsed_time(e); d[1] += f; d[2] += 1
         dom = max(by, key=lambda k: by[k][0])          # dominant kernel = largest total HIP-event time
-        desc = {"conv3x3_halo_ws_kernel": "3x3 stride-1 bf16 convolution, LDS-resident halo, wave-specialised (forward + data gradients)",
-                "conv3x3_halo_kernel": "3x3 stride-1 bf16 convolution, LDS-resident halo (forward + data gradients)",
-                "conv3x3_halo_ws_kernel[zero-stuffed transposed conv]": "data gradient of the stride-2 convs = the same kernel on the zero-stuffed gradient (2 launches/step; algorithmic FLOPs are 1/4 of its MFMA work)",
-                "conv_igemm_dma_kernel": "im2col LDS-DMA convolution (1x1, strided, upsampled, fp32)",
-                "conv_igemm_kernel": "im2col register-staged convolution (small problems)",
-                "conv_wgrad_slots_kernel": "3x3 weight gradient over padded slots (+ slab reduce)",
-                "conv_wgrad_kernel": "im2col split-K weight gradient (+ slab reduce)"}
         ms, fl, n = by[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")     # PMC FETCH/WRITE_SIZE of the same command (rocprofv3)
+        traffic, source = None, None
+        tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")     # HBM bytes per launch from separate rocprofv3 --pmc passes
         if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
-        roofline = {"kernel": dom, "what": desc.get(dom, ""), "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                    "launches_per_step": n // nprof, "avg_launch_us": round(ms * 1e3 / n, 2),
-                    "share_of_step_time": round(ms * 1e-3 / (elapsed * nprof / a.steps), 3),
-                    "profiled_steps": nprof,
-                    "other_kernels": {k: {"achieved": round(v[1] / (v[0] * 1e-3) / 1e12, 2), "avg_launch_us": round(v[0] * 1e3 / v[2], 2),
-                                          "launches_per_step": v[2] // nprof,
-                                          "share_of_step_time": round(v[0] * 1e-3 / (elapsed * nprof / a.steps), 3)}
-                                      for k, v in by.items() if k != dom}}
+            rec = json.load(open(tfile)).get(key, {})
+            traffic = rec.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+            source = rec.get("provenance")
+        step_s = elapsed * nprof / steps
+        share = lambda v: round(v[0] * 1e-3 / step_s, 3)
+        return {"kernel": dom, "what": KERNEL_DESC.get(dom, ""), "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_provenance": source,
+                "launches_per_step": n // nprof, "avg_launch_us": round(ms * 1e3 / n, 2), "share_of_step_time": share(by[dom]),
+                "profiled_steps": nprof,
+                "other_kernels": {k: {"achieved": round(v[1] / (v[0] * 1e-3) / 1e12, 2), "avg_launch_us": round(v[0] * 1e3 / v[2], 2),
+                                      "launches_per_step": v[2] // nprof, "share_of_step_time": share(v)}
+                                  for k, v in by.items() if k != dom}}
 
-    # ---- reverse-diffusion steps/s: DDIM, guidance off (the `evaluate` path), trajectories not recorded
-    from functools import partial
-    model.eval()
-    model.diffusion.num_steps = a.sampler_steps
-    init = model._aux_rng.normal((a.batch, a.in_channels, a.size, a.size), dev)
-    model.diffusion.sample(net=partial(model.net, guide=y), init_x=init, record=False)     # warm-up
-    ts = float("inf")
-    for _ in range(2):                               # two timed passes, the faster one is reported (the chip re-clocks after the train loop)
-        barrier()
-        t0 = time.perf_counter()
-        model.diffusion.sample(net=partial(model.net, guide=y), init_x=init, record=False)
-        barrier()
-        ts = min(ts, time.perf_counter() - t0)
-    if world > 1:
-        t = torch.tensor([ts], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ts = float(t)
-    sampler = {"steps_per_sec": round(a.sampler_steps / ts, 2),
-               "image_steps_per_sec": round(world * a.batch * a.sampler_steps / ts, 1),
-               "batch_per_gpu": a.batch, "mode": "ddim, guidance off, 1 U-Net forward per step",
-               "timed_steps": a.sampler_steps, "timing": "faster of two passes after one warm-up pass"}
-
-    def time_sampler(kind, cond_w):              # the other two modes of SURVEY M1(ii), same batch and step count
-        model.diffusion.sampler = kind
-        run = lambda: model.diffusion.sample(net=partial(model.net, guide=y), init_x=init, cond_w=cond_w, record=False)
+    def time_sampler(self, model, y, init, kind, cond_w, steps):
+        """One warm-up pass of 2 steps, then ONE timed pass of `steps` sampler iterations."""
+        d = model.diffusion
+        d.sampler = kind
+        run = lambda: d.sample(net=partial(model.net, guide=y), init_x=init, cond_w=cond_w, record=False)
+        d.num_steps = 2
         run()
-        t = float("inf")
-        for _ in range(2):
-            barrier()
-            t0 = time.perf_counter()
-            run()
-            barrier()
-            t = min(t, time.perf_counter() - t0)
-        if world > 1:
-            tt = torch.tensor([t], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t = float(tt)
-        return round(a.sampler_steps / t, 2)
+        d.num_steps = steps
+        self.barrier()
+        t0 = time.perf_counter()
+        run()
+        self.barrier()
+        t = self.max_over_ranks(time.perf_counter() - t0)
+        d.sampler = "ddim"
+        return round(steps / t, 2)
 
-    if a.sampler_steps > 0:
-        sampler["other_modes_steps_per_sec"] = {
-            "ddim, guidance on (the `sample` path: conditional + unconditional forward per step)": time_sampler("ddim", 0.5),
-            "noisy (ancestral), guidance off": time_sampler("noisy", None)}
-        model.diffusion.sampler = "ddim"
+    def run_config(self, key, spec, steps, warmup, headline):
+        from generative_models_amd import common
+        a = self.a
+        cin, S, B, attention, what = spec
+        Model = common.discover_models()["diffusion"]
+        G = common.AttrDict(dict(Model.DG))
+        G.update(lr=3e-4, pad32=0, device=str(self.dev), timesteps=1000, bs=B, compute_dtype=a.dtype, in_channels=cin, seed=0,
+                 attention=attention)
+        model = Model(G).to(self.dev)
+        model.size = S
+        from generative_models_amd import parallel
+        sync = parallel.GradSync(model.net)
+        if self.world > 1:
+            sync.broadcast_params(0)
+        model._sync = sync
+        batches = [synthetic_batch(B, cin, S, self.dev, 1000 + 17 * k + self.rank) for k in range(4)]
+        model.train()
+        for i in range(warmup):
+            x, y = batches[i % 4]
+            model.train_step(x, y.clone())
+        prof = None if a.no_profile else []
+        elapsed, nprof = self.timed_steps(model, batches, steps, prof)
+        ips = self.world * B * steps / elapsed
+        out = {"workload": f"DDPM train step, {cin}x{S}x{S} images, SimpleUnet C=128{' + self-attention' if attention else ''}, "
+                           f"per-GPU batch {B}, T=1000 (BASELINE.json {what})",
+               "value": round(ips, 1), "unit": "images/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": round(elapsed / steps * 1e3, 3), "global_batch": self.world * B}
+        if (cin, S) in FWD_GFLOP and not attention:
+            out["model_tflops"] = round(3 * FWD_GFLOP[(cin, S)] * ips / 1e3, 2)            # 3x forward FLOPs per train image
+        roof = self.roofline(prof, nprof, elapsed, steps, key) if self.rank == 0 else None
+        if roof:
+            out["roofline"] = roof
+        if headline and steps < 50:              # SURVEY §8d M1: >= 50 steady-state steps after >= 10 warm-up
+            e2, _ = self.timed_steps(model, batches, 50, None)
+            out["steady_state"] = {"value": round(self.world * B * 50 / e2, 1), "steps": 50, "warmup": warmup + steps,
+                                   "ms_per_step": round(e2 / 50 * 1e3, 3)}
+        if a.sampler_steps > 0:
+            model.eval()
+            x, y = batches[0]
+            init = model._aux_rng.normal((B, cin, S, S), self.dev)
+            T_main = a.sampler_steps if headline else a.sampler_steps_other
+            T_other = min(a.sampler_steps_other, T_main)
+            sps = self.time_sampler(model, y, init, "ddim", None, T_main)
+            out["sampler"] = {
+                "steps_per_sec": sps, "image_steps_per_sec": round(self.world * B * sps, 1), "batch_per_gpu": B,
+                "mode": "ddim, guidance off, 1 U-Net forward per step", "timed_steps": T_main,
+                "timing": "one timed pass over the whole loop after a 2-step warm-up pass",
+                "other_modes": {
+                    "ddim, guidance on (the `sample` path: conditional + unconditional forward per step)":
+                        {"steps_per_sec": self.time_sampler(model, y, init, "ddim", 0.5, T_other), "timed_steps": T_other},
+                    "noisy (ancestral), guidance off":
+                        {"steps_per_sec": self.time_sampler(model, y, init, "noisy", None, T_other), "timed_steps": T_other}}}
+        out["exchange"] = sync.describe() if self.world > 1 else None
+        del model, batches
+        torch.cuda.empty_cache()
+        return out
 
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu:
-        cpu = cpu_baseline(a.cpu_seconds, a.size, a.in_channels)
-
-    if rank == 0:
-        fwd_gflop = {(1, 28): 4.3913, (3, 32): 5.7447, (3, 64): 22.9754}.get((a.in_channels, a.size))
-        line = {
-            "metric": "ddpm_train_images_per_sec", "value": round(images_per_s, 1), "unit": "images/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"DDPM train step, {a.in_channels}x{a.size}x{a.size} images, SimpleUnet C=128"
-                                   f"{' + self-attention' if a.attention else ''}, per-GPU batch {a.batch}, T=1000"
-                                   f"{' (BASELINE.json configs[1])' if (a.in_channels, a.size, a.batch, a.attention) == (1, 28, 1024, 0) else ''}",
-                       "global_batch": world * a.batch, "parallelism": f"dp{world}",
-                       "optimizer": "fused Adam lr=3e-4", "mean_type": "v"},
-            "sampler": sampler,
-        }
-        if fwd_gflop:
-            line["model_tflops"] = round(3 * fwd_gflop * images_per_s / 1e3, 2)   # 3x forward FLOPs per train image
-        if roofline:
-            line["roofline"] = roofline
-        if cpu:
-            line["cpu_baseline"] = cpu
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    def main(self):
+        a = self.a
+        if a.config == "custom":
+            plan = [("custom", (a.in_channels, a.size, a.batch, a.attention, "none: custom shape"))]
+        elif a.config != "auto":
+            plan = [(a.config, CONFIGS[a.config])]
+        elif self.world == 1:
+            plan = [("cfg2", CONFIGS["cfg2"]), ("cfg1", CONFIGS["cfg1"]), ("cfg3", CONFIGS["cfg3"])]
+        else:
+            plan = [("cfg3", CONFIGS["cfg3"]), ("cfg4", CONFIGS["cfg4"])]
+        if not a.others:
+            plan = plan[:1]
+        head = self.run_config(plan[0][0], plan[0][1], a.steps, a.warmup, True)
+        others = {k: self.run_config(k, spec, max(a.steps, 50), max(a.warmup, 10), False) for k, spec in plan[1:]}
+        cpu = None
+        if self.rank == 0 and self.world == 1 and not a.no_cpu:
+            cpu = cpu_baseline(a.cpu_seconds, plan[0][1][1], plan[0][1][0])
+        if self.rank == 0:
+            line = {"metric": "ddpm_train_images_per_sec", "value": head["value"], "unit": "images/s", "n_gpus": self.world,
+                    "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                    "config": {"workload": head["workload"], "global_batch": head["global_batch"], "parallelism": f"dp{self.world}",
+                               "optimizer": "fused Adam lr=3e-4", "mean_type": "v", "resident_batches": 4}}
+            for k in ("steady_state", "sampler", "model_tflops", "roofline", "exchange"):
+                if head.get(k) is not None:
+                    line[k] = head[k]
+            if cpu:
+                line["cpu_baseline"] = cpu
+            if others:
+                line["other_configs"] = others
+            print(json.dumps(line))
+        if self.world > 1:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    Bench(parse()).main()

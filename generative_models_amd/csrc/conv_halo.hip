@@ -948,7 +948,8 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     if ((dev & 0x100) && stats && stats_bytes >= 256 * 16 * 4 * 8) { p.stamps = (unsigned long long*)stats; stats = nullptr; }
     if (stats && cout == out_cstride && stats_bytes >= ntiles * 8 * 2 * (int64_t)(out_cstride / 4) * 2 * 4 && H * W >= 32) p.stats = stats;
     p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 2); p.inv_w = 1.0f / (float)W;
-    dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256), cout / 128);
+    const int ncu = gmk_cu_limit();
+    dim3 grid((unsigned)(ntiles < ncu ? ntiles : ncu), cout / 128);
     p.nfull = (int)ntiles; p.nhalf = 0;
     {   // tail balancing of the wave-specialised kernel: a last round of at most G/2 tiles runs as twice as many half jobs
         const int G = (int)grid.x, rem = (int)(ntiles % G);

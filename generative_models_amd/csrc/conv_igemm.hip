@@ -907,7 +907,7 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
     gmk_note_kernel(dma ? 2 : 1);
     if (dma) {
         p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1; p.nbw = (unsigned)nbw; p.nbo = (unsigned)nbo;
-        int ncu = 256;
+        const int ncu = gmk_cu_limit();
         const int ntiles = (p.M + 255) / 256;
         dim3 grid(ntiles < ncu ? ntiles : ncu, cout / kBN);
         if (dtype == GMK_BF16) conv_igemm_dma_kernel<bf16_t><<<grid, 512, 0, gmk_stream(stream)>>>(p);

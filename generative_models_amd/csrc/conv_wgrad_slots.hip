@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_kernel(const SlotPara
 
 int gmk_wgrad_slots_nsplit(int cout, int ktot) {
     const int tiles = (cout / 128) * (ktot / 64);
-    int ns = 256 / tiles;
+    int ns = gmk_cu_limit() / tiles;
     return ns < 1 ? 1 : ns;
 }
 

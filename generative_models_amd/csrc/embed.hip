@@ -26,13 +26,34 @@ __global__ __launch_bounds__(256) void guide_onehot_kernel(const int64_t* __rest
     keep[b] = masked ? 0.f : 1.f;                      // :57 rows zeroed after the MLP
 }
 
+// classifier-free label drop, in place: y[b] = -1 where element b of the uniform stream (seed, offset) is below p
+__global__ __launch_bounds__(256) void label_drop_kernel(int64_t* __restrict__ y, int B, float p, uint64_t seed, uint64_t offset) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t rnd[4];
+    philox4x32(offset + (uint64_t)(b >> 2), seed, rnd);      // same element mapping as gmk_rng_uniform
+    if (u01(rnd[b & 3]) < p) y[b] = -1;
+}
+
+// out[0] = scale * sum(x[0..n)): one workgroup, fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+}
+
 constexpr int TM = 64, TN = 64, TK = 16;
 
 // C[i][j] = (acc ? C : 0) + rowscale[i] * (bias[j] + sum_k fa(A[i*sa0 + k*sa1]) * fb(B[k*sb0 + j*sb1]))
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t sa0, int64_t sa1,
                                                       const float* __restrict__ Bm, int64_t sb0, int64_t sb1,
                                                       float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                      const float* __restrict__ bias, const float* __restrict__ rowscale,
+                                                      const float* __restrict__ bias, const float* __restrict__ bias2,
+                                                      const float* __restrict__ rowscale,
                                                       int silu, int accumulate, float* __restrict__ ws, int kchunk) {
     __shared__ float As[TK][TM + 4];
     __shared__ float Bs[TK][TN + 4];
@@ -92,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         return;
     }
     if (j >= N) return;
-    const float bj = bias ? bias[j] : 0.f;
+    const float bj = (bias ? bias[j] : 0.f) + (bias2 ? bias2[j] : 0.f);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int i = i0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -105,13 +126,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc,
                                                                int M, int N, int nz, const float* __restrict__ bias,
+                                                               const float* __restrict__ bias2,
                                                                const float* __restrict__ rowscale, int accumulate) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)M * N) return;
     const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
     float s = 0.f;
     for (int z = 0; z < nz; ++z) s += ws[(int64_t)z * M * N + idx];
-    float v = (s + (bias ? bias[j] : 0.f)) * (rowscale ? rowscale[i] : 1.f);
+    float v = (s + ((bias ? bias[j] : 0.f) + (bias2 ? bias2[j] : 0.f))) * (rowscale ? rowscale[i] : 1.f);
     float* c = C + (int64_t)i * ldc + j;
     *c = accumulate ? *c + v : v;
 }
@@ -185,6 +207,18 @@ extern "C" int gmk_guide_onehot(const int64_t* guide, float* onehot, float* keep
     return gmk_check_launch("gmk_guide_onehot");
 }
 
+extern "C" int gmk_label_drop(int64_t* y, int B, float p, uint64_t seed, uint64_t offset, void* stream) {
+    GMK_REQUIRE(y && B > 0 && p >= 0.f && p <= 1.f, "gmk_label_drop: bad arguments");
+    label_drop_kernel<<<(B + 255) / 256, 256, 0, gmk_stream(stream)>>>(y, B, p, seed, offset);
+    return gmk_check_launch("gmk_label_drop");
+}
+
+extern "C" int gmk_mean(const float* x, int n, float* out, void* stream) {
+    GMK_REQUIRE(x && out && n > 0, "gmk_mean: bad arguments");
+    sum_scale_kernel<<<1, 256, 0, gmk_stream(stream)>>>(x, n, 1.0f / (float)n, out);
+    return gmk_check_launch("gmk_mean");
+}
+
 static int gemm_ksplit(int M, int N, int K, int* kchunk) {
     const int tiles = ((N + TN - 1) / TN) * ((M + TM - 1) / TM);
     int nz = 1;
@@ -208,8 +242,8 @@ extern "C" int64_t gmk_gemm_f32_workspace_bytes(int M, int N, int K) {
 }
 
 extern "C" int gmk_gemm_f32(const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1, float* C,
-                            int64_t ldc, int M, int N, int K, const float* bias, const float* rowscale, int silu,
-                            int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+                            int64_t ldc, int M, int N, int K, const float* bias, const float* bias2, const float* rowscale,
+                            int silu, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
     GMK_REQUIRE(A && B && C, "gmk_gemm_f32: null pointer");
     GMK_REQUIRE(M > 0 && N > 0 && K > 0 && ldc >= N, "gmk_gemm_f32: bad shape M=%d N=%d K=%d ldc=%lld", M, N, K,
                 (long long)ldc);
@@ -217,13 +251,13 @@ extern "C" int gmk_gemm_f32(const float* A, int64_t sa0, int64_t sa1, const floa
     int nz = gemm_ksplit(M, N, K, &kc);
     if (nz > 1 && (!workspace || workspace_bytes < (int64_t)nz * M * N * 4)) { nz = 1; kc = K; }
     dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM, nz);
-    gemm_f32_kernel<<<grid, 256, 0, gmk_stream(stream)>>>(A, sa0, sa1, B, sb0, sb1, C, ldc, M, N, K, bias, rowscale, silu,
-                                                          accumulate, (float*)workspace, kc);
+    gemm_f32_kernel<<<grid, 256, 0, gmk_stream(stream)>>>(A, sa0, sa1, B, sb0, sb1, C, ldc, M, N, K, bias, bias2, rowscale,
+                                                          silu, accumulate, (float*)workspace, kc);
     int rc = gmk_check_launch("gmk_gemm_f32");
     if (rc || nz == 1) return rc;
     const int64_t n = (int64_t)M * N;
     gemm_splitk_reduce_kernel<<<(int)((n + 255) / 256), 256, 0, gmk_stream(stream)>>>((const float*)workspace, C, ldc, M, N, nz,
-                                                                                       bias, rowscale, accumulate);
+                                                                                       bias, bias2, rowscale, accumulate);
     return gmk_check_launch("gmk_gemm_f32(reduce)");
 }
 

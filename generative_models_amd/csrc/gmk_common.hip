@@ -43,3 +43,20 @@ int gmk_kernel_choice(int which, const char* env) {
     const char* v = getenv(env);
     return v ? atoi(v) : 0;
 }
+
+// Workgroups the persistent kernels (one 512-thread, 160 KiB-LDS workgroup per CU) may occupy.  256 = the whole chip; a
+// data-parallel run lowers it so that RCCL's all-reduce kernels find free CUs beside the backward pass instead of queueing
+// behind a chip-filling persistent grid (generative_models_amd/parallel.py; GMK_CU_LIMIT overrides).
+static int g_cu_limit = -1;
+extern "C" int gmk_set_cu_limit(int n) {
+    if (n < 8 || n > 256) { gmk_set_error("gmk_set_cu_limit: %d not in [8, 256]", n); return GMK_ERR_ARG; }
+    g_cu_limit = n;
+    return 0;
+}
+int gmk_cu_limit(void) {
+    if (g_cu_limit > 0) return g_cu_limit;
+    const char* v = getenv("GMK_CU_LIMIT");
+    const int n = v ? atoi(v) : 256;
+    return n >= 8 && n <= 256 ? n : 256;
+}
+extern "C" int gmk_get_cu_limit(void) { return gmk_cu_limit(); }

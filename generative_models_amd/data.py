@@ -97,3 +97,44 @@ def load_mnist(bs, binarize=True, pad32=False, root="data", device="cpu", seed=0
     """-> (train_loader, test_loader), the call shape of gms/common.py:102."""
     return (MnistLoader(root, True, bs, binarize, pad32, device, seed, rank, world),
             MnistLoader(root, False, bs, binarize, pad32, device, seed + 1, rank, world))
+
+
+class SyntheticMNIST:
+    """MNIST-shaped stand-in for `load_mnist` when the IDX files are absent (no network here): per epoch `n_batches`
+    batches of (x fp32 [bs, 1, 28|32, 28|32], y int64 [bs] in 0..9).  About 85 % of the raw pixels are background (0 before the
+    transform chain), the rest uniform in [0, 1); the reference's transform chain is then applied as `transform` does
+    (binarize or 2x-1, zero pad32).  On a GPU the draws come from the device's counter-based Philox kernels — a host generator
+    costs 20+ ms per 1024-image batch and would bound the training loop."""
+
+    def __init__(self, bs, n_batches, pad32, binarize, device, seed):
+        self.bs, self.n_batches = int(bs), int(n_batches)
+        self.pad32, self.binarize, self.device = bool(pad32), bool(binarize), device
+        self.seed, self._counter = int(seed), 0
+        self._host_gen = torch.Generator().manual_seed(self.seed)
+
+    def __len__(self):
+        return self.n_batches
+
+    def _draw(self):
+        shape = (self.bs, 1, 28, 28)
+        if str(self.device).startswith("cuda"):
+            from . import ops
+            quads = (self.bs * 784 + 3) // 4                     # Philox counters one uniform tensor of this shape consumes
+            base = self._counter
+            self._counter += 2 * quads + (self.bs + 3) // 4
+            raw = ops.rng_uniform(shape, self.seed, base, self.device)
+            ink = ops.rng_uniform(shape, self.seed, base + quads, self.device) < 0.15
+            labels = (ops.rng_uniform((self.bs,), self.seed, base + 2 * quads, self.device) * 10).long().clamp_(0, 9)
+            return raw, ink, labels
+        raw = torch.rand(shape, generator=self._host_gen)
+        ink = torch.rand(shape, generator=self._host_gen) < 0.15
+        return raw, ink, torch.randint(0, 10, (self.bs,), generator=self._host_gen)
+
+    def __iter__(self):
+        for _ in range(self.n_batches):
+            raw, ink, labels = self._draw()
+            x = raw * ink                                          # background pixels are exactly 0 before the transform
+            x = (x > 0.5).float() if self.binarize else 2 * x - 1  # gms/common.py:105-109
+            if self.pad32:
+                x = torch.nn.functional.pad(x, (2, 2, 2, 2))       # :110-111 (zeros)
+            yield x, labels

@@ -18,7 +18,7 @@ from pathlib import Path
 
 import torch
 
-from .. import common, parallel
+from .. import common, ops, parallel
 from .gaussian_diffusion import GaussianDiffusion, PhiloxStream
 from .optim import FusedAdam
 from .simple_unet import SimpleUnet
@@ -79,11 +79,13 @@ def make_plugin(GMBase, AttrDict):
         # -- training (diffusion_model.py:63-74)
         def train_step(self, x, y):
             B = x.shape[0]
-            # classifier-free label drop (:67); mutates the caller's y in place like the reference, but the mask
-            # comes from the device RNG (the reference's CPU-generated mask forces a host sync every step)
-            drop = self._aux_rng.uniform((B,), x.device) < float(self.G.cf_drop_prob if "cf_drop_prob" in self.G
-                                                                   else self.DG.cf_drop_prob)
-            y.masked_fill_(drop, -1)
+            # classifier-free label drop (:67): mutates the caller's y in place like the reference, but the mask comes from the
+            # device RNG inside one small kernel (the reference's CPU-generated mask forces a host sync every step)
+            p_drop = float(self.G.cf_drop_prob if "cf_drop_prob" in self.G else self.DG.cf_drop_prob)
+            if y.dtype == torch.int64 and y.is_contiguous() and y.data_ptr() % 16 == 0:
+                ops.label_drop(y, p_drop, self._aux_rng.seed, self._aux_rng._take(B))
+            else:                                   # odd label tensors (a slice, int32): same draw, torch does the masking
+                y.masked_fill_(self._aux_rng.uniform((B,), x.device) < p_drop, -1)
             if self._sync is None:
                 self._sync = parallel.GradSync(self.net)
             world = parallel.world()
@@ -91,7 +93,7 @@ def make_plugin(GMBase, AttrDict):
                                                         on_grads_ready=self._sync.hook)
             self._sync.finish()
             self.optimizer.step(grad_scale=1.0 / world)
-            metrics = {"loss": out["loss"].mean()}
+            metrics = {"loss": ops.mean(out["loss"])}
             metrics["loss_scale"] = torch.tensor(1.0)
             return metrics
 

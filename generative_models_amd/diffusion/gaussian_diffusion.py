@@ -69,6 +69,29 @@ def _unwrap(net):
     return net, kw.get("guide"), kw.get("cond_w")
 
 
+def resolve_guidance(*, sample_cond_w, net_cond_w, kw_cond_w, has_teacher, sampler):
+    """Guidance-weight policy of `GaussianDiffusion.sample` (gaussian_diffusion.py:246-257,271-278) as a pure function.
+    net_cond_w: the per-sample draw 4*U[0,1) made when the caller passed `cond_w` (else None); kw_cond_w: a `cond_w=` keyword the
+    caller's partial already carried.  -> (student_w, guidance_w, use_teacher):
+      student_w    conditions the network through `cond_w_embed`
+      guidance_w   classifier-free guidance weight (None: one unguided forward per step)
+      use_teacher  evaluate the frozen teacher instead of `net` (sampler='teacher_test')
+    No teacher: guidance_w = sample_cond_w unless that is -1.0 (then the draw, which is None when the caller did not ask) —
+    so `--sample_cond_w 2.0` also guides `evaluate()`, which passes no cond_w (:257).  With a teacher the student is
+    conditioned on the draw and never guided (:252-255); 'teacher_test' runs the teacher, guided by the weight the student
+    would have been conditioned on (:271-278: `net.keywords['cond_w']`), unguided when there is none."""
+    fixed = sample_cond_w is not None and float(sample_cond_w) != -1.0
+    if has_teacher:
+        student_w, guidance_w = net_cond_w, None
+    else:
+        student_w, guidance_w = kw_cond_w, (sample_cond_w if fixed else net_cond_w)
+    if sampler == "teacher_test":
+        if not has_teacher:
+            raise ValueError("sampler='teacher_test' needs a teacher_net")
+        return None, student_w, True
+    return student_w, guidance_w, False
+
+
 class _VLoss(torch.autograd.Function):
     """loss_b = max(mse_x, mse_eps) of the clipped v-parameterised prediction, differentiable w.r.t. v."""
 
@@ -187,33 +210,18 @@ class GaussianDiffusion:
         module, guide, kw_cond_w = _unwrap(net)
         B = init_x.shape[0]
         dev = init_x.device
-        student_w = None
         if cond_w is not None and net_cond_w is None:
             net_cond_w = 4.0 * self.rng.uniform((B,), dev)           # :247-251
-        if self.teacher_net is not None and self.sampler != "teacher_test":
-            # :252-255 during distillation the student is conditioned on w instead of doing classifier-free guidance
-            student_w = ops.aligned(net_cond_w.float()) if net_cond_w is not None else None
-            cond_w = None
-        teacher_w = None
-        if self.sampler == "teacher_test":                            # :271-278 guided teacher with the student's w
-            module = self.teacher_net
-            teacher_w = kw_cond_w if kw_cond_w is not None else net_cond_w
-            if teacher_w is None:
-                raise ValueError("sampler='teacher_test' needs a guidance weight (cond_w)")
-            cond_w = 0.5
-        if teacher_w is not None:
-            w = ops.aligned(teacher_w.float())
-        elif cond_w is not None:
-            if isinstance(self.sample_cond_w, torch.Tensor):
-                w = self.sample_cond_w.to(dev).float().expand(B).contiguous()
-            elif self.sample_cond_w is not None and float(self.sample_cond_w) != -1.0:
-                w = torch.full((B,), float(self.sample_cond_w), device=dev)
-            else:
-                w = ops.aligned(net_cond_w.float())                   # :257
-        else:
-            w = None
         if self.sampler not in ("ddim", "noisy", "teacher_test"):
             raise NotImplementedError(self.sampler)
+        student_w, w, use_teacher = resolve_guidance(sample_cond_w=self.sample_cond_w, net_cond_w=net_cond_w, kw_cond_w=kw_cond_w,
+                                                     has_teacher=self.teacher_net is not None, sampler=self.sampler)
+        if use_teacher:
+            module = self.teacher_net
+        as_vec = lambda t: (t.to(dev).float().expand(B).contiguous() if isinstance(t, torch.Tensor)
+                            else torch.full((B,), float(t), device=dev))
+        student_w = ops.aligned(as_vec(student_w)) if student_w is not None else None
+        w = ops.aligned(as_vec(w)) if w is not None else None
         if w is not None and guide is None:
             raise ValueError("classifier-free guidance needs class labels (net must carry guide=)")
         z_t = ops.aligned(init_x.float())
@@ -229,7 +237,7 @@ class GaussianDiffusion:
                 vu = None
             else:
                 lvec = torch.full((2 * B,), float(lt), device=dev)
-                v2 = module.forward_hip(torch.cat([z_t, z_t]), lvec, guide2, None)
+                v2 = module.forward_hip(torch.cat([z_t, z_t]), lvec, guide2, None if student_w is None else torch.cat([student_w, student_w]))
                 v, vu = v2[:B], v2[B:]
             noise = None
             if self.sampler == "noisy":

@@ -101,12 +101,14 @@ class SimpleUnet(nn.Module):
         self.drop_seed, self._drop_counter = 0x5EEDD0, 0
         self.attention = bool(attention)
         self._inventory = param_inventory(channels, in_channels, self.attention)
-        # arena order: the 12 emb_layers Linear weights, then their biases (one batched GEMM serves all 12
-        # ResBlocks), then everything else in reference order; every tensor starts on a 16-byte boundary.
+        # arena order: the 12 emb_layers Linear weights, their biases, the 12 conv1 biases (one batched GEMM with two bias
+        # tables serves all 12 ResBlocks), then everything else in reference order; every tensor starts on a 16-byte boundary.
         emb_w = [f"{b}.emb_layers.1.weight" for b in RES_BLOCKS]
         emb_b = [f"{b}.emb_layers.1.bias" for b in RES_BLOCKS]
+        conv1_b = [f"{b}.in_layers.2.bias" for b in RES_BLOCKS]      # second bias table of the emb_layers GEMM (_embed_fwd)
         shapes = dict(self._inventory)
-        order = emb_w + emb_b + [n for n, _ in self._inventory if n not in set(emb_w + emb_b)]
+        front = emb_w + emb_b + conv1_b
+        order = front + [n for n, _ in self._inventory if n not in set(front)]
         self._offsets = OrderedDict()
         off = 0
         for n in order:
@@ -151,7 +153,8 @@ class SimpleUnet(nn.Module):
             self._pv[n] = p.data
             self._gv[n] = p.grad
         self._packs = None
-        self._conv1_bias_idx = None
+        self._plist = [named[n] for n, _ in self._inventory]
+        self._packed_version = -1
         self._side = None          # side stream of the weight gradients (backward_hip)
         self._packs_stale = True
         self._freqs = {}
@@ -170,6 +173,12 @@ class SimpleUnet(nn.Module):
 
     def mark_params_changed(self):
         self._packs_stale = True
+
+    def _version_sum(self):
+        """Sum of the parameters' autograd version counters: any in-place update through torch (torch.optim, EMA copy_,
+        p.data.mul_ ...) bumps one of them, so the packed convolution weights are refreshed without the caller having to
+        say so.  Kernel-side updates (FusedAdam, broadcast) do not bump versions and call mark_params_changed()."""
+        return sum(p._version for p in self._plist)
 
     def param(self, name):
         return self._pv[name]
@@ -215,6 +224,7 @@ class SimpleUnet(nn.Module):
             self._pack_table = table
         ops.pack_conv_weights_multi(self.flat_params, self._pack_buf, self._pack_table)      # all convolutions, one launch
         self._packs_stale = False
+        self._packed_version = self._version_sum()
 
     # ---- embedding path (simple_unet.py:45-64 + the 12 emb_layers of :166) --------------------------------
     def _freq_table(self, max_period, dev):
@@ -262,11 +272,8 @@ class SimpleUnet(nn.Module):
         # conv1's bias rides with the embedding: h = conv1(a) + bias + emb_out[..., None, None] (simple_unet.py:183) is a
         # per-(sample, channel) addend, applied by the GroupNorm that consumes h (gmk_gn_silu_fwd xadd) instead of by the
         # MFMA kernel's epilogue, where its loads cost 25 % of a tile
-        if self._conv1_bias_idx is None or self._conv1_bias_idx.device != dev:
-            idx = [torch.arange(self._offsets[f"{b}.in_layers.2.bias"], self._offsets[f"{b}.in_layers.2.bias"] + C) for b in RES_BLOCKS]
-            self._conv1_bias_idx = torch.cat(idx).to(dev)
-        bias_all = bcat + self.flat_params[self._conv1_bias_idx]
-        emb_all = ops.gemm(emb, wcat.t(), bias=bias_all, silu_a=True)
+        c0 = self._offsets[f"{RES_BLOCKS[0]}.in_layers.2.bias"]
+        emb_all = ops.gemm(emb, wcat.t(), bias=bcat, bias2=self.flat_params[c0:c0 + 12 * C], silu_a=True)
         if ctx is not None:
             ctx["emb"] = emb
             ctx["emb_all"] = emb_all
@@ -310,7 +317,8 @@ class SimpleUnet(nn.Module):
         h = ops.conv_igemm(a, wf1, C, 3, ops.NORMAL, (H, W))      # bias + embedding enter through `xadd` below
         eadd = emb_all[:, blk * C:(blk + 1) * C]
         drop = None
-        if self.dropout > 0.0 and self.training:              # mask = Philox uniform >= p, regenerated by the backward kernel
+        # reference quirk kept: `up.seq[3]`'s ResBlock is built WITHOUT the dropout argument (simple_unet.py:138), so it never drops
+        if self.dropout > 0.0 and self.training and name != "up.seq.3.0":      # mask = Philox uniform >= p, regenerated by the backward kernel
             drop = (self.dropout, self.drop_seed, self._drop_counter)
             self._drop_counter += (h.numel() + 3) // 4
         a2, mean2, rstd2 = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], 32, dropout=drop,
@@ -448,7 +456,7 @@ class SimpleUnet(nn.Module):
     # ---- whole network ---------------------------------------------------------------------------------
     def forward_hip(self, x, logsnr, guide=None, cond_w=None, ctx=None):
         """x: NCHW fp32 [B, in_channels, H, W]; returns NCHW fp32.  ctx: dict receiving what backward needs."""
-        if self._packs_stale:
+        if self._packs_stale or self._packed_version != self._version_sum():
             self._repack()
         P, C, T = self._pv, self.channels, self.compute_dtype
         B, cin, H, W = x.shape
@@ -497,7 +505,7 @@ class SimpleUnet(nn.Module):
         late = ("up.seq.4", "up.seq.5", "up.seq.6", "out.")
         mid = ("up.seq.0", "up.seq.1", "up.seq.2", "up.seq.3")
         emb = ("time_embed", "cond_w_embed", "guide_embed")
-        is_emb = lambda n: n.startswith(emb) or ".emb_layers." in n
+        is_emb = lambda n: n.startswith(emb) or ".emb_layers." in n or n.endswith(".in_layers.2.bias")   # the arena's front block
         b0 = rng(lambda n: n.startswith(late) and not is_emb(n))
         b1 = rng(lambda n: n.startswith(mid) and not is_emb(n))
         b2 = rng(lambda n: (n.startswith("down.") or n.startswith("turn.") or n.startswith("attn.")) and not is_emb(n))

@@ -1,30 +1,31 @@
-"""Training driver — mirror of reference gms/main.py (load_model_and_data :43-92, train :152-217).
+"""Training driver for the `GM` plugin surface — the caller above the hot path (reference gms/main.py).
 
-Same flag surface (`DG`, :20-40, merged with the model's `DG`, two-pass argparse with prefix matching), same
-eval-first epoch order and the same calls on the model (to / eval / loss / evaluate / save / train / train_step),
-same metric key naming (`<model>/train/<key>`, `<model>/test/<key>`, `dt/train`, `num_vars`).
+What is kept from the reference is its INTERFACE: the flag table `DG` (gms/main.py:20-40) merged with the selected model's own
+`DG`, `--weights_from <dir>/model.pt` re-reading `<dir>/hps.yaml` (:55-64,79-82), the order in which a model is driven (evaluate
+first, then train: :159-217), the calls made on it (`to / eval / loss / evaluate / save / train / train_step`), the metric key
+naming (`<model>/test/<key>`, `<model>/train/<key>`, `eval/*`, `dt/*`, `num_vars`) and the `load_model_and_data()` / `train()`
+entry points.  How it is built is this repository's own: one `Session` object per run, flags resolved in layers by `FlagSpace`,
+an `EpochLog` that keeps device tensors on the device until the epoch ends (the reference's `.cpu()` per step, :215, would
+serialise host and GPU every step), rank-aware logging and checkpointing for one-process-per-GPU runs.
 
-Differences forced by the environment (no network, no tensorboard/ignite in the image): the data source is a
-synthetic MNIST-shaped generator (`--data synthetic`: x fp32 [B,1,28,28] in [-1,1] with the 2x-1 scaling and
-zero pad-to-32 of gms/common.py:104-112, y int64 in 0..9), the writer is `common.NullWriter`, and the heavy eval
-(FID / precision-recall, :95-149) is SURVEY §8f "next" and skipped.  The per-step `.cpu()` of :215 is deferred to
-the end of the epoch so the training loop never synchronises with the device.
+Environment differences (no network, no tensorboard / ignite in the image): `--data synthetic` (default) is an MNIST-shaped
+generator, `--data mnist` reads the IDX files if they are present; the writer is `common.NullWriter`.
 
     python -m generative_models_amd.main --model=diffusion --epochs=1 --bs 32
-    torchrun --nproc-per-node 8 -m generative_models_amd.main --model=diffusion   (one process per GPU, RCCL)
+    torchrun --nproc-per-node 8 -m generative_models_amd.main --model=diffusion      (one process per GPU, RCCL)
 """
 import argparse
 import os
 import time
-from itertools import count
+from collections import defaultdict
 from pathlib import Path
 
-import numpy as np
 import torch
 import torch.distributed as dist
 import yaml
 
 from . import common, parallel
+from . import data as datasets
 from . import metrics as heavy
 
 DG = common.AttrDict()     # gms/main.py:20-40
@@ -51,160 +52,216 @@ DG.data_root = Path("data")
 DG.train_batches = 8       # synthetic batches per epoch (per rank)
 DG.test_batches = 2
 
+SyntheticMNIST = datasets.SyntheticMNIST       # kept importable from here
 
-class SyntheticMNIST:
-    """MNIST-shaped batches: ~85 % background pixels at exactly -1 (after 2x-1), the rest uniform in [-1, 1]."""
 
-    def __init__(self, bs, n_batches, pad32, binarize, device, seed):
-        self.bs, self.n, self.pad32, self.binarize, self.device = bs, n_batches, pad32, binarize, device
-        self.gen = torch.Generator().manual_seed(seed)
-        self._seed, self._ctr = int(seed), 0
+class FlagSpace:
+    """Flags in layers: the driver's table, then either the model's own `DG` or — with `--weights_from` — the `hps.yaml`
+    saved next to the checkpoint, then the command line.  Driver keys parse through `common.args_type` (bools as
+    'True'/'False', '1e3' for ints, expanded Paths); keys a later layer introduces parse with the type of their default."""
 
-    def __iter__(self):
-        on_gpu = str(self.device).startswith("cuda")
-        for _ in range(self.n):
-            if on_gpu:      # drawn on the device (Philox kernels): the host generator costs 20+ ms per batch and would bound the loop
-                from . import ops
-                shape = (self.bs, 1, 28, 28)
-                nq = (self.bs * 784 + 3) // 4
-                raw = ops.rng_uniform(shape, self._seed, self._ctr, self.device)
-                ink = ops.rng_uniform(shape, self._seed, self._ctr + nq, self.device) < 0.15
-                y = (ops.rng_uniform((self.bs,), self._seed, self._ctr + 2 * nq, self.device) * 10).long().clamp_(0, 9)
-                self._ctr += 2 * nq + (self.bs + 3) // 4
+    def __init__(self, base):
+        self.base = base
+
+    @staticmethod
+    def _parser(typed):
+        parser = argparse.ArgumentParser()
+        for key, (convert, default) in typed.items():
+            parser.add_argument(f"--{key}", type=convert, default=default)
+        return parser
+
+    def resolve(self, argv=None):
+        """-> (G, Model)"""
+        typed = {key: (common.args_type(value), value) for key, value in self.base.items()}
+        peek, _ = self._parser(typed).parse_known_args(argv)          # first look: which model, which checkpoint, which logdir
+        registry = common.discover_models()
+        if peek.weights_from != Path("."):
+            with open(peek.weights_from.parent / "hps.yaml") as f:
+                layer = dict(yaml.load(f, Loader=yaml.Loader))
+            layer.pop("full_cmd", None)                                   # the saved command line is a record, not a flag
+            Model = registry[layer["model"]]
+        else:
+            Model = registry[peek.model]
+            layer = dict(Model.DG)
+            layer["logdir"] = peek.logdir / peek.model
+        for key, value in layer.items():
+            convert = typed[key][0] if key in typed else type(value)
+            typed[key] = (convert, value)
+        G = common.AttrDict(vars(self._parser(typed).parse_args(argv)))
+        return G, Model
+
+
+class EpochLog:
+    """Metric lists of one epoch.  Values may be device tensors: they are moved to the host in ONE pass when the epoch is
+    flushed, so nothing in the training loop waits for the GPU."""
+
+    def __init__(self, model_key):
+        self.model_key = model_key
+        self.values = defaultdict(list)
+
+    def key_for(self, split, name):
+        if name == "nlogp":                                            # gms/main.py:170-174,212-214
+            return "eval/nlogp" if split == "test" else "train/nlogp"
+        return f"{self.model_key}/{split}/{name}"
+
+    def add(self, split, metrics):
+        for name, value in metrics.items():
+            self.values[self.key_for(split, name)].append(value.detach() if isinstance(value, torch.Tensor) else value)
+
+    def set(self, key, value):
+        self.values[key] = value
+
+    def to_host(self):
+        out = {}
+        for key, vals in self.values.items():
+            if isinstance(vals, list):
+                out[key] = [v.cpu().item() if isinstance(v, torch.Tensor) else v for v in vals]
             else:
-                raw = torch.rand((self.bs, 1, 28, 28), generator=self.gen)
-                ink = torch.rand((self.bs, 1, 28, 28), generator=self.gen) < 0.15
-                y = torch.randint(0, 10, (self.bs,), generator=self.gen)
-            x = torch.where(ink, raw, torch.zeros_like(raw))
-            x = (x > 0.5).float() if self.binarize else 2 * x - 1          # gms/common.py:105-109
-            if self.pad32:
-                x = torch.nn.functional.pad(x, (2, 2, 2, 2))                # :110-111 pads with 0
-            yield x, y
+                out[key] = vals
+        return out
 
-    def __len__(self):
-        return self.n
+
+class Session:
+    """One run of the driver: model, data, feature extractors, flags."""
+
+    def __init__(self, model, train_ds, test_ds, autoencoder, classifier, G):
+        self.model, self.train_ds, self.test_ds = model, train_ds, test_ds
+        self.autoencoder, self.classifier, self.G = autoencoder, classifier, G
+        self.device = getattr(model, "run_device", G.device)
+        self.lead = parallel.rank() == 0                               # rank 0 prints, writes hps.yaml and checkpoints
+        self.writer = common.NullWriter(G.logdir)
+
+    def _batches(self, ds):
+        for batch in ds:
+            yield batch[0].to(self.device), batch[1].to(self.device)
+
+    def flush(self, log, epoch):
+        record = log.to_host()
+        if self.lead:
+            common.dump_logger(record, self.writer, epoch, self.G)
+        return EpochLog(self.G.model)
+
+    def evaluate(self, log, epoch):
+        """Test-set pass + the model's own `evaluate` (gms/main.py:159-183)."""
+        self.model.eval()
+        last = None
+        with torch.no_grad():
+            if hasattr(self.model, "loss"):
+                for last in self._batches(self.test_ds):
+                    log.add("test", self.model.loss(*last)[1])
+            else:
+                last = next(self._batches(self.test_ds))
+            started = time.time()
+            self.model.evaluate(self.writer if self.lead else None, last[0], last[1], epoch)
+            log.set("dt/eval", time.time() - started)
+        log.set("num_vars", common.count_vars(self.model))
+        return last
+
+    def checkpoint(self, log, last_batch):
+        if not self.lead:
+            return
+        Path(self.G.logdir).mkdir(parents=True, exist_ok=True)
+        self.model.save(Path(self.G.logdir), *last_batch)
+        print("SAVED MODEL", self.G.logdir)
+        if self.G.eval_heavy:                                          # gms/main.py:191-196
+            print("RUNNING HEAVY EVAL...")
+            started = time.time()
+            host_log = defaultdict(list)
+            heavy.eval_heavy(host_log, self.model, self.test_ds, self.autoencoder, self.classifier, self.G)
+            for key, vals in host_log.items():
+                log.set(key, vals)
+            log.set("dt/eval_heavy", time.time() - started)
+            print("DONE HEAVY EVAL")
+
+    def train_epoch(self, log):
+        self.model.train()
+        started = time.time()
+        if not self.G.skip_training:
+            for x, y in self._batches(self.train_ds):
+                log.add("train", self.model.train_step(x, y))
+        log.set("dt/train", time.time() - started)
+
+    def run(self):
+        log = self.flush(EpochLog(self.G.model), 0)                     # writes hps.yaml before anything else, like the reference
+        epoch = 0
+        while True:
+            last = self.evaluate(log, epoch)
+            if epoch % self.G.save_n == 0:
+                self.checkpoint(log, last)
+            final = log.to_host() if epoch >= self.G.epochs else None
+            log = self.flush(log, epoch)
+            if final is not None:
+                return final
+            self.train_epoch(log)
+            epoch += 1
 
 
 def init_distributed():
-    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    """One process per GPU under torchrun: RCCL (backend "nccl") when GPUs are present, gloo otherwise."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ and not dist.is_initialized():
         if torch.cuda.is_available():
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend=backend)
+            dist.init_process_group(backend="nccl")
+        else:
+            dist.init_process_group(backend="gloo")
+
+
+def _run_device(flag):
+    """The torch device of this rank.  `G.device` itself stays what the user passed ('cuda'), so an hps.yaml written by a
+    multi-GPU run does not pin a later `--weights_from` run to one rank's card."""
+    if str(flag) == "cuda" and torch.cuda.is_available() and dist.is_initialized():
+        return f"cuda:{torch.cuda.current_device()}"
+    return str(flag)
+
+
+def _feature_extractors(G, device):
+    """TorchScript autoencoder / classifier of the heavy eval (gms/main.py:86-91).  The reference's weight files are not in its
+    checkout (.MISSING_LARGE_BLOBS): without them the heavy eval is switched off with a message instead of failing the run."""
+    if not G.eval_heavy:
+        return None, None
+    wanted = [Path(G.autoencoder)] + ([Path(G.classifier)] if G.get("class_cond", 0) else [])
+    absent = [str(f) for f in wanted if not f.exists()]
+    if absent:
+        print(f"eval_heavy disabled: {', '.join(absent)} not found (the reference's weight files are not in its checkout)")
+        G.eval_heavy = 0
+        return None, None
+    autoencoder = torch.jit.load(str(G.autoencoder)).to(device)
+    classifier = torch.jit.load(str(G.classifier)).to(device) if G.get("class_cond", 0) else None
+    return autoencoder, classifier
+
+
+def _datasets(G, device):
+    rank, world = parallel.rank(), parallel.world()
+    if G.data == "mnist":          # gms/main.py:84 `load_mnist`
+        return datasets.load_mnist(G.bs, G.binarize, G.pad32, root=str(G.data_root), device=device, seed=1000, rank=rank, world=world)
+    if G.data == "synthetic":
+        return (datasets.SyntheticMNIST(G.bs, G.train_batches, G.pad32, G.binarize, device, seed=1000 + rank),
+                datasets.SyntheticMNIST(G.bs, G.test_batches, G.pad32, G.binarize, device, seed=2000 + rank))
+    raise ValueError(f"--data {G.data!r}: 'synthetic' or 'mnist'")
 
 
 def load_model_and_data(argv=None):
-    parser = argparse.ArgumentParser()
-    for key, value in DG.items():
-        parser.add_argument(f"--{key}", type=common.args_type(value), default=value)
-    tempG, _ = parser.parse_known_args(argv)
-
-    defaults = {}
-    if tempG.weights_from != Path("."):
-        with open(tempG.weights_from.parent / "hps.yaml") as f:
-            loadedG = common.AttrDict(yaml.load(f, Loader=yaml.Loader))
-        for key, value in loadedG.items():
-            defaults[key] = value
-            if key not in tempG:
-                parser.add_argument(f"--{key}", type=type(value), default=value)
-        Model = common.discover_models()[loadedG.model]
-    else:
-        Model = common.discover_models()[tempG.model]
-        for key, value in Model.DG.items():
-            defaults[key] = value
-            if key not in tempG:
-                parser.add_argument(f"--{key}", type=type(value), default=value)
-        defaults["logdir"] = tempG.logdir / tempG.model
-    defaults.pop("full_cmd", None)
-    parser.set_defaults(**defaults)
-    G = common.AttrDict(parser.parse_args(argv).__dict__)
+    """-> (model, train_ds, test_ds, autoencoder, classifier, G), the reference's call shape (gms/main.py:43-92)."""
+    G, Model = FlagSpace(DG).resolve(argv)
     init_distributed()
-    if G.device == "cuda" and torch.cuda.is_available() and dist.is_initialized():
-        G.device = f"cuda:{torch.cuda.current_device()}"
-    model = Model(G=G).to(G.device)
+    device = _run_device(G.device)
+    model = Model(G=G).to(device)
+    model.run_device = device
     if G.weights_from != Path("."):
-        model.load_state_dict(torch.load(G.weights_from, map_location=G.device), strict=False)
+        model.load_state_dict(torch.load(G.weights_from, map_location=device), strict=False)
     if parallel.world() > 1 and hasattr(model, "net"):
         parallel.GradSync(model.net).broadcast_params(0)
-    r = parallel.rank()
-    if G.data == "mnist":         # gms/main.py:84 load_mnist: the IDX files under data/MNIST/raw (cannot be downloaded here)
-        from . import data as mnist_data
-        train_ds, test_ds = mnist_data.load_mnist(G.bs, G.binarize, G.pad32, root=str(G.data_root), device=G.device, seed=1000,
-                                                  rank=r, world=parallel.world())
-    elif G.data == "synthetic":
-        train_ds = SyntheticMNIST(G.bs, G.train_batches, G.pad32, G.binarize, G.device, seed=1000 + r)
-        test_ds = SyntheticMNIST(G.bs, G.test_batches, G.pad32, G.binarize, G.device, seed=2000 + r)
-    else:
-        raise ValueError(f"--data {G.data!r}: 'synthetic' or 'mnist'")
-    print("num_vars", common.count_vars(model))
-    # heavy eval (gms/main.py:86-91): TorchScript feature extractors; the reference's weight files are not in the checkout
-    # (.MISSING_LARGE_BLOBS), so a missing file is an error only when --eval_heavy asks for it
-    autoencoder = classifier = None
-    if G.eval_heavy:
-        need = [Path(G.autoencoder)] + ([Path(G.classifier)] if G.get("class_cond", 0) else [])
-        missing = [str(f) for f in need if not f.exists()]
-        if missing:       # DiffusionModel.DG.eval_heavy defaults to 1 as in the reference; without the files it cannot run
-            print(f"eval_heavy disabled: {', '.join(missing)} not found (the reference's weight files are not in its checkout)")
-            G.eval_heavy = 0
-        else:
-            autoencoder = torch.jit.load(str(G.autoencoder)).to(G.device)
-            if G.get("class_cond", 0):
-                classifier = torch.jit.load(str(G.classifier)).to(G.device)
+    train_ds, test_ds = _datasets(G, device)
+    if parallel.rank() == 0:
+        print("num_vars", common.count_vars(model))
+    autoencoder, classifier = _feature_extractors(G, device)
     return model, train_ds, test_ds, autoencoder, classifier, G
 
 
 def train(model, train_ds, test_ds, autoencoder, classifier, G):
-    writer = common.NullWriter(G.logdir)
-    logger = common.dump_logger({}, writer, 0, G)
-    for epoch in count(0):
-        # TEST (eval first, gms/main.py:159-183)
-        model.eval()
-        with torch.no_grad():
-            if hasattr(model, "loss"):
-                for test_batch in test_ds:
-                    test_x, test_y = test_batch[0].to(G.device), test_batch[1].to(G.device)
-                    _, test_metrics = model.loss(test_x, test_y)
-                    for key in test_metrics:
-                        prefix_key = f"{G.model}/test/{key}" if not key == "nlogp" else f"eval/{key}"
-                        logger[prefix_key] += [test_metrics[key].detach().cpu().item()]
-            else:
-                test_batch = next(iter(test_ds))
-                test_x, test_y = test_batch[0].to(G.device), test_batch[1].to(G.device)
-            eval_time = time.time()
-            model.evaluate(writer, test_x, test_y, epoch)
-            logger["dt/eval"] = time.time() - eval_time
-        logger["num_vars"] = common.count_vars(model)
-        if epoch % G.save_n == 0 and parallel.rank() == 0:
-            Path(G.logdir).mkdir(parents=True, exist_ok=True)
-            model.save(Path(G.logdir), test_x, test_y)
-            print("SAVED MODEL", G.logdir)
-            if G.eval_heavy:                       # gms/main.py:191-196
-                print("RUNNING HEAVY EVAL...")
-                eval_heavy_time = time.time()
-                heavy.eval_heavy(logger, model, test_ds, autoencoder, classifier, G)
-                logger["dt/eval_heavy"] = time.time() - eval_heavy_time
-                print("DONE HEAVY EVAL")
-        logger = common.dump_logger(logger, writer, epoch, G)
-        if epoch >= G.epochs:
-            break
-        # TRAIN (gms/main.py:202-217)
-        model.train()
-        train_time = time.time()
-        pending = []
-        for batch in train_ds:
-            if G.skip_training:
-                break
-            train_x, train_y = batch[0].to(G.device), batch[1].to(G.device)
-            metrics = model.train_step(train_x, train_y)
-            pending.append(metrics)
-        for metrics in pending:       # one device->host transfer pass per epoch instead of one sync per step
-            for key in metrics:
-                prefix_key = f"{G.model}/train/{key}" if not key == "nlogp" else f"train/{key}"
-                logger[prefix_key] += [metrics[key].detach().cpu()]
-        logger["dt/train"] = time.time() - train_time
-    return logger, writer
+    """Evaluate-then-train epochs until `G.epochs`; returns the host-side metrics of the final evaluation pass."""
+    return Session(model, train_ds, test_ds, autoencoder, classifier, G).run()
 
 
 if __name__ == "__main__":
-    model, train_ds, test_ds, autoencoder, classifier, G = load_model_and_data()
-    train(model, train_ds, test_ds, autoencoder, classifier, G)
+    train(*load_model_and_data())

@@ -1,76 +1,105 @@
-"""Heavy-eval metrics of the reference driver: `compute_fid` (gms/common.py:267-288) and
-`precision_recall_f1` (gms/common.py:291-319) on latent vectors, and the `eval_heavy` loop (gms/main.py:95-149).
+"""Sample-quality metrics of the heavy evaluation, written from their definitions:
 
-They work on [N, Z] latents of a feature extractor (the reference's pretrained autoencoder / classifier, whose weight
-files are not part of the checkout — `.MISSING_LARGE_BLOBS`); any callables can be passed.  Off the throughput path:
-500 x 64 latents, stock numpy / torch ops."""
+* Fréchet distance between two Gaussians fitted to latent sets — the quantity the reference logs as `eval/fid`
+  (gms/common.py:267-288).  d = m(mu_a, mu_b) + tr(S_a) + tr(S_b) - 2 tr((S_a S_b)^(1/2)), with the reference's one deviation
+  from the textbook formula kept: m is the MEAN of the squared mean differences, not their sum.
+* k-NN manifold precision / recall / F1 (Kynkäänniemi et al., arXiv 1904.06991; gms/common.py:291-319): a point is covered by a
+  set if it lies strictly inside the k-th-neighbour ball of at least one member of the set.
+* `eval_heavy`: the sampling loop of gms/main.py:95-149 that feeds them (same metric keys, `y = -1` = unconditional).
+
+Everything here works on [N, Z] latents of a feature extractor passed in by the caller (the reference's pretrained
+autoencoder / classifier TorchScript files are not part of its checkout).  Off the throughput path: 500 x 64 latents."""
 import numpy as np
 import torch
 import torch.nn.functional as F
-from scipy.linalg import fractional_matrix_power
+
+
+def _trace_sqrt_product(cov_a, cov_b):
+    """tr((A B)^(1/2)) for covariance matrices: the principal square root has the square roots of the eigenvalues of A B as
+    its eigenvalues, so its trace is their sum (complex arithmetic: round-off can push a zero eigenvalue below zero)."""
+    eig = np.linalg.eigvals(cov_a @ cov_b).astype(np.complex128)
+    return np.sqrt(eig).sum()
 
 
 def compute_fid(x, y):
-    """Fréchet distance between Gaussians fitted to x and y ([N, Z] numpy).  As in the reference: the mean term is the MEAN
-    (not the sum) of squared differences, the real part is returned, any failure gives NaN (gms/common.py:273-288)."""
+    """x, y: [N, Z] numpy latents -> float; NaN for anything that cannot be evaluated (wrong rank, too few rows, a failed
+    eigen-decomposition) — the reference swallows every failure into NaN too."""
+    x, y = np.asarray(x), np.asarray(y)
+    if x.ndim != 2 or y.ndim != 2 or x.shape[1] != y.shape[1] or min(x.shape[0], y.shape[0]) < 2:
+        return np.nan
     try:
-        assert x.ndim == 2 and y.ndim == 2
-        pmu, tmu = np.mean(x, 0), np.mean(y, 0)
-        pcov, tcov = np.cov(x, rowvar=False), np.cov(y, rowvar=False)
-        assert pcov.shape[0] == x.shape[-1]
-        fid = np.mean((pmu - tmu) ** 2) + np.trace(pcov + tcov - 2 * fractional_matrix_power(pcov.dot(tcov), 0.5))
-        return fid.real
-    except Exception:
+        mean_term = np.mean(np.square(x.mean(axis=0) - y.mean(axis=0)))
+        cov_x = np.atleast_2d(np.cov(x, rowvar=False))
+        cov_y = np.atleast_2d(np.cov(y, rowvar=False))
+        value = mean_term + np.trace(cov_x) + np.trace(cov_y) - 2.0 * _trace_sqrt_product(cov_x, cov_y)
+        return float(np.real(value))
+    except (np.linalg.LinAlgError, ValueError, FloatingPointError):
         return np.nan
 
 
-def _manifold_estimate(set_a, set_b, k=3):
-    """Fraction of set_b inside the k-NN manifold of set_a (arXiv 1904.06991; gms/common.py:307-314)."""
-    d = torch.cdist(set_a, set_a)
-    radii = torch.topk(d, k + 1, largest=False).values[..., -1:]
-    d2 = torch.cdist(set_a, set_b)
-    return (d2 < radii).any(0).float().mean()
+def knn_radii(points, k):
+    """Distance from every point to its k-th nearest OTHER point of the same set ([N] tensor)."""
+    pairwise = torch.cdist(points, points)
+    return pairwise.kthvalue(k + 1, dim=1).values            # position 0 of the sorted row is the point itself (distance 0)
+
+
+def coverage(manifold, queries, k=3):
+    """Fraction of `queries` lying strictly inside at least one k-NN ball of `manifold`."""
+    inside = torch.cdist(queries, manifold) < knn_radii(manifold, k)[None, :]
+    return inside.any(dim=1).float().mean()
 
 
 def precision_recall_f1(*, real, gen, k=3):
-    precision = _manifold_estimate(real, gen, k)
-    recall = _manifold_estimate(gen, real, k)
-    f1 = 2 * (precision * recall) / (precision + recall)
-    return {"precision": precision, "recall": recall, "f1": f1}
+    precision = coverage(real, gen, k)            # generated samples that fall on the data manifold
+    recall = coverage(gen, real, k)               # data points the generated manifold reaches
+    return {"precision": precision, "recall": recall, "f1": 2 * (precision * recall) / (precision + recall)}
+
+
+class _LatentBank:
+    """Named lists of latent batches, concatenated on demand."""
+
+    def __init__(self):
+        self._rows = {}
+
+    def add(self, name, z):
+        self._rows.setdefault(name, []).append(z.detach().float())
+
+    def get(self, name):
+        return torch.cat(self._rows[name])
 
 
 @torch.inference_mode()
 def eval_heavy(logger, model, test_ds, autoencoder, classifier, G, total_samples=500):
-    """gms/main.py:95-149.  Draws >= total_samples samples (unconditional: y = -1; class-conditional when G.class_cond),
-    embeds samples and test images with `autoencoder`, logs eval/fid, eval/precision|recall|f1 (+ cond_*, classifier_loss).
-    The reference's extra `ignite_fid` needs pytorch-ignite, which is not installed: it is logged only if importable."""
-    from . import common
-    sample_ct = 0
-    all_z_sample, all_z_real, all_z_cond_sample = [], [], []
-    metrics = {}
-    if G.class_cond:
-        metrics["classifier_loss"] = []
-    for test_batch in test_ds:
-        test_x, test_y = test_batch[0].to(G.device), test_batch[1].to(G.device)
-        bs = test_x.shape[0]
+    """Draw at least `total_samples` samples batch by batch (unconditional: y = -1; additionally class-conditional when
+    G.class_cond), embed samples and test images, log eval/fid, eval/precision|recall|f1 (+ cond_* and classifier_loss).
+    The reference also logs ignite's own FID (`ignite_fid`); pytorch-ignite is not installed here, so that key is absent."""
+    bank = _LatentBank()
+    clf_losses = []
+    drawn = 0
+    for x, y in ((b[0].to(G.device), b[1].to(G.device)) for b in test_ds):
+        n = x.shape[0]
         if G.class_cond:
-            cond_samp = model.sample(bs, y=test_y)
-            metrics["classifier_loss"].append(F.cross_entropy(classifier(cond_samp), test_y).item())
-            all_z_cond_sample.append(autoencoder(cond_samp))
-        samp = model.sample(bs, y=-torch.ones_like(test_y))
-        all_z_real.append(autoencoder(test_x))
-        all_z_sample.append(autoencoder(samp))
-        sample_ct += bs
-        if sample_ct >= total_samples:
+            guided = model.sample(n, y=y)
+            clf_losses.append(F.cross_entropy(classifier(guided), y).item())
+            bank.add("cond", autoencoder(guided))
+        bank.add("gen", autoencoder(model.sample(n, y=torch.full_like(y, -1))))
+        bank.add("real", autoencoder(x))
+        drawn += n
+        if drawn >= total_samples:
             break
-    z_samp, z_real = torch.cat(all_z_sample).float(), torch.cat(all_z_real).float()
-    metrics["fid"] = compute_fid(z_samp.cpu().numpy(), z_real.cpu().numpy())
-    metrics.update(precision_recall_f1(real=z_real, gen=z_samp))
+    real = bank.get("real")
+
+    def against_real(name):
+        gen = bank.get(name)
+        scores = precision_recall_f1(real=real, gen=gen)
+        scores["fid"] = compute_fid(gen.cpu().numpy(), real.cpu().numpy())
+        return scores
+
+    results = against_real("gen")
     if G.class_cond:
-        z_cond = torch.cat(all_z_cond_sample).float()
-        cond = precision_recall_f1(real=z_real, gen=z_cond)
-        cond["fid"] = compute_fid(z_cond.cpu().numpy(), z_real.cpu().numpy())
-        metrics.update(common.prefix_dict("cond_", cond))
-    for key, val in metrics.items():
-        logger[f"eval/{key}"] += [np.mean(common.to_numpy(val))]
-    return metrics
+        results["classifier_loss"] = clf_losses
+        results.update({"cond_" + key: val for key, val in against_real("cond").items()})
+    for key, val in results.items():
+        val = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else val
+        logger[f"eval/{key}"] += [float(np.mean(val))]
+    return results

@@ -369,8 +369,23 @@ def guide_onehot(guide):
     return onehot, keep
 
 
-def gemm(A, B, out=None, bias=None, rowscale=None, silu_a=False, silu_b=False, accumulate=False):
-    """out[M,N] (+)= rowscale * (bias + fa(A) @ fb(B)) for 2-D fp32 views A [M,K], B [K,N] with arbitrary strides."""
+def label_drop(y, p, seed, offset):
+    """In place: y[b] = -1 where rng_uniform((B,), seed, offset)[b] < p (diffusion_model.py:67)."""
+    _chk(y, torch.int64, "y")
+    check(lib.gmk_label_drop(_p(y), y.numel(), float(p), int(seed), int(offset), _s()), "label_drop")
+    return y
+
+
+def mean(x):
+    """0-dim fp32 mean of a contiguous fp32 vector (fixed summation order)."""
+    _f32(x, "x")
+    out = torch.empty((), device=x.device, dtype=torch.float32)
+    check(lib.gmk_mean(_p(x), x.numel(), _p(out), _s()), "mean")
+    return out
+
+
+def gemm(A, B, out=None, bias=None, rowscale=None, silu_a=False, silu_b=False, accumulate=False, bias2=None):
+    """out[M,N] (+)= rowscale * (bias + bias2 + fa(A) @ fb(B)) for 2-D fp32 views A [M,K], B [K,N] with arbitrary strides."""
     assert A.dtype == torch.float32 and B.dtype == torch.float32 and A.is_cuda and B.is_cuda
     M, K = A.shape
     K2, N = B.shape
@@ -379,14 +394,15 @@ def gemm(A, B, out=None, bias=None, rowscale=None, silu_a=False, silu_b=False, a
         assert not accumulate
         out = torch.empty((M, N), device=A.device, dtype=torch.float32)
     assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
-    if bias is not None:
-        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    for bv in (bias, bias2):
+        if bv is not None:
+            assert bv.dtype == torch.float32 and bv.numel() == N and bv.is_contiguous()
     if rowscale is not None:
         assert rowscale.dtype == torch.float32 and rowscale.numel() == M and rowscale.is_contiguous()
     need = lib.gmk_gemm_f32_workspace_bytes(M, N, K)
     wsb = _workspace(need, A.device, "gemm") if need else None
     check(lib.gmk_gemm_f32(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(out), out.stride(0), M, N, K,
-                           _p(bias), _p(rowscale), int(silu_a) | (int(silu_b) << 1), int(accumulate), _p(wsb), need, _s()),
+                           _p(bias), _p(bias2), _p(rowscale), int(silu_a) | (int(silu_b) << 1), int(accumulate), _p(wsb), need, _s()),
           "gemm_f32")
     return out
 

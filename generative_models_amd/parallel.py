@@ -3,11 +3,18 @@
 The reference has no distributed code at all; data parallelism is the one exchange step the
 hot path needs: per-sample work is independent (GroupNorm normalises within a sample), so ranks
 take equal shards of the global batch and sum-all-reduce the flat fp32 gradient once per step.  The arena is cut
-into 4 contiguous buckets in backward-readiness order (`SimpleUnet.grad_buckets`); each bucket's all-reduce is
-issued the moment its last gradient kernel has been enqueued, so it runs on RCCL's stream underneath the rest of
-the backward pass.  xGMI is point-to-point and a 24 MB all-reduce is latency-bound, hence few, large buckets.
-The 1/world scaling is folded into the fused Adam kernel (`grad_scale`).
+into contiguous buckets in backward-readiness order (`SimpleUnet.grad_buckets`: 4 natural ones; `GMK_GRAD_BUCKETS` = 1, 2 or 4
+merges neighbours); each bucket's all-reduce is issued the moment its last gradient kernel has been enqueued, so it runs on
+RCCL's stream underneath the rest of the backward pass.  xGMI is point-to-point and a 24 MB all-reduce is latency-bound, hence
+few, large buckets.  The 1/world scaling is folded into the fused Adam kernel (`grad_scale`).
+
+CU carve-out: the convolution kernels are persistent grids of one 160 KiB-LDS workgroup per CU — they leave RCCL's reduction
+kernels nowhere to run until a whole kernel drains.  With world > 1 the persistent grids are therefore limited to
+256 - `GMK_RCCL_CUS` CUs (default 8: RCCL's ring kernels use a handful of workgroups per channel), costing the convolutions
+3 % of the chip and buying overlap of the exchange with the backward pass.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -32,28 +39,71 @@ def shard_batch(x, r=None, w=None):
     return x[r * per:(r + 1) * per]
 
 
+def merge_buckets(natural, count):
+    """Merge the natural buckets (in readiness order) into `count` groups of neighbours.
+    -> [(start, end, last natural index of the group)]; every group must stay one contiguous arena range."""
+    if count not in (1, 2, 4) or len(natural) != 4:
+        raise ValueError(f"GMK_GRAD_BUCKETS must be 1, 2 or 4 (got {count})")
+    per = len(natural) // count
+    groups = []
+    for g in range(count):
+        members = natural[g * per:(g + 1) * per]
+        start, end = min(s for s, _ in members), max(e for _, e in members)
+        if sum(e - s for s, e in members) != end - start:
+            raise ValueError("merged gradient bucket is not contiguous")
+        groups.append((start, end, g * per + per - 1))
+    return groups
+
+
+def reserve_cus_for_rccl():
+    """Limit the persistent kernels to 256 - GMK_RCCL_CUS CUs when more than one rank runs (see the module docstring)."""
+    from ._lib import check, lib
+    keep = int(os.environ.get("GMK_RCCL_CUS", "8"))
+    if world() > 1 and keep > 0 and "GMK_CU_LIMIT" not in os.environ:
+        check(lib.gmk_set_cu_limit(256 - keep), "set_cu_limit")
+    return lib.gmk_get_cu_limit()
+
+
 class GradSync:
     """Bucketed, overlapped sum-all-reduce of `net.flat_grads`.  `hook(k)` is SimpleUnet.backward_hip's
-    `on_grads_ready` callback; `finish()` makes the current stream wait for every outstanding bucket."""
+    `on_grads_ready` callback (k = natural bucket index, called in order 0..3); `finish()` makes the current stream wait for
+    every outstanding bucket."""
 
-    def __init__(self, net, group=None):
+    def __init__(self, net, group=None, buckets=None):
         self.net = net
         self.group = group
-        self.buckets = net.grad_buckets()
+        count = int(buckets if buckets is not None else os.environ.get("GMK_GRAD_BUCKETS", "4"))
+        self.buckets = merge_buckets(net.grad_buckets(), count)
+        self._fire = {last: (s, e) for s, e, last in self.buckets}
         self.works = []
+        self.issued = []                      # (natural index, start, end) of every all-reduce issued this step (tests, bench)
+        self.cu_limit = reserve_cus_for_rccl() if net.flat_params.is_cuda else None
 
     def hook(self, k):
-        if world() == 1:
+        if world() == 1 or k not in self._fire:
             return
-        s, e = self.buckets[k]
+        s, e = self._fire[k]
+        self.issued.append((k, s, e))
         self.works.append(dist.all_reduce(self.net.flat_grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         for w in self.works:
             w.wait()
         self.works.clear()
+        self.issued.clear()
 
     def broadcast_params(self, src=0):
         if world() > 1:
             dist.broadcast(self.net.flat_params, src=src, group=self.group)
             self.net.mark_params_changed()
+
+    def describe(self):
+        """What the exchange looks like from this rank (bench.py puts it beside the scaling numbers)."""
+        info = {"world": world(), "backend": dist.get_backend() if world() > 1 else None,
+                "bucket_bytes": [4 * (e - s) for s, e, _ in self.buckets], "persistent_kernel_cus": self.cu_limit}
+        if torch.cuda.is_available():
+            try:
+                info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as exc:                      # the query needs the RCCL library; report, do not fail a bench over it
+                info["rccl_version"] = f"unavailable ({type(exc).__name__})"
+        return info

@@ -41,6 +41,11 @@ int gmk_set_kernel_choice(int conv, int wgrad, int gn);
 /* development aid: a free integer (GMK_DEV_VARIANT) that experimental code paths may read for in-process A/B runs
  * (tools/step_ab.py); 0 / unset = the shipped behaviour */
 int gmk_set_dev_variant(int v);
+/* number of CUs the persistent convolution kernels may occupy (8..256, default 256 = the whole chip).  New with the build (the
+ * reference has no multi-GPU path): data-parallel runs leave a few CUs to RCCL's all-reduce kernels, which otherwise queue
+ * behind a chip-filling persistent grid */
+int gmk_set_cu_limit(int n);
+int gmk_get_cu_limit(void);
 /* number of bytes of scratch gmk_conv_wgrad needs for the given problem (split-K slabs) */
 int64_t gmk_conv_wgrad_workspace_bytes(int64_t n_pixels, int taps, int cout, int ktot);
 
@@ -141,13 +146,19 @@ int gmk_head_wgrad(const float* dout, const void* a, float* dw_part, int B, int 
 int gmk_timestep_embedding(const float* t, const float* freqs, float* out, int B, void* stream);
 /* onehot[b][0:10]: F.one_hot(guide with -1 -> 0) as fp32 (simple_unet.py:53-56); keep[b] = guide[b] != -1 */
 int gmk_guide_onehot(const int64_t* guide, float* onehot, float* keep, int B, void* stream);
-/* C[i][j] = (accumulate ? C[i][j] : 0) + rowscale[i] * (bias[j] + sum_k fa(A[i*sa0 + k*sa1]) * fb(B[k*sb0 + j*sb1]))
- * fa / fb = SiLU when bit 0 / bit 1 of `silu` is set, else identity; bias / rowscale may be NULL (rowscale = the
+/* classifier-free label drop of DiffusionModel.train_step (diffusion_model.py:67 `y[torch.rand(B) < cf_drop_prob] = -1`), in
+ * place on the caller's labels like the reference: y[b] = -1 where gmk_rng_uniform(seed, offset)[b] < p */
+int gmk_label_drop(int64_t* y, int B, float p, uint64_t seed, uint64_t offset, void* stream);
+/* out[0] = mean(x[0..n)), fixed summation order: the batch mean of the per-sample losses (diffusion_model.py:78) */
+int gmk_mean(const float* x, int n, float* out, void* stream);
+/* C[i][j] = (accumulate ? C[i][j] : 0) + rowscale[i] * (bias[j] + bias2[j] + sum_k fa(A[i*sa0 + k*sa1]) * fb(B[k*sb0 + j*sb1]))
+ * fa / fb = SiLU when bit 0 / bit 1 of `silu` is set, else identity; bias / bias2 / rowscale may be NULL (bias2: the conv1
+ * bias that rides with the 12 emb_layers of simple_unet.py:166,183; rowscale = the
  * `guide != -1` row mask of simple_unet.py:57).  Small strided fp32 GEMM behind every nn.Linear forward/backward
  * of the embedding path. */
 int gmk_gemm_f32(const float* A, int64_t sa0, int64_t sa1, const float* B, int64_t sb0, int64_t sb1, float* C,
-                 int64_t ldc, int M, int N, int K, const float* bias, const float* rowscale, int silu,
-                 int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+                 int64_t ldc, int M, int N, int K, const float* bias, const float* bias2, const float* rowscale,
+                 int silu, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 /* scratch the GEMM wants for its deterministic split-K (few output tiles, long K); 0 if none */
 int64_t gmk_gemm_f32_workspace_bytes(int M, int N, int K);
 /* dpre[i] = dpost[i] * SiLU'(pre[i]) * (rowscale ? rowscale[i / ncols] : 1) */

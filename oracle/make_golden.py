@@ -265,6 +265,43 @@ def gen_meantypes(C, S, B, T, seed, name):
     save(name, **out)
 
 
+def gen_default_init(S, B, seed, name, C=128):
+    """Default-init-scale set: the reference net filled with `reference_init_params(zero_out_layers=False)` — PyTorch's own
+    initialisation scale with the zero-initialised `out_layers.3` convolutions (simple_unet.py:172) made live, i.e. the
+    conditioning of a real (un)trained model rather than the cancellation-heavy closed-form fill.  This is the set the
+    bf16 bar (north_star: 1e-2) is held on: forward with / without labels, per-sample training loss, every gradient norm,
+    two full gradients."""
+    net = R_su.SimpleUnet(C, 0.0)
+    sd = unet_ref.reference_init_params(C, 1, seed=seed, zero_out_layers=False)
+    missing = net.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    net.eval()
+    x0, y = inputs(B, S, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    logsnr = (torch.rand(B, generator=g) * 30 - 15)
+    z = torch.randn((B, 1, S, S), generator=g)
+    out = {"init_seed": np.int64(seed), "z": z, "logsnr": logsnr, "guide": y}
+    with torch.no_grad():
+        out["v"] = net(z, logsnr, guide=y)
+        out["v_noguide"] = net(z, logsnr)
+    net.train()
+    diff = R_gd.GaussianDiffusion(mean_type="v", num_steps=250, sampler="ddim", sample_cond_w=-1.0)
+    torch.manual_seed(seed)
+    eps = torch.randn(x0.shape)
+    u = torch.rand(size=(B,))
+    torch.manual_seed(seed)
+    losses = diff.training_losses(net=partial(net, guide=y), x=x0)["loss"]
+    losses.mean().backward()
+    out.update(x0=x0, eps=eps, u=u, loss_b=losses.detach())
+    names = [k for k, _ in net.named_parameters()]
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = torch.stack([p.grad.norm() if p.grad is not None else torch.tensor(0.0) for _, p in net.named_parameters()])
+    for k, p in net.named_parameters():
+        if k in ("down.seq.0.conv.weight", "out.2.weight"):
+            out["grad__" + k] = p.grad.detach().clone()
+    save(name, **out)
+
+
 def gen_metrics(name):
     """compute_fid / precision_recall_f1 (gms/common.py:267-319).  gms.common itself cannot be imported here (torchvision is
     absent), so the two function definitions are taken out of the reference file with `ast` and executed as they stand."""
@@ -310,6 +347,8 @@ def main():
     gen_distill(128, 8, 3, 8, 41, "distill_c128_s8.npz")
     gen_meantypes(128, 8, 3, 4, 50, "meantype_c128_s8.npz")
     gen_metrics("metrics.npz")
+    gen_default_init(28, 4, 70, "definit_c128_s28.npz")
+    gen_default_init(32, 3, 71, "definit_c128_s32.npz")
 
 
 if __name__ == "__main__":

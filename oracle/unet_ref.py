@@ -206,7 +206,8 @@ def unet_forward(p, x, logsnr, guide=None, cond_w=None, taps=None, dropout=None)
 
     `taps`, if a dict, receives named intermediate activations (NCHW) for per-layer checks.
     `dropout` = (masks, p): training-mode nn.Dropout(p) with one explicit NCHW keep-mask per ResBlock name."""
-    dm = (lambda n: (dropout[0][n], dropout[1])) if dropout is not None else (lambda n: None)
+    # `up.seq[3]`'s ResBlock is constructed without the dropout argument (simple_unet.py:138): it never drops
+    dm = (lambda n: (dropout[0][n], dropout[1]) if n != "up.seq.3.0" else None) if dropout is not None else (lambda n: None)
     emb = embed(p, logsnr, guide, cond_w)
     t = taps if taps is not None else {}
     t["emb"] = emb

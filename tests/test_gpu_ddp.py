@@ -10,6 +10,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+def free_port():
+    """A TCP port nobody listens on right now: fixed rendezvous ports collide between test runs."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
 _WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])
@@ -64,7 +72,7 @@ def test_two_rank_step_equals_single_rank(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29541", str(script), ROOT]
+           "127.0.0.1", "--master-port", free_port(), str(script), ROOT]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="2"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == 2
@@ -76,8 +84,8 @@ def test_bench_two_ranks_rehearsal():
     one JSON line from rank 0 with the whole-job rate."""
     import json
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64",
-           "--sampler_steps", "2", "--no_cpu"]
+           "--master-port", free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--config", "custom", "--batch", "64", "--sampler_steps", "2", "--sampler_steps_other", "2", "--no_cpu"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
                        env=dict(os.environ, GMK_DIST_BACKEND="gloo", OMP_NUM_THREADS="2"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -86,3 +94,6 @@ def test_bench_two_ranks_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
     assert d["value"] > 0 and "cpu_baseline" not in d and d["roofline"]["kernel"].startswith("conv")
+    ex = d["exchange"]
+    assert ex["world"] == 2 and ex["backend"] == "gloo" and len(ex["bucket_bytes"]) == 4 and ex["persistent_kernel_cus"] == 248
+    assert d["steady_state"]["steps"] == 50 and d["sampler"]["timed_steps"] == 2

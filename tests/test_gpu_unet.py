@@ -13,11 +13,11 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# north_star: 1e-3 fp32 / 1e-2 bf16.  fp32 is judged on the max-abs error relative to the output scale; bf16 on the
-# same metric at realistic (default-init-scale) weights, and at 1e-1 on the ill-conditioned closed-form goldens,
-# whose head convolution cancels to ~1/10 of its operands' scale (measured: fp32 7e-6, bf16 3e-2 L2 there).
+# north_star: 1e-3 fp32 / 1e-2 bf16, both judged on the max-abs error relative to the output scale.  The reference-pinned
+# vectors come in two sets: the closed-form fill (tests/golden/{unet,train,...}_c128_*.npz: every conv live, heavy
+# cancellation in the head - the bug-exposing set, run in the exact-fp32 mode) and the default-init-scale fill
+# (tests/golden/definit_c128_*.npz: the conditioning of a real model), on which BOTH modes are held to their bar.
 TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2}
-TOL_GOLDEN = {torch.float32: 1e-3, torch.bfloat16: 1e-1}
 T = torch.from_numpy
 
 
@@ -40,15 +40,45 @@ def make_net(dtype, C=128, in_channels=1, closed_form=True):
     return net.cuda(), params
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_unet_forward_vs_golden(golden, dtype):
+def test_unet_forward_vs_golden(golden):
     g = golden("unet_c128_s28.npz")
-    net, _ = make_net(dtype)
+    net, _ = make_net(torch.float32)
     z, l, y = T(g["z"]).cuda(), T(g["logsnr"]).cuda(), T(g["guide"]).cuda()
     with torch.no_grad():
-        assert rel_err(net(z, l, guide=y), T(g["v"])) < TOL_GOLDEN[dtype]
-        assert rel_err(net(z, l), T(g["v_noguide"])) < TOL_GOLDEN[dtype]
-        assert rel_err(net(z, l, guide=y, cond_w=T(g["cond_w"]).cuda()), T(g["v_condw"])) < TOL_GOLDEN[dtype]
+        assert rel_err(net(z, l, guide=y), T(g["v"])) < 1e-3
+        assert rel_err(net(z, l), T(g["v_noguide"])) < 1e-3
+        assert rel_err(net(z, l, guide=y, cond_w=T(g["cond_w"]).cuda()), T(g["v_condw"])) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["definit_c128_s28.npz", "definit_c128_s32.npz"])
+def test_default_init_goldens(golden, dtype, name):
+    """Reference-pinned vectors at default-init scale (oracle/make_golden.py:gen_default_init): forward with / without labels,
+    per-sample training loss, every gradient norm, two full gradients.  fp32 mode 1e-3, bf16 mode 1e-2 - max-norm, no slack."""
+    from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    from generative_models_amd.diffusion.simple_unet import SimpleUnet
+    from oracle import unet_ref as U
+    g = golden(name)
+    params = U.reference_init_params(128, 1, seed=int(g["init_seed"]), zero_out_layers=False)
+    net = SimpleUnet(128, 0.0, compute_dtype=dtype); net.load_state_dict(params, strict=True); net = net.cuda()
+    tol = TOL[dtype]
+    z, l, y = T(g["z"]).cuda(), T(g["logsnr"]).cuda(), T(g["guide"]).cuda()
+    with torch.no_grad():
+        e1, e2 = rel_err(net(z, l, guide=y), T(g["v"])), rel_err(net(z, l), T(g["v_noguide"]))
+    assert e1 < tol and e2 < tol, (e1, e2)
+    diff = GaussianDiffusion(mean_type="v", num_steps=250)
+    x0, u, eps = (T(g[k]).cuda() for k in ("x0", "u", "eps"))
+    B = x0.shape[0]
+    out = diff.train_forward_backward(net=partial(net, guide=y), x=x0, grad_scale=1.0 / B, u=u, eps=eps)
+    assert rel_err(out["loss"], T(g["loss_b"])) < tol
+    names = [str(n) for n in g["grad_names"]]
+    norms = torch.stack([net.grad(n).norm() for n in names]).cpu()
+    ref = T(g["grad_norms"])
+    ok = (norms - ref).abs() <= 3 * tol * ref.abs() + 1e-3 * tol * ref.abs().max()
+    assert bool(ok.all()), [(names[i], float(norms[i]), float(ref[i])) for i in (~ok).nonzero().flatten()[:8]]
+    for k in g.files:
+        if k.startswith("grad__"):
+            assert rel_err(net.grad(k[6:]), T(g[k])) < 3 * tol, k
 
 
 def test_state_dict_roundtrip_and_arena():
@@ -98,9 +128,9 @@ def test_unet_forward_backward_vs_oracle(dtype, in_channels, S):
     assert not bad, bad[:8]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_training_step_vs_golden(golden, dtype):
-    """(x0, y, u, eps) -> loss[B], gradient norms of every tensor, selected gradients, two Adam steps (row H1)."""
+def test_training_step_vs_golden(golden, dtype=torch.float32):
+    """(x0, y, u, eps) -> loss[B], gradient norms of every tensor, selected gradients, two Adam steps (row H1).  Closed-form
+    fill, exact-fp32 mode; the bf16 bar on a training step is held by test_default_init_goldens."""
     from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
     from generative_models_amd.diffusion.optim import FusedAdam
     g = golden("train_c128_s28.npz")
@@ -109,7 +139,7 @@ def test_training_step_vs_golden(golden, dtype):
     opt = FusedAdam(net, lr=3e-4)
     x0, y, u, eps = (T(g[k]).cuda() for k in ("x0", "y", "u", "eps"))
     B = x0.shape[0]
-    tol = TOL_GOLDEN[dtype]
+    tol = TOL[dtype]
     for step in (1, 2):
         out = diff.train_forward_backward(net=partial(net, guide=y), x=x0, grad_scale=1.0 / B, u=u, eps=eps)
         if step == 1:
@@ -333,14 +363,16 @@ def test_dropout_training_mode_vs_oracle(dtype):
     ctx = {}
     out = net.forward_hip(z.cuda(), l.cuda(), y.cuda(), None, ctx=ctx)
     masks, kept = {}, []
-    for name in RES_BLOCKS:
+    assert ctx["up.seq.3.0.dropout"] is None          # reference quirk: that ResBlock is built without dropout (simple_unet.py:138)
+    dropping = [n for n in RES_BLOCKS if n != "up.seq.3.0"]
+    for name in dropping:
         pd, seed, off = ctx[name + ".dropout"]
         h = ctx[name][3]                                           # conv1 output, NHWC: the tensor the mask is laid over
         m = (ops.rng_uniform(tuple(h.shape), seed, off, h.device) >= pd).float()
         masks[name] = m.permute(0, 3, 1, 2).cpu()
         kept.append(float(m.mean()))
     assert all(abs(k - (1 - p_drop)) < 0.02 for k in kept), kept
-    assert len({ctx[n + ".dropout"][2] for n in RES_BLOCKS}) == len(RES_BLOCKS)      # disjoint counter ranges
+    assert len({ctx[n + ".dropout"][2] for n in dropping}) == len(dropping)      # disjoint counter ranges
     pr = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     ref = U.unet_forward(pr, z, l, guide=y, dropout=(masks, p_drop))
     tol = TOL[dtype]

@@ -14,6 +14,14 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def free_port():
+    """A TCP port nobody listens on right now (bind to 0, read it back): fixed rendezvous ports collide between test runs."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 def test_args_type_truth_table():
     """Restates gms/common.py:85-92."""
     from generative_models_amd.common import args_type
@@ -171,6 +179,19 @@ for k in range(4):
 sync.finish()
 expect = torch.arange(net.flat_grads.numel(), dtype=torch.float32) * 1e-6 * sum(range(1, w + 1))
 assert torch.allclose(net.flat_grads, expect, rtol=1e-6, atol=0), float((net.flat_grads - expect).abs().max())
+# merged buckets (GMK_GRAD_BUCKETS=2): two all-reduces, issued when the LAST natural bucket of each pair is ready
+sync2 = parallel.GradSync(net, buckets=2)
+net.flat_grads.copy_(g_local)
+order = []
+for k in range(4):
+    sync2.hook(k)
+    order.append(len(sync2.works))
+assert order == [0, 1, 1, 2], order
+assert [k for k, _, _ in sync2.issued] == [1, 3]
+sync2.finish()
+assert torch.allclose(net.flat_grads, expect, rtol=1e-6, atol=0)
+d = sync2.describe()
+assert d["world"] == w and d["backend"] == "gloo" and sum(d["bucket_bytes"]) == 4 * net.flat_grads.numel() and len(d["bucket_bytes"]) == 2
 x = torch.arange(8.0)
 assert parallel.shard_batch(x).tolist() == x[r * 8 // w:(r + 1) * 8 // w].tolist()
 dist.destroy_process_group()
@@ -182,7 +203,7 @@ def test_gradient_exchange_two_ranks_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29531", str(script), ROOT]
+           "127.0.0.1", "--master-port", free_port(), str(script), ROOT]
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -300,3 +321,81 @@ def test_eval_heavy_flow_and_metric_keys():
     logger2 = defaultdict(list)
     metrics.eval_heavy(logger2, M(), ds, enc, None, common.AttrDict(device="cpu", class_cond=0), total_samples=50)
     assert "eval/cond_fid" not in logger2 and "eval/classifier_loss" not in logger2 and "eval/fid" in logger2
+
+
+def test_guidance_weight_policy_table():
+    """gaussian_diffusion.py:246-257,271-278 as a truth table: {caller asked for guidance or not} x {--sample_cond_w -1 / 2.0}
+    x {no teacher / teacher / teacher_test}."""
+    from generative_models_amd.diffusion.gaussian_diffusion import resolve_guidance
+    draw = torch.tensor([0.5, 3.0])
+    R = lambda **kw: resolve_guidance(kw_cond_w=None, **kw)
+    # no teacher: sample_cond_w wins whenever it is not -1, whether or not the caller passed cond_w (`evaluate` passes none)
+    assert R(sample_cond_w=-1.0, net_cond_w=None, has_teacher=False, sampler="ddim") == (None, None, False)
+    s, g, t = R(sample_cond_w=-1.0, net_cond_w=draw, has_teacher=False, sampler="ddim")
+    assert s is None and g is draw and not t
+    assert R(sample_cond_w=2.0, net_cond_w=None, has_teacher=False, sampler="ddim") == (None, 2.0, False)
+    assert R(sample_cond_w=2.0, net_cond_w=draw, has_teacher=False, sampler="noisy") == (None, 2.0, False)
+    assert R(sample_cond_w=None, net_cond_w=None, has_teacher=False, sampler="ddim") == (None, None, False)
+    # distillation: the student is conditioned on the draw, never guided, sample_cond_w is ignored
+    s, g, t = R(sample_cond_w=2.0, net_cond_w=draw, has_teacher=True, sampler="ddim")
+    assert s is draw and g is None and not t
+    assert R(sample_cond_w=-1.0, net_cond_w=None, has_teacher=True, sampler="ddim") == (None, None, False)
+    # teacher_test: the teacher, guided by the student's weight; unguided when there is none
+    s, g, t = R(sample_cond_w=-1.0, net_cond_w=draw, has_teacher=True, sampler="teacher_test")
+    assert s is None and g is draw and t
+    assert R(sample_cond_w=-1.0, net_cond_w=None, has_teacher=True, sampler="teacher_test") == (None, None, True)
+    with pytest.raises(ValueError):
+        R(sample_cond_w=-1.0, net_cond_w=None, has_teacher=False, sampler="teacher_test")
+    # a cond_w the caller's partial already carried conditions the (undistilled) network and does not guide
+    kw = torch.tensor([1.0, 1.0])
+    s, g, t = resolve_guidance(sample_cond_w=-1.0, net_cond_w=None, kw_cond_w=kw, has_teacher=False, sampler="ddim")
+    assert s is kw and g is None and not t
+
+
+def test_bucket_merging():
+    from generative_models_amd import parallel
+    from generative_models_amd.diffusion.simple_unet import SimpleUnet
+    net = SimpleUnet(128)
+    nat = net.grad_buckets()
+    n = net.flat_params.numel()
+    for count in (1, 2, 4):
+        groups = parallel.merge_buckets(nat, count)
+        assert len(groups) == count and sum(e - s for s, e, _ in groups) == n
+        assert [last for _, _, last in groups] == {1: [3], 2: [1, 3], 4: [0, 1, 2, 3]}[count]
+    with pytest.raises(ValueError):
+        parallel.merge_buckets(nat, 3)
+    # the 12 conv1 biases ride with the embedding block at the front of the arena (second bias table of the emb_layers GEMM)
+    o = [net._offsets[f"{b}.in_layers.2.bias"] for b in ("down.seq.1", "down.seq.2", "up.seq.6")]
+    assert o[1] - o[0] == 128 and nat[3][0] == 0 and nat[3][0] <= o[0] < o[2] < nat[3][1]
+
+
+def test_flag_space_layers_and_hps_roundtrip(tmp_path):
+    """gms/main.py:43-76: driver table -> model DG -> command line; with --weights_from the saved hps.yaml replaces the model DG
+    layer (and its model key selects the class), `full_cmd` is dropped, the command line still wins."""
+    import yaml
+    from generative_models_amd import common, main
+    G, Model = main.FlagSpace(main.DG).resolve(["--model=diffusion", "--bs", "8", "--epochs=1e1", "--timesteps", "4"])
+    assert Model.__name__ == "DiffusionModel" and G.bs == 8 and G.epochs == 10.0 and G.timesteps == 4
+    assert G.logdir == Path("logs") / "diffusion" and G.hidden_size == 128 and G.sample_cond_w == -1.0
+    G2, _ = main.FlagSpace(main.DG).resolve(["--model=diffusion", "--logdir", str(tmp_path / "run")])
+    assert G2.logdir == tmp_path / "run"                               # an explicit --logdir is used as is
+    saved = dict(G)
+    saved.update(full_cmd="python old", timesteps=7, model="diffusion_model", logdir=tmp_path / "ck")
+    (tmp_path / "ck").mkdir()
+    with open(tmp_path / "ck" / "hps.yaml", "w") as f:
+        yaml.dump(saved, f, width=float("inf"))
+    G3, M3 = main.FlagSpace(main.DG).resolve(["--weights_from", str(tmp_path / "ck" / "model.pt"), "--bs", "16"])
+    assert M3 is Model and G3.timesteps == 7 and G3.bs == 16 and "full_cmd" not in G3 and G3.logdir == tmp_path / "ck"
+    assert G3.weights_from == tmp_path / "ck" / "model.pt"
+
+
+def test_epoch_log_keys_and_deferred_host_transfer():
+    from generative_models_amd.main import EpochLog
+    log = EpochLog("diffusion")
+    log.add("train", {"loss": torch.tensor(2.0), "nlogp": torch.tensor(1.0)})
+    log.add("train", {"loss": torch.tensor(4.0)})
+    log.add("test", {"loss": torch.tensor(3.0), "nlogp": 0.5})
+    log.set("dt/train", 1.5)
+    host = log.to_host()
+    assert host == {"diffusion/train/loss": [2.0, 4.0], "train/nlogp": [1.0], "diffusion/test/loss": [3.0], "eval/nlogp": [0.5],
+                    "dt/train": 1.5}

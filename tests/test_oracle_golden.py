@@ -203,3 +203,23 @@ def test_attention_block_definition_matches_sdpa():
     names = [n for n, _ in U.param_spec(C, attention=True)]
     assert len(names) == 166 and names.index("attn.norm.weight") == names.index("turn.out_layers.3.bias") + 1
     assert len(U.param_spec(C)) == 160
+
+
+@pytest.mark.parametrize("name", ["definit_c128_s28.npz", "definit_c128_s32.npz"])
+def test_default_init_goldens_pin_the_oracle(golden, name):
+    """The default-init-scale set (oracle/make_golden.py:gen_default_init) the bf16 bar is held on: forward with / without
+    labels, per-sample loss and every gradient norm of the reference, reproduced by the oracle."""
+    g = golden(name)
+    p = U.reference_init_params(128, 1, seed=int(g["init_seed"]), zero_out_layers=False)
+    z, l, y = T(g["z"]), T(g["logsnr"]), T(g["guide"])
+    with torch.no_grad():
+        close(U.unet_forward(p, z, l, guide=y), g["v"])
+        close(U.unet_forward(p, z, l), g["v_noguide"])
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss_b = D.training_losses(pr, T(g["x0"]), y, T(g["u"]), T(g["eps"]))["loss"]
+    close(loss_b, g["loss_b"], 2e-5)
+    loss_b.mean().backward()
+    names = [str(n) for n in g["grad_names"]]
+    norms = torch.stack([pr[n].grad.norm() if pr[n].grad is not None else torch.tensor(0.0) for n in names])
+    ref = T(g["grad_norms"])
+    assert float(((norms - ref).abs() / (ref.abs() + 1e-6 * ref.abs().max())).max()) < 2e-3
