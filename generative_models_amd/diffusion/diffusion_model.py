@@ -94,6 +94,7 @@ def make_plugin(GMBase, AttrDict):
             self._sync.finish()
             self.optimizer.step(grad_scale=1.0 / world)
             metrics = {"loss": ops.mean(out["loss"])}
+            ops.throttle()                          # at most two steps queued on the GPU (see ops.throttle)
             metrics["loss_scale"] = torch.tensor(1.0)
             return metrics
 

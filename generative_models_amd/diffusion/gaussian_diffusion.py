@@ -245,6 +245,7 @@ class GaussianDiffusion:
             z_t, xp, ep = ops.sampler_step(v, z_t, lt, ls, i == 0, v_uncond=vu, cond_w=w, noise=noise, want_pred=record, mean_type=self.mean_type)
             if record:
                 zs.append(z_t); xs.append(xp); es.append(ep)
+            ops.throttle()                              # at most two sampler iterations queued on the GPU (see ops.throttle)
         if record:
             return torch.stack(zs), torch.stack(xs), torch.stack(es)
         return z_t[None], None, None
