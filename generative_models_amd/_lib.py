@@ -11,7 +11,8 @@ import re
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "gmk.h")
-LIBPATH = os.path.join(_PKG, "libgmk.so")
+# GMK_LIBGMK: another build of the SAME library (diagnostic variants made by tools/build_variant.sh); still the HIP path
+LIBPATH = os.environ.get("GMK_LIBGMK") or os.path.join(_PKG, "libgmk.so")
 
 _CTYPES = {
     "int": ctypes.c_int,

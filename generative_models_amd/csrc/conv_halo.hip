@@ -29,6 +29,10 @@
 // D[channel][pixel] orientation + v_permlane32_swap widening as conv_igemm_dma_kernel).
 #include "gmk_common.h"
 
+#ifndef GMK_HALO_STORE_AUX
+#define GMK_HALO_STORE_AUX 0      // cache policy of the wave-specialised kernel's output stores (experiments: 16 = sc1, write-through)
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -832,7 +836,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q4][1], pk[q4 + 1][1], false, false);
                         u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                         const unsigned off = live ? row_b + (unsigned)(cb + 8 * (q4 + h)) * ES : kBadOff;
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rso, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rso, off, 0, GMK_HALO_STORE_AUX);
                     }
                 }
             }
@@ -906,6 +910,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         stamp(3);
         ++tile_it;
     }
+#ifdef GMK_TS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every output store of this wave is complete
+    if (lane == 0) atomicMax(&g_ts.end[ts_slot(p.out)], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 }  // namespace

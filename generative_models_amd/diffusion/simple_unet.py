@@ -303,10 +303,18 @@ class SimpleUnet(nn.Module):
         B, H, W, _ = srcs[0].shape
         gpc = 32 // len(srcs)                                    # GroupNorm(32, cin): 16 groups per 128-ch source
         skip = {}
-        if len(srcs) == 2:      # the 1x1 skip convolution (HBM-bound) only needs the block input: it runs on the side stream beside
-            wfs, _ = self._packs[f"{name}.skip_connection"]      # GroupNorm / conv1 / GroupNorm and is joined in front of conv2
-            self._on_side(lambda: skip.__setitem__("res", ops.conv_igemm(srcs, wfs, C, 1, ops.NORMAL, (H, W),
-                                                                           bias=P[f"{name}.skip_connection.bias"])), tuple(srcs))
+        fwd_side = len(srcs) == 2 and ops.FWD_SIDE and ops.WGRAD_STREAM
+        if len(srcs) == 2:
+            # The 1x1 skip convolution (HBM-bound) only needs the block input.  With GMK_FWD_SIDE=1 it runs on the side stream beside
+            # GroupNorm / conv1 / GroupNorm and is joined in front of conv2 (-1 % of a forward).  OFF by default: that co-residency
+            # (conv_igemm_kernel's LDS staging next to the GroupNorm kernel) is where round 1's unexplained fault lived.
+            wfs, _ = self._packs[f"{name}.skip_connection"]
+            run_skip = lambda: skip.__setitem__("res", ops.conv_igemm(srcs, wfs, C, 1, ops.NORMAL, (H, W),
+                                                                      bias=P[f"{name}.skip_connection.bias"]))
+            if fwd_side:
+                self._on_side(run_skip, tuple(srcs))
+            else:
+                run_skip()
         a, stats1 = [], []
         for i, s in enumerate(srcs):
             g = P[f"{name}.in_layers.0.weight"][i * C:(i + 1) * C]
@@ -324,9 +332,10 @@ class SimpleUnet(nn.Module):
         a2, mean2, rstd2 = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], 32, dropout=drop,
                                            xadd=eadd)
         if len(srcs) == 2:
-            self._join_side()
             res = skip["res"]
-            res.record_stream(torch.cuda.current_stream())      # allocated on the side stream, consumed here
+            if fwd_side:
+                self._join_side()
+                res.record_stream(torch.cuda.current_stream())      # allocated on the side stream, consumed here
         else:
             res = srcs[0]
         wf2, _ = self._packs[f"{name}.out_layers.3"]
@@ -402,6 +411,8 @@ class SimpleUnet(nn.Module):
             self._side = torch.cuda.Stream(device=tensors[0].device)
         side = self._side
         side.wait_stream(torch.cuda.current_stream())
+        if ops.SIDE_DUMMY:          # experiment (tools/side_stream_det.py): a no-op kernel as the first dispatch behind the event marker
+            ops.rng_uniform((4,), 0, 0, tensors[0].device)
         with torch.cuda.stream(side):
             fn()
         for t in tensors:

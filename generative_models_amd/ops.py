@@ -126,6 +126,8 @@ def pack_conv_weights_multi(arena, packs, table):
 # measured on MI355X the DPP reductions in the conv epilogue cost as much as the statistics pass they save (27.25 vs
 # 27.19 ms/step), and with it a sample's result depends (in the last bits) on which tile neighbours it had.
 GN_STATS = False
+SIDE_DUMMY = os.environ.get("GMK_SIDE_DUMMY", "0") == "1"      # experiment switch, see simple_unet._on_side
+FWD_SIDE = os.environ.get("GMK_FWD_SIDE", "0") == "1"          # forward 1x1 skip convolutions on the side stream (simple_unet._res_fwd)
 WGRAD_STREAM = os.environ.get("GMK_WGRAD_STREAM", "1") != "0"    # weight gradients on a side stream beside the data-gradient chain (simple_unet._wgrad)
 
 

@@ -85,3 +85,21 @@ def test_sampler_full_batch(net):
     assert float(xs.abs().max()) <= 1.0 and bool(torch.isfinite(zs).all())
     z2 = d.sample(net=partial(net, guide=y), init_x=eps, record=False)[0][-1]
     assert torch.equal(z2, zs[-1])
+
+
+def test_forward_is_bit_reproducible_with_the_skip_convs_on_the_side_stream(net):
+    """tools/side_stream_det.py as a test: repeated identical forwards with GMK_FWD_SIDE (1x1 skip convolutions beside the
+    GroupNorm / conv1 chain) are bit-identical, and equal to the forward without the overlap.  A -DGMK_SHFL_BPERMUTE build fails
+    this about every second forward; the shipped DPP / permlane reductions have never failed it."""
+    from generative_models_amd import ops
+    x, y, u, _ = data(3)
+    l = u * 20 - 10
+    keep = ops.FWD_SIDE
+    try:
+        ops.FWD_SIDE = True
+        outs = [net.forward_hip(x, l, y, None).clone() for _ in range(8)]
+        ops.FWD_SIDE = False
+        plain = net.forward_hip(x, l, y, None)
+    finally:
+        ops.FWD_SIDE = keep
+    assert all(torch.equal(outs[0], o) for o in outs[1:]) and torch.equal(outs[0], plain)

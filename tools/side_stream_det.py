@@ -8,6 +8,7 @@ import sys
 import torch
 sys.path.insert(0, ".")
 from generative_models_amd import ops
+ops.FWD_SIDE = True          # the overlap under investigation (off by default in the product)
 from generative_models_amd.diffusion.simple_unet import SimpleUnet
 
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 12
