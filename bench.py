@@ -53,7 +53,8 @@ KERNEL_DESC = {
     "conv3x3_halo_ws_kernel[zero-stuffed transposed conv]": "data gradient of the stride-2 convs = the same kernel on the zero-stuffed gradient (algorithmic FLOPs are 1/4 of its MFMA work)",
     "conv_igemm_dma_kernel": "im2col LDS-DMA convolution (1x1, strided, upsampled, fp32)",
     "conv_igemm_kernel": "im2col register-staged convolution (small problems)",
-    "conv_wgrad_slots_kernel": "3x3 weight gradient over padded slots (+ slab reduce)",
+    "conv_wgrad_slots_kernel": "3x3 weight gradient over padded slots, 8 compute waves (+ slab reduce)",
+    "conv_wgrad_slots_ws_kernel": "3x3 weight gradient over padded slots, wave-specialised (+ slab reduce)",
     "conv_wgrad_kernel": "im2col split-K weight gradient (+ slab reduce)"}
 
 

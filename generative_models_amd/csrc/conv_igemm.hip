@@ -940,9 +940,8 @@ extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, 
     const int wforce = gmk_kernel_choice(1, "GMK_WGRAD_KERNEL");
     if (wforce != 1 && dtype == GMK_BF16 && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2) && ksize == 3) {
         const int ns2 = gmk_conv_wgrad_slots_try(dy, dy_cstride, src0, src1, c0, c1, B, ho, wo, cout, (float*)workspace,
-                                                 workspace_bytes, wforce == 2, mode == GMK_CONV_UPSAMPLE2, gmk_stream(stream));
+                                                 workspace_bytes, wforce, mode == GMK_CONV_UPSAMPLE2, gmk_stream(stream));
         if (ns2 > 0) {
-            gmk_note_kernel(12);
             int rc2 = gmk_check_launch("gmk_conv_wgrad(slots)");
             if (rc2) return rc2;
             const int64_t per2 = (int64_t)taps * cout * (c0 + c1);

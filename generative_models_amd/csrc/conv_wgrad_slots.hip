@@ -211,6 +211,201 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_kernel(const SlotPara
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-specialised form of the same slot correlation (the shape that took the forward 3x3 kernel from 810 to 970 TFLOP/s):
+// waves 4..7 only move data - every LDS-DMA instruction of a step and ALL the slot arithmetic behind it - waves 0..3 only
+// compute, one per SIMD (w and w + 4 share a SIMD).  Why: in the kernel above a SIMD hosts two waves that each issue 36 MFMAs,
+// 80 transposed fragment reads, 4 LDS-DMA instructions (60 - 185 issue cycles apiece) and ~150 VALU of slot arithmetic per
+// 64-slot step - about 2,900 - 3,900 issue cycles per SIMD against 2,304 cycles of MFMA time, in lockstep on both sides of one
+// barrier (MFMA busy 38 %).  A consumer cannot hold the 128 co x 64 ci x 9 taps tile alone (18 accumulators = 288 registers),
+// so the workgroup tile is 64 co x 64 ci x 9 taps: consumer (wco, wci) owns one 32 x 32 block of all 9 taps (9 accumulators) and
+// issues per step 36 MFMAs + 80 fragment reads and nothing else; twice as many workgroups split the slot range half as often,
+// so the slab bytes stay what they were, and the X / dY streams of the workgroups that share them meet in L2.
+// Pipeline: chunk c + AHEAD is issued during step c (AHEAD = 4, or 3 where 64-pixel rows need the wider X window) and the wait
+// in front of barrier c leaves the last AHEAD - 2 issue blocks in flight, so every chunk up to c + 1 has landed at barrier c: all
+// data of step c + 1 is already valid during step c, and the consumers read the next step's first fragments before its barrier.
+// LDS: dY ring 8 x 64 slots x 128 B (the workgroup's 64-co half of every dY row, swizzled like X), X ring as above.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kWsDyBase = 0;                 // 8 x 8 KiB
+constexpr int kWsXBase = 65536;              // 512-slot ring + mirror of its first LOOK*128 slots
+template <int LOOK> struct SlotWsLds {
+    static constexpr int kBytes = kWsXBase + (512 + LOOK * 128) * 128;
+    static constexpr int kAhead = LOOK == 1 ? 4 : 3;          // X ring: chunks c-LOOK .. c+LOOK+AHEAD must fit 8
+};
+
+template <int LOOK>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[SlotWsLds<LOOK>::kBytes];
+    constexpr unsigned kBadPix = 0x00FFFFFFu;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, W = p.W, WE = p.WE, RE = p.RE;
+    const int cis = blockIdx.y, cob = blockIdx.z;            // 64-ci tile, 64-co tile
+    const int c_begin = blockIdx.x * p.chunks_per_split;
+    const int c_end = min(c_begin + p.chunks_per_split, p.nchunks);
+    if (c_begin >= c_end) return;
+    const int nsteps = c_end - c_begin;
+    constexpr int AHEAD = SlotWsLds<LOOK>::kAhead;
+
+    if (wave >= 4) {
+        // =========================================== producer waves ===========================================
+        const int pw = wave - 4;
+        const int kelem0 = cis * 64;
+        const bool second = kelem0 >= p.c0;
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(second ? p.src1 : p.src0), 0, (int)(second ? p.nb1 : p.nb0), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)p.nbdy, 0x00020000);
+        const unsigned xs_b = (unsigned)(second ? p.c1 : p.c0) * 2;
+        const unsigned xoff_b = (unsigned)(second ? kelem0 - p.c0 : kelem0) * 2;
+        const unsigned ys_b = (unsigned)p.dy_cstride * 2;
+        const unsigned yoff_b = (unsigned)cob * 128;
+        // one instruction = 8 slots x 128 B; lane -> slot 8 (2 pw + u) + (lane >> 3) of the chunk, physical 16-B chunk lane & 7 holding
+        // logical chunk (lane & 7) ^ (bit1(S) << 2), bit1(S) = bit 4 of the lane index (same swizzle for X and dY)
+        const unsigned lc = (unsigned)(((lane & 7) ^ (((lane >> 4) & 1) << 2)) << 4);
+        const float inv_we = 1.0f / (float)WE, inv_re = 1.0f / (float)RE;
+        // position of this lane's slot u = 0 in the next chunk to issue, as (row index over all images, xe); branch-free advance
+        auto decode = [&](int S, int& row, int& xe) { row = S / WE; xe = S - row * WE; };
+        const int d64r = 64 / WE, d64x = 64 % WE, d8r = 8 / WE, d8x = 8 % WE;
+        auto advance = [&](int& row, int& xe, int dr, int dx) { xe += dx; row += dr; if (xe >= WE) { xe -= WE; ++row; } };
+        auto pixel = [&](int row, int xe, int shift) -> unsigned {
+            const int b = (int)(((float)row + 0.5f) * inv_re);           // exact for row < 2^22
+            const int ye = row - b * RE;
+            const bool ok = b < p.B && ye >= 1 && xe >= 1;               // ye <= H and xe <= W hold by construction
+            return ok ? (unsigned)((b * (H >> shift) + ((ye - 1) >> shift)) * (W >> shift) + ((xe - 1) >> shift)) : kBadPix;
+        };
+        int xc = c_begin - LOOK, yc = c_begin;
+        int xrow, xxe, yrow, yxe;
+        decode(64 * max(xc, 0) + 16 * pw + (lane >> 3), xrow, xxe);
+        decode(64 * yc + 16 * pw + (lane >> 3), yrow, yxe);
+        (void)inv_we;
+
+        auto issue_x = [&]() -> int {      // -> number of DMA instructions (2, or 4 with the mirror copy)
+            unsigned pix0 = kBadPix, pix1 = kBadPix;
+            if (xc >= 0) {
+                int r1 = xrow, x1 = xxe;
+                advance(r1, x1, d8r, d8x);
+                pix0 = pixel(xrow, xxe, p.xshift); pix1 = pixel(r1, x1, p.xshift);
+                advance(xrow, xxe, d64r, d64x);
+            }
+            const unsigned v0 = __umul24(pix0, xs_b) + xoff_b + lc, v1 = __umul24(pix1, xs_b) + xoff_b + lc;
+            const int rp = xc & 7;
+            GMK_LDS char* dst = (GMK_LDS char*)(smem + kWsXBase + rp * 8192 + pw * 2048);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (GMK_LDS void*)dst, 16, v0, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (GMK_LDS void*)(dst + 1024), 16, v1, 0, 0, 0);
+            ++xc;
+            if (rp < 2 * LOOK) {           // wave-uniform: mirror of the first ring chunks behind the ring's end
+                GMK_LDS char* dst2 = (GMK_LDS char*)(smem + kWsXBase + 65536 + rp * 8192 + pw * 2048);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (GMK_LDS void*)dst2, 16, v0, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (GMK_LDS void*)(dst2 + 1024), 16, v1, 0, 0, 0);
+                return 4;
+            }
+            return 2;
+        };
+        auto issue_y = [&]() {
+            int r1 = yrow, x1 = yxe;
+            advance(r1, x1, d8r, d8x);
+            const unsigned p0 = pixel(yrow, yxe, 0), p1 = pixel(r1, x1, 0);
+            advance(yrow, yxe, d64r, d64x);
+            GMK_LDS char* dst = (GMK_LDS char*)(smem + kWsDyBase + (yc & 7) * 8192 + pw * 2048);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (GMK_LDS void*)dst, 16, __umul24(p0, ys_b) + yoff_b + lc, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (GMK_LDS void*)(dst + 1024), 16, __umul24(p1, ys_b) + yoff_b + lc, 0, 0, 0);
+            ++yc;
+        };
+        // prologue: X chunks c-LOOK .. c+LOOK + dY chunk c (step 0's data), one block per further chunk up to c + AHEAD - 1
+#pragma unroll
+        for (int k = 0; k < 2 * LOOK + 1; ++k) issue_x();
+        issue_y();
+        issue_x(); issue_y();                    // chunk c + 1 (step 1's data)
+        int n2 = 0, n1 = 0;                      // instruction counts of the last two issue blocks (4, or 6 with a mirror copy)
+        if (AHEAD == 4) { n2 = issue_x() + 2; issue_y(); }
+        n1 = issue_x() + 2; issue_y();
+        for (int s = 0; s < nsteps; ++s) {
+            // everything but the last AHEAD - 2 issue blocks has to have landed
+            const int n = n1 + n2;
+            if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (AHEAD == 4) n2 = n1;
+            n1 = issue_x() + 2;                    // chunk c + AHEAD: X (+ mirror), dY
+            issue_y();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead DMA before the LDS is released
+        return;
+    }
+
+    // =============================================== consumer waves ===============================================
+    const int wco = wave >> 1, wci = wave & 1;
+    const int gg = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+    const int hh = gg >> 1, cblk = gg & 1;
+    // transposed fragment reads, 16-lane group gg, lane-in-group 4q + pp: rows = slots 16 kk + 8 hh + 4 t + q of the chunk, the
+    // 64-B half of a row is the wave's 32-channel block flipped by bit 1 of the slot index
+    const int dy_lane = kWsDyBase + (8 * hh + q) * 128 + ((wco ^ ((q >> 1) & 1)) << 6) + cblk * 32 + pp * 8;
+    int x_tap[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int off = (t / 3 - 1) * WE + (t % 3 - 1);
+        const int cls = (off + 64) & 3;
+        x_tap[t] = kWsXBase + (8 * hh + q + 64 * LOOK + off) * 128 + ((wci ^ (((q + cls) >> 1) & 1)) << 6) + cblk * 32 + pp * 8;
+    }
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    auto ld_a = [&](int c, int kk) -> bf16x8 {
+        const char* yb = smem + (c & 7) * 8192 + dy_lane + (16 * kk) * 128;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)yb);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)(yb + 4 * 128));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto ld_b = [&](int c, int kk, int t) -> bf16x8 {
+        const char* xb = smem + (((c - LOOK) & 7) << 13) + x_tap[t] + (16 * kk) * 128;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)xb);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)(xb + 4 * 128));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    bf16x8 a[2], b[4];
+    __builtin_amdgcn_s_barrier();                 // step 0's barrier: chunk c_begin (and c_begin + 1) are in LDS
+    a[0] = ld_a(c_begin, 0);
+    b[0] = ld_b(c_begin, 0, 0); b[1] = ld_b(c_begin, 0, 1); b[2] = ld_b(c_begin, 0, 2);
+    for (int c = c_begin; c < c_end; ++c) {
+        // 36 units (kk, tap) per step; the X fragment of unit u + 3 (three MFMAs = 96 cycles ahead of its use) and, at tap 5, the dY
+        // fragment of the next kk are read under the MFMA of unit u; the last three units read the first fragments of the NEXT
+        // step (valid already, see the header)
+#pragma unroll
+        for (int u = 0; u < 36; ++u) {
+            const int kk = u / 9, t = u % 9;
+            if (u + 3 < 36) b[(u + 3) & 3] = ld_b(c, (u + 3) / 9, (u + 3) % 9);
+            else b[(u + 3) & 3] = ld_b(c + 1, 0, u + 3 - 36);
+            if (t == 5) a[(kk + 1) & 1] = kk < 3 ? ld_a(c, kk + 1) : ld_a(c + 1, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk & 1], b[u & 3], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (t == 5) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        if (c + 1 < c_end) __builtin_amdgcn_s_barrier();      // the next step's barrier (one per producer iteration)
+    }
+
+    // ---- slab[split][tap][co][ci]
+    const int r = lane & 31, h = lane >> 5;
+    float* slab = p.slab + (((int64_t)blockIdx.x * 9) * p.cout + cob * 64 + wco * 32) * p.ktot + cis * 64 + wci * 32 + r;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = (e & 3) + 8 * (e >> 2) + 4 * h;
+            slab[((int64_t)t * p.cout + co) * p.ktot] = acc[t][e];
+        }
+}
+
 }  // namespace
 
 int gmk_wgrad_slots_nsplit(int cout, int ktot) {
@@ -250,7 +445,26 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
     p.B = B; p.H = H; p.W = W; p.WE = WE; p.RE = RE; p.slab = slab; p.nchunks = nchunks; p.chunks_per_split = cps;
     p.nbdy = (unsigned)nbdy; p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1;
     dim3 grid(ns, ktot / 64, cout / 128);
+    // forced: 0 automatic = 3 the wave-specialised kernel (1.37 - 1.58 x the 8-compute-wave kernel at every shape of the train step:
+    // tools/wgrad_bench.py); 2 the 8-compute-wave kernel (A/B)
+    const bool ws = forced != 2;
+    if (ws) {
+        int ns3 = gmk_cu_limit() / ((cout / 64) * (ktot / 64));
+        if (ns3 >= 8) ns3 &= ~7;          // workgroups that stream the same dY / X are ns3 block ids apart: a multiple of 8 keeps them on one XCD
+        if (ns3 < 1) ns3 = 1;
+        if (nchunks < 8 * ns3) ns3 = nchunks / 8 > 0 ? nchunks / 8 : 1;
+        const int cps3 = (nchunks + ns3 - 1) / ns3;
+        ns3 = (nchunks + cps3 - 1) / cps3;
+        if ((int64_t)ns3 * 9 * cout * ktot * 4 > slab_bytes) return 0;
+        p.chunks_per_split = cps3;
+        dim3 grid3(ns3, ktot / 64, cout / 64);
+        if (wide) conv_wgrad_slots_ws_kernel<2><<<grid3, 512, 0, stream>>>(p);
+        else conv_wgrad_slots_ws_kernel<1><<<grid3, 512, 0, stream>>>(p);
+        gmk_note_kernel(13);
+        return ns3;
+    }
     if (wide) conv_wgrad_slots_kernel<2><<<grid, 512, 0, stream>>>(p);
     else conv_wgrad_slots_kernel<1><<<grid, 512, 0, stream>>>(p);
+    gmk_note_kernel(12);
     return ns;
 }
