@@ -185,7 +185,209 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused forward: O = softmax(Q K^T / sqrt(C)) V for one sample per workgroup, C = 128 channels, N <= 256 tokens (BASELINE config 5:
+// 16 x 16 tokens at the lowest level of a 64 x 64 net), no N x N matrix in HBM (training passes `pout` to keep P for the backward).
+// K and V of the sample are staged once into LDS (128 KiB at N = 256); wave w owns queries 32 w .. 32 w + 31.
+//   S^T = K Q^T   one v_mfma_f32_32x32x16 chain per 32-key block with the KEY on the accumulator row and the QUERY on the lane,
+//                 so a lane holds 128 of its query's scores: the row maximum / sum are register reductions plus one
+//                 v_permlane32_swap with the lane that holds the other 128;
+//   O^T = V^T P^T the probabilities never leave the registers: registers 8 s .. 8 s + 7 of a score block, rounded pairwise, ARE
+//                 the B operand of k-step s of the next product (k order 16 s + 8 (j >> 2) + 4 h + (j & 3)); the A operand
+//                 V^T[d][key] comes from LDS in that same key order - ds_read_b64_tr_b16 on the bf16 image, plain 8-byte reads
+//                 on a transposed fp8 image laid out in that order.
+// kFp8: both contractions on v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3; K, V, Q and P rounded to fp8, fp32 accumulation) - the
+// north_star's "fp8 MFMA" for config 5.  Parity: vs the bf16 three-kernel path, tests/test_gpu_ops.py.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2a;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4a;
+
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
+template <bool kFp8>
+__global__ __launch_bounds__(512, 2) void attn_fused_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                               bf16_t* __restrict__ pout, int N, float c_log2e) {
+    constexpr int C = 128;
+    // bf16: Ks [N][256 B] (16-B chunk ^ (row & 15)), Vs [N][256 B] (T10 image (b): chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)))
+    // fp8 : Ks [N][128 B] (8-B chunk ^ ((row >> 1) & 15)), Vt [128 d][N B] in the permuted key order (8-B chunk ^ (d & 31))
+    __shared__ __attribute__((aligned(16))) char smem[2 * 256 * 256];
+    char* Ks = smem;
+    char* Vs = smem + (kFp8 ? N * 128 : N * 256);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x;
+    const bf16_t* base = qkv + (size_t)b * N * (3 * C);
+
+    // ---- stage K and V: N rows x 16 chunks of 8 channels each
+    for (int idx = tid; idx < N * 16; idx += 512) {
+        const int row = idx >> 4, ch = idx & 15;
+        const bf16x8 kv = *reinterpret_cast<const bf16x8*>(base + (size_t)row * (3 * C) + C + ch * 8);
+        const bf16x8 vv = *reinterpret_cast<const bf16x8*>(base + (size_t)row * (3 * C) + 2 * C + ch * 8);
+        if (!kFp8) {
+            *reinterpret_cast<bf16x8*>(Ks + row * 256 + ((ch ^ (row & 15)) << 4)) = kv;
+            *reinterpret_cast<bf16x8*>(Vs + row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4)) = vv;
+        } else {
+            u32x2a k8 = {pack4_fp8((float)kv[0], (float)kv[1], (float)kv[2], (float)kv[3]),
+                         pack4_fp8((float)kv[4], (float)kv[5], (float)kv[6], (float)kv[7])};
+            *reinterpret_cast<u32x2a*>(Ks + row * 128 + ((ch ^ ((row >> 1) & 15)) << 3)) = k8;
+            // V^T image: byte (d, pos), pos = the key's place in the k order of the P^T operand: key = 32 kb + 16 s + 8 g + 4 hh + jj
+            // sits at pos = 32 kb + 16 s + 8 hh + 4 g + jj
+            const int kin = row & 31;
+            const int pos = (row & ~31) | (kin & 16) | (((kin >> 2) & 1) << 3) | (((kin >> 3) & 1) << 2) | (kin & 3);
+            const unsigned lo = pack4_fp8((float)vv[0], (float)vv[1], (float)vv[2], (float)vv[3]);
+            const unsigned hi = pack4_fp8((float)vv[4], (float)vv[5], (float)vv[6], (float)vv[7]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = ch * 8 + e;
+                const unsigned byte = ((e < 4 ? lo : hi) >> (8 * (e & 3))) & 0xFFu;
+                Vs[d * N + ((((pos >> 3) ^ (d & 31)) & ((N >> 3) - 1)) << 3) + (pos & 7)] = (char)byte;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave * 32 >= N) return;                      // N = 64: two waves compute (no barrier follows)
+
+    // ---- Q fragments of this wave's 32 queries: B operand, lane (query r, half h) holds d = 16 kg + 8 h .. + 7
+    const bf16_t* qrow = base + (size_t)(wave * 32 + r) * (3 * C);
+    bf16x8 qf[8];
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) qf[kg] = *reinterpret_cast<const bf16x8*>(qrow + kg * 16 + h * 8);
+    long q8[8];
+    if (kFp8) {
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) {
+            const u32x2a v = {pack4_fp8((float)qf[kg][0], (float)qf[kg][1], (float)qf[kg][2], (float)qf[kg][3]),
+                              pack4_fp8((float)qf[kg][4], (float)qf[kg][5], (float)qf[kg][6], (float)qf[kg][7])};
+            q8[kg] = __builtin_bit_cast(long, v);
+        }
+    }
+
+    // ---- S^T = K Q^T, one 32-key block at a time
+    const int nkb = N >> 5;
+    f32x16 sc[8];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[kb][e] = 0.f;
+        if (kb < nkb) {
+            const int key = kb * 32 + r;
+#pragma unroll
+            for (int kg = 0; kg < 8; ++kg) {
+                if (!kFp8) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + key * 256 + (((kg * 2 + h) ^ (key & 15)) << 4));
+                    sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kg], sc[kb], 0, 0, 0);
+                } else {
+                    const long kf = *reinterpret_cast<const long*>(Ks + key * 128 + (((kg * 2 + h) ^ ((key >> 1) & 15)) << 3));
+                    sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(kf, q8[kg], sc[kb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- softmax over the query's N keys: this lane holds N / 2 of them, lane ^ 32 the others
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+        if (kb < nkb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[kb][e]);
+        }
+    { float a = mx, bq = mx; halves_swap32(a, bq); mx = fmaxf(a, bq); }
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+        if (kb < nkb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sc[kb][e] = __builtin_amdgcn_exp2f((sc[kb][e] - mx) * c_log2e); sum += sc[kb][e]; }
+        }
+    { float a = sum, bq = sum; halves_swap32(a, bq); sum = a + bq; }
+    const float inv = 1.0f / sum;
+    const int qi = wave * 32 + r;
+    if (pout) {       // P[b][q][key] for the backward pass: key = 32 kb + 8 g + 4 h + (0..3) -> 8-byte stores
+        bf16_t* prow = pout + ((size_t)b * N + qi) * N;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb)
+            if (kb < nkb) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const bf16x4 t = {(bf16_t)(sc[kb][4 * g] * inv), (bf16_t)(sc[kb][4 * g + 1] * inv), (bf16_t)(sc[kb][4 * g + 2] * inv),
+                                      (bf16_t)(sc[kb][4 * g + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(prow + kb * 32 + 8 * g + 4 * h) = t;
+                }
+            }
+    }
+    // ---- O^T = V^T P^T (un-normalised probabilities; 1 / sum applied to the result)
+    f32x16 oc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oc[db][e] = 0.f;
+    const int gg = lane >> 4, i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        if (kb < nkb) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (!kFp8) {
+                    const bf16x8 pf = {(bf16_t)sc[kb][8 * s], (bf16_t)sc[kb][8 * s + 1], (bf16_t)sc[kb][8 * s + 2], (bf16_t)sc[kb][8 * s + 3],
+                                       (bf16_t)sc[kb][8 * s + 4], (bf16_t)sc[kb][8 * s + 5], (bf16_t)sc[kb][8 * s + 6], (bf16_t)sc[kb][8 * s + 7]};
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) {
+                        // transposed read of V: rows = keys 32 kb + 16 s + 4 hh (+ 8) + 0..3, columns d = 32 db + 16 (gg & 1) + 0..15
+                        const int c0 = 4 * db + 2 * (gg & 1) + (pp >> 1);
+                        typedef __attribute__((ext_vector_type(8))) short s16x8;
+                        s16x4 lo, hi;
+                        {
+                            const int row = kb * 32 + 16 * s + 4 * (gg >> 1) + qq;
+                            lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)(Vs + row * 256 + ((c0 ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4) + 8 * (pp & 1)));
+                        }
+                        {
+                            const int row = kb * 32 + 16 * s + 8 + 4 * (gg >> 1) + qq;
+                            hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)(Vs + row * 256 + ((c0 ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4) + 8 * (pp & 1)));
+                        }
+                        const s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        oc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pf, oc[db], 0, 0, 0);
+                    }
+                } else {
+                    const u32x2a pv = {pack4_fp8(sc[kb][8 * s], sc[kb][8 * s + 1], sc[kb][8 * s + 2], sc[kb][8 * s + 3]),
+                                       pack4_fp8(sc[kb][8 * s + 4], sc[kb][8 * s + 5], sc[kb][8 * s + 6], sc[kb][8 * s + 7])};
+                    const long pf = __builtin_bit_cast(long, pv);
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) {
+                        const int d = 32 * db + r;
+                        const int chunk = (kb * 32 + 16 * s + 8 * h) >> 3;
+                        const long vf = *reinterpret_cast<const long*>(Vs + d * N + (((chunk ^ (d & 31)) & ((N >> 3) - 1)) << 3));
+                        oc[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf, oc[db], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- O[b][q][d], d = 32 db + 8 g + 4 h + (0..3)
+    bf16_t* orow = o + ((size_t)b * N + qi) * C;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bf16x4 t = {(bf16_t)(oc[db][4 * g] * inv), (bf16_t)(oc[db][4 * g + 1] * inv), (bf16_t)(oc[db][4 * g + 2] * inv),
+                              (bf16_t)(oc[db][4 * g + 3] * inv)};
+            *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * g + 4 * h) = t;
+        }
+}
+
 }  // namespace
+
+extern "C" int gmk_attention_fwd(const void* qkv, void* o, void* p_out, int B, int N, int C, float scale, int fp8, void* stream) {
+    GMK_REQUIRE(qkv && o && B > 0, "gmk_attention_fwd: bad arguments");
+    GMK_REQUIRE(C == 128 && (N == 64 || N == 128 || N == 256), "gmk_attention_fwd: needs C = 128 and N in {64, 128, 256} tokens (got C=%d N=%d)", C, N);
+    const float c_log2e = scale * 1.4426950408889634f;
+    if (fp8) attn_fused_fwd_kernel<true><<<B, 512, 0, gmk_stream(stream)>>>((const bf16_t*)qkv, (bf16_t*)o, (bf16_t*)p_out, N, c_log2e);
+    else attn_fused_fwd_kernel<false><<<B, 512, 0, gmk_stream(stream)>>>((const bf16_t*)qkv, (bf16_t*)o, (bf16_t*)p_out, N, c_log2e);
+    return gmk_check_launch("gmk_attention_fwd");
+}
 
 extern "C" int gmk_bgemm_nt(const void* A, int64_t a_batch, int64_t lda, const void* B, int64_t b_batch, int64_t ldb, void* C,
                             int64_t c_batch, int64_t ldc, int batch, int M, int N, int K, float alpha, int in_dtype, int out_dtype,

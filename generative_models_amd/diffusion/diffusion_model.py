@@ -45,20 +45,21 @@ def make_plugin(GMBase, AttrDict):
         # additions of the HIP path
         DG.compute_dtype = "bf16"      # 'bf16' (MFMA) or 'fp32' (exact-fp32 MFMA, 1e-3 parity mode)
         DG.in_channels = 1             # reference: 1 (simple_unet.py:93,41)
-        DG.attention = 0               # 1: self-attention block behind `turn` (north_star / BASELINE config 5; not in the reference)
+        DG.attention = 0               # 1: self-attention block behind `turn` (north_star / BASELINE config 5; not in the reference); 2: the same
+                                       # with QK^T / PV on the fp8 matrix cores
         DG.seed = 0
 
         def __init__(self, G):
             super().__init__(G)
             get = lambda k: G[k] if k in G else self.DG[k]
             self.net = SimpleUnet(get("hidden_size"), get("dropout"), in_channels=get("in_channels"),
-                                  compute_dtype=_DTYPES[get("compute_dtype")], attention=bool(get("attention")))
+                                  compute_dtype=_DTYPES[get("compute_dtype")], attention=int(get("attention")))
             weights_from = Path(G["weights_from"]) if "weights_from" in G else Path(".")
             if Path(get("teacher_path")) != Path(".") and weights_from == Path("."):      # diffusion_model.py:34-43
                 print("Loading teacher model")
                 self.load_state_dict(torch.load(get("teacher_path"), map_location="cpu"), strict=False)
                 self.teacher_net = SimpleUnet(get("hidden_size"), get("dropout"), in_channels=get("in_channels"),
-                                              compute_dtype=_DTYPES[get("compute_dtype")], attention=bool(get("attention")))
+                                              compute_dtype=_DTYPES[get("compute_dtype")], attention=int(get("attention")))
                 self.teacher_net.load_state_dict(self.net.state_dict())
                 self.teacher_net.eval()
                 for param in self.teacher_net.parameters():

@@ -100,6 +100,7 @@ class SimpleUnet(nn.Module):
         self.dropout = float(dropout)      # nn.Dropout(p) of every ResBlock's out_layers (simple_unet.py:171); training mode only
         self.drop_seed, self._drop_counter = 0x5EEDD0, 0
         self.attention = bool(attention)
+        self.attention_fp8 = int(attention) == 2      # attention=2: QK^T / PV on the fp8 matrix cores (BASELINE config 5)
         self._inventory = param_inventory(channels, in_channels, self.attention)
         # arena order: the 12 emb_layers Linear weights, their biases, the 12 conv1 biases (one batched GEMM with two bias
         # tables serves all 12 ResBlocks), then everything else in reference order; every tensor starts on a 16-byte boundary.
@@ -359,9 +360,13 @@ class SimpleUnet(nn.Module):
         qkv = ops.conv_igemm([a], self._packs["attn.qkv"][0], 3 * C, 1, ops.NORMAL, (H, W), cout=3 * C, bias=P["attn.qkv.bias"])
         t = qkv.view(B, N, 3 * C)
         q, k, v = t[:, :, :C], t[:, :, C:2 * C], t[:, :, 2 * C:]
-        S = ops.bgemm_nt(q, k, out_dtype=torch.float32)
-        Pm = ops.softmax_fwd(S, C ** -0.5, T)
-        o = ops.bgemm_nt(Pm, ops.transpose_last2(v)).view(B, H, W, C)
+        if T == torch.bfloat16 and N in (64, 128, 256):       # fused: K / V resident in LDS, no fp32 score matrix in HBM
+            o, Pm = ops.attention_fwd(t, C ** -0.5, want_p=ctx is not None, fp8=self.attention_fp8)
+            o = o.view(B, H, W, C)
+        else:
+            S = ops.bgemm_nt(q, k, out_dtype=torch.float32)
+            Pm = ops.softmax_fwd(S, C ** -0.5, T)
+            o = ops.bgemm_nt(Pm, ops.transpose_last2(v)).view(B, H, W, C)
         out = ops.conv_igemm([o], self._packs["attn.proj"][0], C, 1, ops.NORMAL, (H, W), bias=P["attn.proj.bias"], residual=x)
         if ctx is not None:
             ctx["attn"] = (x, a, mean, rstd, qkv, Pm, o)

@@ -563,6 +563,18 @@ def bgemm_nt(A, B, out=None, alpha=1.0, out_dtype=None):
     return out
 
 
+def attention_fwd(qkv, scale, want_p=False, fp8=False):
+    """Fused softmax(scale * q k^T) v for qkv [B, N, 3C] (bf16, C = 128, N in {64, 128, 256}) -> (o [B, N, C], P [B, N, N] or None).
+    fp8: both contractions on the fp8 (e4m3) matrix cores."""
+    _chk(qkv, torch.bfloat16, "qkv")
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    o = torch.empty((B, N, C), device=qkv.device, dtype=qkv.dtype)
+    P = torch.empty((B, N, N), device=qkv.device, dtype=qkv.dtype) if want_p else None
+    check(lib.gmk_attention_fwd(_p(qkv), _p(o), _p(P), B, N, C, float(scale), int(bool(fp8)), _s()), "attention_fwd")
+    return o, P
+
+
 def transpose_last2(x, out=None):
     """[batch, R, C] (unit last stride, free row / batch strides) -> contiguous [batch, C, R]."""
     assert x.dim() == 3 and x.stride(2) == 1 and x.is_cuda and x.dtype in _DT

@@ -207,6 +207,11 @@ int gmk_transpose(const void* in, int64_t in_batch, int64_t ld_in, void* out, in
 /* P[r][:] = softmax(scale * S[r][:]) over rows of N <= 1024 fp32 scores; P in out_dtype */
 int gmk_softmax_fwd(const float* S, void* P, int64_t rows, int N, float scale, int out_dtype, void* stream);
 /* dS = scale * P * (dP - sum_j dP_j P_j)  (P, dS in dtype; dP fp32) */
+/* fused forward of the block's core: o[b] = softmax(scale * q[b] k[b]^T) v[b] with q, k, v the three C-column blocks of qkv
+ * [B][N][3C] (bf16), one workgroup per sample, K / V resident in LDS, no N x N matrix in HBM unless p_out (bf16 [B][N][N], the
+ * probabilities the backward pass needs) is given.  fp8 != 0: both contractions on the fp8 (OCP e4m3) matrix cores with fp32
+ * accumulation - BASELINE config 5's "fp8 MFMA".  C = 128, N in {64, 128, 256}. */
+int gmk_attention_fwd(const void* qkv, void* o, void* p_out, int B, int N, int C, float scale, int fp8, void* stream);
 int gmk_softmax_bwd(const void* P, const float* dP, void* dS, int64_t rows, int N, float scale, int dtype, void* stream);
 
 /* ---- progressive distillation (gaussian_diffusion.py:87-91,105-154) ------------------------------------------ */

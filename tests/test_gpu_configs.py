@@ -117,6 +117,28 @@ def test_distillation_integer_times_bit_exact(golden, name):
         assert uu.cpu().numpy().tobytes() == ref.numpy().tobytes()
 
 
+def test_fp8_attention_net_vs_bf16_attention_net():
+    """`--attention 2` (configs[4]: QK^T / PV on the fp8 matrix cores) against `--attention 1` on the same weights at the config's
+    shape (3x64x64 -> 256 tokens): same parameters (166 tensors), outputs within 2e-2 of the output scale (the block is one of
+    thirteen residual branches; its own fp8 error is 4e-2 ... 8e-2 of the block output, tests/test_gpu_ops.py)."""
+    from generative_models_amd.diffusion.simple_unet import SimpleUnet
+    net1, params = live_net(torch.bfloat16, in_channels=3, attention=True)
+    net2 = SimpleUnet(128, 0.0, in_channels=3, compute_dtype=torch.bfloat16, attention=2)
+    net2.load_state_dict(params, strict=True)
+    net2 = net2.cuda()
+    assert net2.attention and net2.attention_fp8 and not net1.attention_fp8 and len(net2.state_dict()) == 166
+    g = torch.Generator().manual_seed(8)
+    z = torch.randn((2, 3, 64, 64), generator=g).cuda(); l = torch.tensor([0.5, -3.0]).cuda(); y = torch.tensor([1, 6]).cuda()
+    a, b = net1.forward_hip(z, l, y, None), net2.forward_hip(z, l, y, None)
+    e = rel_err(b, a)
+    assert 0 < e < 2e-2, e
+    # training through the fp8 forward: the backward consumes the stored probabilities as before
+    ctx = {}
+    out = net2.forward_hip(z, l, y, None, ctx=ctx)
+    net2.backward_hip(ctx, torch.randn_like(out))
+    assert bool(torch.isfinite(net2.flat_grads).all()) and float(net2.grad("attn.qkv.weight").abs().max()) > 0
+
+
 def test_gradient_buckets_are_final_when_handed_over():
     """Data parallelism hands bucket k to the all-reduce at `on_grads_ready(k)`.  The gradient arena is filled with a sentinel, a
     snapshot is taken inside each callback (in stream order, behind the side-stream join): the snapshot must already equal the

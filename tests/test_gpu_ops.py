@@ -501,3 +501,33 @@ def test_pack_multi_equals_single(ops):
             wf = torch.empty(n, device="cuda", dtype=dtype); wd = torch.empty_like(wf)
             ops.pack_conv_weight(arena[wo:wo + n].view(shp), wf, wd)
             assert torch.equal(packs[pofs:pofs + n], wf) and torch.equal(packs[pofs + n:pofs + 2 * n], wd)
+
+
+@pytest.mark.parametrize("N", [64, 256])
+@pytest.mark.parametrize("fp8", [False, True])
+def test_fused_attention_forward(ops, N, fp8):
+    """gmk_attention_fwd (BASELINE config 5: 256 tokens x 128 channels; 64 tokens at 32 x 32 inputs): o and the optional P against
+    softmax(q k^T / sqrt(C)) v in fp32 on the same bf16 inputs, and against the three-kernel bf16 path it replaces.  The fp8 form
+    (both contractions on the e4m3 matrix cores, fp32 accumulation; e4m3 carries 3 mantissa bits, 2^-4 per element) is held to 1e-1
+    max-norm / 8e-2 L2 against that path: measured 4.7e-2 ... 8.5e-2 / 3.9e-2 ... 7.3e-2 from soft to sharp softmax (tools/attn_probe.py);
+    the bf16 form measures 2e-3 ... 3.6e-3."""
+    B, C = 5, 128
+    g = torch.Generator().manual_seed(N + fp8)
+    qkv = (torch.randn((B, N, 3 * C), generator=g) * 1.5).bfloat16().cuda()
+    q, k, v = (qkv[:, :, i * C:(i + 1) * C].float() for i in range(3))
+    scale = C ** -0.5
+    Pref = torch.softmax(torch.einsum("bic,bjc->bij", q, k) * scale, dim=-1)
+    oref = torch.einsum("bij,bjc->bic", Pref, v)
+    o, P = ops.attention_fwd(qkv, scale, want_p=True, fp8=fp8)
+    o2, none = ops.attention_fwd(qkv, scale, want_p=False, fp8=fp8)
+    assert none is None and torch.equal(o, o2)
+    S = ops.bgemm_nt(qkv[:, :, :C], qkv[:, :, C:2 * C], out_dtype=torch.float32)
+    Pm = ops.softmax_fwd(S, scale, torch.bfloat16)
+    o3 = ops.bgemm_nt(Pm, ops.transpose_last2(qkv[:, :, 2 * C:]))
+    err = lambda a, b: float((a.float() - b.float()).abs().max() / b.float().abs().max())
+    tol = 1e-1 if fp8 else 1e-2
+    assert err(o, oref) < tol and err(o, o3) < tol, (err(o, oref), err(o, o3))
+    l2 = float((o.float() - oref).norm() / oref.norm())
+    assert l2 < (8e-2 if fp8 else 5e-3), l2
+    assert err(P, Pref) < (1e-1 if fp8 else 1e-2), err(P, Pref)
+    assert float((P.float().sum(-1) - 1).abs().max()) < 2e-2
