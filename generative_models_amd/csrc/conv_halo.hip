@@ -54,6 +54,7 @@ struct HaloParams {
     const float* bias; const float* emb; int emb_stride;
     const void* residual; void* out; int out_cstride; int M;
     unsigned nb0, nb1, nbw, nbo;
+    const float* gn_scale; const float* gn_shift; int gn_stride;      // fused GroupNorm-apply + SiLU on the SOURCE: y = silu(x * scale[b][k] + shift[b][k])
     float* stats;                              // optional GroupNorm partial sums [ntiles][8][2][Cout/4][2] (see gmk.h)
     int stats_groups;                          // Cout/4
     int variant;                               // GMK_DEV_VARIANT (experiments)
@@ -441,7 +442,7 @@ template <int N> struct IntTag { static constexpr int value = N; };
 // MFMA time: tools/halo_stamps.py).  Here a SIMD hosts one consumer (32 MFMAs + 24 ds_read_b128 per K-step: 0.75 reads
 // per MFMA instead of 1) and one producer, w and w+4 share a SIMD, and the consumer's epilogue stores no longer sit in the
 // same vmcnt queue as the DMA (no `fresh` bookkeeping).  One s_barrier per K-step, crossed by all 8 waves.
-template <bool kPrefetchW, int kShape = 32>
+template <bool kPrefetchW, int kShape = 32, bool kFuse = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParams p) {
     constexpr int ES = 2;
     __shared__ __attribute__((aligned(16))) char smem[kWOFF + 3 * kWST];
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 const int b = b0 + k;
                 const bool ok = exists && y >= 0 && y < H && x >= 0 && x < W && b < p.B;
                 const unsigned pix = ok && !((y | x) & p.pmask) ? (unsigned)((b * (H >> p.shift) + (y >> p.shift)) * (W >> p.shift) + (x >> p.shift)) : kBadPix;
-                hpix[j][u] = pix | ((unsigned)(lch ^ ((n >> 1) & 7)) << 24);
+                hpix[j][u] = pix | ((unsigned)(lch ^ ((n >> 1) & 7)) << 24) | ((unsigned)(k & 1) << 28);      // bit 28: sample b0 + k (fused GroupNorm)
             }
         };
         auto issue_fill = [&](int hbuf, int ph, int j) {
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 GMK_LDS char* dst = (GMK_LDS char*)(smem + hbuf * kHB + j * 8192 + (pw * 2 + u) * 1024);
-                const unsigned voff = __umul24(hpix[j][u], cs_b) + koff_b + ((hpix[j][u] >> 24) << 4);
+                const unsigned voff = __umul24(hpix[j][u], cs_b) + koff_b + (((hpix[j][u] >> 24) & 7u) << 4);
                 if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (GMK_LDS void*)dst, 16, voff, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (GMK_LDS void*)dst, 16, voff, 0, 0, 0);
             }
@@ -553,6 +554,172 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             }
         };
 
+
+        if constexpr (kFuse) {
+            // ------------------------------------------------------------------------------------------------------------
+            // Fused GroupNorm-apply + SiLU (reference sites simple_unet.py:161-163,169-172): the source is the RAW tensor; the halo
+            // pieces come through registers instead of LDS-DMA: 16-byte loads two K-steps ahead of their use, y = silu(x * scale +
+            // shift) with the (sample, channel) tables of gmk_gn_stats in fp32, rounded to bf16, ds_write_b128 into the slot's
+            // swizzled chunk (pad slots stay exact zeros).  A lane always handles the SAME 8 channels of its slots (logical chunk
+            // lane & 7), so a phase needs 2 x 8 scale and 2 x 8 shift values per lane: a tile of R <= H rows touches at most the
+            // samples b0 and b0 + 1 (bit 28 of hpix selects).  Counted waits: the weight DMA of a step is issued first, then the
+            // table loads (tap 0) and the step's two halo loads; loads of piece t are complete at the top of step t + 2 because the
+            // weights issued behind them at step t + 1 have to be (vmcnt retires in order).
+            // ------------------------------------------------------------------------------------------------------------
+            const char* gsrc[2] = {(const char*)p.src0, (const char*)(p.c1 ? p.src1 : p.src0)};
+            u32x4 L[3][2];
+            f32x4 Csc[2][2], Csh[2][2];         // [sample b0 / b0 + 1][channels 0-3 / 4-7 of this lane's chunk] of the phase being filled
+            auto load_tables = [&](int tl, int ph) {          // 8 x 16-byte loads (counted by hand)
+                const int gr0 = (tl < p.ntiles ? tl : 0) * p.R;
+                const int b0 = gr0 / H;
+                const int kch = (ph << 6) + lch * 8;
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    const int bb = min(b0 + sidx, p.B - 1);
+                    const float* ps = p.gn_scale + (size_t)bb * p.gn_stride + kch;
+                    const float* ph_ = p.gn_shift + (size_t)bb * p.gn_stride + kch;
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Csc[sidx][0]) : "v"(ps) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(Csc[sidx][1]) : "v"(ps) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Csh[sidx][0]) : "v"(ph_) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(Csh[sidx][1]) : "v"(ph_) : "memory");
+                }
+            };
+            auto load_piece = [&](int ph, int j, int set) {   // 2 x 16-byte loads of this lane's logical chunk of its two slots
+                const int kelem = ph << 6;
+                const bool second = kelem >= p.c0;
+                const unsigned cs_b = (unsigned)(second ? p.c1 : p.c0) * ES;
+                const unsigned koff_b = (unsigned)(second ? kelem - p.c0 : kelem) * ES + (unsigned)lch * 16u;
+                const char* sb = gsrc[second ? 1 : 0];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned pix = hpix[j][u] & 0x00FFFFFFu;
+                    const char* a = sb + (pix == kBadPix ? 0u : __umul24(pix, cs_b) + koff_b);      // pad slots: any valid address, zeroed below
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(L[set][u]) : "v"(a) : "memory");
+                }
+            };
+            // one instruction's worth (this lane's 16-byte chunk of one slot): kSel 0 / 1 = every live lane belongs to sample b0 / b0 + 1
+            // (wave-uniform, the common case), 2 = mixed (a piece that straddles the image boundary): per-lane select
+            auto xform = [&](const u32x4 raw, unsigned hp, auto sel_tag) -> u32x4 {
+                constexpr int kSel = decltype(sel_tag)::value;
+                constexpr float kNegLog2e = -1.4426950408889634f;
+                const bool valid = (hp & 0x00FFFFFFu) != kBadPix;
+                const bool s1 = (hp >> 28) & 1u;
+                u32x4 o;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float x0 = __builtin_bit_cast(float, raw[w] << 16), x1 = __builtin_bit_cast(float, raw[w] & 0xFFFF0000u);
+                    const int h0 = (2 * w) >> 2, l0 = (2 * w) & 3, l1 = l0 + 1;
+                    float a0, c0, a1, c1;
+                    if (kSel == 0) { a0 = Csc[0][h0][l0]; c0 = Csh[0][h0][l0]; a1 = Csc[0][h0][l1]; c1 = Csh[0][h0][l1]; }
+                    else if (kSel == 1) { a0 = Csc[1][h0][l0]; c0 = Csh[1][h0][l0]; a1 = Csc[1][h0][l1]; c1 = Csh[1][h0][l1]; }
+                    else {
+                        a0 = s1 ? Csc[1][h0][l0] : Csc[0][h0][l0]; c0 = s1 ? Csh[1][h0][l0] : Csh[0][h0][l0];
+                        a1 = s1 ? Csc[1][h0][l1] : Csc[0][h0][l1]; c1 = s1 ? Csh[1][h0][l1] : Csh[0][h0][l1];
+                    }
+                    const float t0 = fmaf(x0, a0, c0), t1 = fmaf(x1, a1, c1);
+                    const float y0 = t0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t0 * kNegLog2e));
+                    const float y1 = t1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t1 * kNegLog2e));
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                    const bf16x2 pk = {(bf16_t)y0, (bf16_t)y1};
+                    o[w] = valid ? __builtin_bit_cast(unsigned, pk) : 0u;
+                }
+                return o;
+            };
+            auto store_piece = [&](int hb, int j, int set) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    asm volatile("" : "+v"(L[set][u]));
+                    const unsigned hp = hpix[j][u];
+                    const bool valid = (hp & 0x00FFFFFFu) != kBadPix;
+                    const unsigned long long mv = __builtin_amdgcn_ballot_w64(valid);
+                    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(valid && ((hp >> 28) & 1u));
+                    u32x4 o = {0u, 0u, 0u, 0u};
+                    if (mv != 0) {                       // pieces of pad slots only (a third of a 28 x 28 halo) skip the arithmetic
+                        if (m1 == 0) o = xform(L[set][u], hp, IntTag<0>{});
+                        else if (m1 == mv) o = xform(L[set][u], hp, IntTag<1>{});
+                        else o = xform(L[set][u], hp, IntTag<2>{});
+                    }
+                    char* dst = smem + hb * kHB + j * 8192 + (pw * 2 + u) * 1024 + lrow * 128 + (((hp >> 24) & 7u) << 4);
+                    *reinterpret_cast<u32x4*>(dst) = o;
+                }
+            };
+            const __amdgpu_buffer_rsrc_t rsr =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
+            unsigned pf0 = 0, pf1 = 0;
+            int sq = 2, hbuf = 0;
+            int tile = job_tile(0), ch = job_half(0);
+            // prologue: the whole first halo half through registers, then the first two weight tiles
+            load_tables(tile, 0);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) resolve_piece(tile, j);
+#pragma unroll
+            for (int j0 = 0; j0 < 7; j0 += 3) {
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) if (j0 + jj < 7) load_piece(0, j0 + jj, jj);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) asm volatile("" : "+v"(Csc[sidx][w]), "+v"(Csh[sidx][w]));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) if (j0 + jj < 7) store_piece(0, j0 + jj, jj);
+            }
+            issue_w(0, 0, 0, ch);
+            issue_w(1, 1, 0, ch);
+            if (ch < 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // start-up barrier: weight tile 0 and the first halo half are in LDS
+            for (int k = 0; k < njobs; ++k) {
+                const int ntile = job_tile(k + 1), nch = job_half(k + 1);
+                for (int ph = 0; ph < nph; ++ph) {
+                    const bool last_ph = ph + 1 == nph;
+                    const int ph_next = last_ph ? 0 : ph + 1;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        // behind the weights of step q - 1 there may still fly: the tables + piece 0 (issued at tap 0), one piece
+                        // (taps 1 .. 6), the residual warm-up (tap 7)
+                        const bool warmed = last_ph && p.residual != nullptr;
+                        if (tap == 0 || (tap == 8 && !warmed)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        else if (tap == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's ds_writes of the previous step
+                        if (tap == 0) asm volatile("" :: "v"(pf0), "v"(pf1));
+                        __builtin_amdgcn_s_barrier();
+                        if (tap < 7) issue_w(sq, tap + 2, ph, ch);
+                        else issue_w(sq, tap - 7, ph_next, last_ph ? nch : ch);
+                        if (tap == 0) load_tables(last_ph ? ntile : tile, ph_next);
+                        if (tap < 7) {
+                            if (last_ph) resolve_piece(ntile, tap);
+                            load_piece(ph_next, tap, tap % 3);
+                        }
+                        if (tap == 7 && warmed) {
+                            const int ml = pw * 64 + lane;
+                            const int m = tile * p.TP + ml;
+                            const unsigned off = (ml < p.TP && m < p.M) ? (unsigned)m * (unsigned)p.out_cstride * ES + (unsigned)nblk * ES : kBadOff;
+                            pf0 = __builtin_amdgcn_raw_buffer_load_b32(rsr, off, 0, 0);
+                            pf1 = __builtin_amdgcn_raw_buffer_load_b32(rsr, off + 128u, 0, 0);
+                        }
+                        if (tap >= 2) {           // piece tap - 2 (and at tap 2 the tables) landed with the top-of-step wait
+                            if (tap == 2) {
+#pragma unroll
+                                for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                                    for (int w = 0; w < 2; ++w) asm volatile("" : "+v"(Csc[sidx][w]), "+v"(Csh[sidx][w]));
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            store_piece(hbuf ^ 1, tap - 2, (tap - 2) % 3);
+                        }
+                        sq = sq == 2 ? 0 : sq + 1;
+                    }
+                    hbuf ^= 1;
+                }
+                tile = ntile; ch = nch;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
         const __amdgpu_buffer_rsrc_t rsr =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
         unsigned pf0 = 0, pf1 = 0;
@@ -1137,7 +1304,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int B, int H, int W, const void* w, int w_rows,
                          int n0, int cout, const float* bias, const float* emb, int emb_stride, const void* residual,
                          void* out, int out_cstride, int min_tiles, int upsample, float* stats, int64_t stats_bytes,
-                         hipStream_t stream) {
+                         const float* gn_scale, const float* gn_shift, int gn_stride, hipStream_t stream) {
     if (c0 % 64 || c1 % 64 || cout % 128) return 0;
     if (W < 4 || W > 254 || H < 2) return 0;
     const int R = 256 / W;
@@ -1164,6 +1331,9 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     p.bias = bias; p.emb = emb; p.emb_stride = emb_stride; p.residual = residual; p.out = out; p.out_cstride = out_cstride;
     p.M = (int)M;
     p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1; p.nbw = (unsigned)nbw; p.nbo = (unsigned)nbo;
+    p.gn_scale = gn_scale; p.gn_shift = gn_shift; p.gn_stride = gn_stride;
+    // fused GroupNorm-apply: plain 3x3 only, and a tile (R rows of the global row list) may touch at most two samples
+    if (gn_scale && (upsample || R > H || !gn_shift || gn_stride < c0 + c1)) return 0;
     p.stats = nullptr; p.stats_groups = out_cstride / 4;
     const int dev = gmk_kernel_choice(3, "GMK_DEV_VARIANT");    // low byte: code variant; 0x100: write per-tile s_memtime stamps
     p.variant = dev & 0xFF;
@@ -1179,11 +1349,16 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
         // not for variant 4 (its vmcnt waits count 4 weight DMAs per step); variant 6 is the A/B switch
         if (ntiles > G && rem > 0 && 2 * rem <= G && p.variant != 4 && p.variant != 6) { p.nfull = (int)ntiles - rem; p.nhalf = 2 * rem; }
     }
+    const bool use16 = p.variant != 32 && (p.variant == 16 || (p.variant == 0 && (p.ktot >= 256 || W >= 32 || W <= 16)));
+    if (gn_scale) {                 // fused GroupNorm-apply + SiLU in the producer waves (statistics tables from gmk_gn_stats)
+        if (use16) conv3x3_halo_ws_kernel<true, 16, true><<<grid, 512, 0, stream>>>(p);
+        else conv3x3_halo_ws_kernel<true, 32, true><<<grid, 512, 0, stream>>>(p);
+        return 2;
+    }
     if (p.variant == 4 && !p.stats) conv3x3_halo_ws_kernel<false><<<grid, 512, 0, stream>>>(p);
     // MFMA shape of the consumers: bit-identical results either way; v_mfma_f32_16x16x32_bf16 measured +2 ... +4 % at K = 2304, at
     // 64- / 32- / 14-pixel rows, and -2 % at 28 x 28 with K = 1152 (tools/halo_ab.py).  GMK_DEV_VARIANT 16 / 32 force one form.
-    else if (!p.stats && p.variant != 32 && (p.variant == 16 || (p.variant == 0 && (p.ktot >= 256 || W >= 32 || W <= 16))))
-        conv3x3_halo_ws_kernel<true, 16><<<grid, 512, 0, stream>>>(p);
+    else if (!p.stats && use16) conv3x3_halo_ws_kernel<true, 16><<<grid, 512, 0, stream>>>(p);
     else if (p.variant != 1 && p.variant != 3 && !p.stats) conv3x3_halo_ws_kernel<true, 32><<<grid, 512, 0, stream>>>(p);     // 1, 3: the 8-compute-wave kernel
     else {
         conv3x3_halo_kernel<<<grid, 512, 0, stream>>>(p);

@@ -862,7 +862,8 @@ extern "C" int gmk_pack_conv_weights_multi(const float* arena, void* packs, int 
 extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1, int B, int hs, int ws, int ho, int wo,
                               int ksize, int mode, const void* w, int w_rows, int n0, int cout, const float* bias,
                               const float* emb, int emb_stride, const void* residual, void* out, int out_cstride,
-                              float* gn_stats, int64_t gn_stats_bytes, int dtype, void* stream) {
+                              float* gn_stats, int64_t gn_stats_bytes, const float* gn_scale, const float* gn_shift, int gn_stride,
+                              int dtype, void* stream) {
     GMK_REQUIRE(src0 && w && out, "gmk_conv_igemm: null pointer");
     GMK_REQUIRE(dtype == GMK_BF16 || dtype == GMK_F32, "gmk_conv_igemm: bad dtype %d", dtype);
     GMK_REQUIRE(ksize == 1 || ksize == 3, "gmk_conv_igemm: ksize %d", ksize);
@@ -888,12 +889,14 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
     if ((force == 0 || force == 3) && dtype == GMK_BF16 && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2 || stuffed) && ksize == 3) {
         const int rc = gmk_conv3x3_halo_try(src0, src1, c0, c1, B, ho, wo, w, w_rows, n0, cout, bias, emb, emb_stride, residual,
                                             out, out_cstride, force == 3 ? 1 : 32, stuffed ? 2 : mode == GMK_CONV_UPSAMPLE2, gn_stats,
-                                            gn_stats_bytes, gmk_stream(stream));
+                                            gn_stats_bytes, gn_scale, gn_shift, gn_stride, gmk_stream(stream));
         if (rc == 1 || rc == 2) {
             gmk_note_kernel(stuffed ? 5 : rc == 2 ? 4 : 3);       // 5: a halo kernel on the zero-stuffed source (transposed conv)
             return gmk_check_launch("gmk_conv_igemm(halo)");
         }
     }
+    GMK_REQUIRE(!gn_scale, "gmk_conv_igemm: the fused GroupNorm-apply needs the 3x3 halo kernel (bf16, plain 3x3, a tile within two samples, "
+                           ">= 32 tiles): ask gmk_conv_gn_fusable first");
     const int es = gmk_esize(dtype);
     const int64_t nb0 = (int64_t)B * hs * ws * c0 * es, nb1 = (int64_t)B * hs * ws * c1 * es;
     const int64_t nbw = (int64_t)ksize * ksize * w_rows * (c0 + c1) * es;
@@ -918,6 +921,21 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
         else conv_igemm_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(p);
     }
     return gmk_check_launch("gmk_conv_igemm");
+}
+
+// 1 if gmk_conv_igemm(ksize 3, GMK_CONV_NORMAL, bf16) of this shape runs on the halo kernel AND can apply a GroupNorm to its source
+extern "C" int gmk_conv_gn_fusable(int B, int H, int W, int c0, int c1, int cout) {
+    if (c0 % 64 || c1 % 64 || cout % 128 || W < 4 || W > 254 || H < 2) return 0;
+    const int R = 256 / W;
+    if (R < 1 || R > H) return 0;
+    const int crossings = H % R == 0 ? 0 : (R - 1 + H - 1) / H;
+    if ((R + 2 + 2 * crossings) * (W + 2) > 448) return 0;
+    const int64_t rows_total = (int64_t)B * H, M = rows_total * W;
+    const int64_t lim = 0xFFFF0000ll;
+    if (M * c0 * 2 >= lim || M * c1 * 2 >= lim || M * cout * 2 >= lim || M >= 0x00FFFFFF) return 0;
+    if ((rows_total + R - 1) / R < 32) return 0;
+    const int force = gmk_kernel_choice(0, "GMK_CONV_KERNEL");
+    return force == 0 || force == 3;
 }
 
 extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B,

@@ -35,7 +35,7 @@ void gmk_note_kernel(int id);             // 1 conv_igemm_kernel, 2 conv_igemm_d
 int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int B, int H, int W, const void* w, int w_rows,
                          int n0, int cout, const float* bias, const float* emb, int emb_stride, const void* residual,
                          void* out, int out_cstride, int min_tiles, int upsample, float* stats, int64_t stats_bytes,
-                         hipStream_t stream);
+                         const float* gn_scale, const float* gn_shift, int gn_stride, hipStream_t stream);
 
 // conv_wgrad_slots.hip: 3x3 stride-1 bf16 weight gradient over padded slots; returns the number of slabs written or 0
 int gmk_wgrad_slots_nsplit(int cout, int ktot);

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
                                                               const float* __restrict__ part, int TP, int ntiles,
                                                               int CS, int B, float drop_p, uint64_t drop_seed,
                                                               uint64_t drop_off, const float* __restrict__ xadd,
-                                                              int xadd_stride) {
+                                                              int xadd_stride, float* __restrict__ tab_sc = nullptr,
+                                                              float* __restrict__ tab_sh = nullptr, int tab_stride = 0) {
     __shared__ float red[kThreads * 4];
     __shared__ float smean[64], srstd[64];
     const int tid = threadIdx.x;
@@ -129,14 +130,22 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
     for (int i = 0; i < 8; ++i) {
         const int cl = vec * 8 + i, g = cl / cpg, c = c0 + cl;
         sc[i] = srstd[g] * gamma[c];
-        sh[i] = beta[c] - smean[g] * sc[i];
+        sh[i] = fmaf(ea[i], sc[i], beta[c] - smean[g] * sc[i]);      // the addend folded into the shift: (x + ea - mean) * sc + beta
     }
+    if (tab_sc && pl == 0) {        // y = silu(x * sc + sh) for whoever applies the normalisation itself (gmk_gn_stats)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            tab_sc[(size_t)b * tab_stride + c0 + vec * 8 + i] = sc[i];
+            tab_sh[(size_t)b * tab_stride + c0 + vec * 8 + i] = sh[i];
+        }
+    }
+    if (!y) return;
 #pragma unroll 4
     for (int p = pl; p < HW; p += planes) {
         float v[8];
         load8(xb + (size_t)p * C, v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = siluf_(fmaf(v[i] + ea[i], sc[i], sh[i]));
+        for (int i = 0; i < 8; ++i) v[i] = siluf_(fmaf(v[i], sc[i], sh[i]));
         if (drop_p > 0.f) drop8(v, ((size_t)b * HW + p) * C + c0 + vec * 8, drop_p, drop_seed, drop_off);
         store8(yb + (size_t)p * C, v);
     }
@@ -303,7 +312,8 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
                                                              float* __restrict__ mean, float* __restrict__ rstd, int HW, int C,
                                                              int G, float eps, int B, int planes, float drop_p,
                                                              uint64_t drop_seed, uint64_t drop_off, const float* __restrict__ xadd,
-                                                             int xadd_stride) {
+                                                             int xadd_stride, float* __restrict__ tab_sc = nullptr,
+                                                             float* __restrict__ tab_sh = nullptr, int tab_stride = 0) {
     __shared__ float red[8][NVEC][4];       // [wave][vec][s0, q0, s1, q1]
     __shared__ float smean[16], srstd[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -436,6 +446,14 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
         sc[i] = srstd[g] * gamma[c];
         sh[i] = beta[c] - (smean[g] - ea[i]) * sc[i];          // (x + ea - mean) * sc + beta
     }
+    if (tab_sc && pl == 0) {        // y = silu(x * sc + sh) for whoever applies the normalisation itself (gmk_gn_stats)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            tab_sc[(size_t)b * tab_stride + c0 + vec * 8 + i] = sc[i];
+            tab_sh[(size_t)b * tab_stride + c0 + vec * 8 + i] = sh[i];
+        }
+    }
+    if (!y) return;
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
         if (!ok[i]) continue;
@@ -445,7 +463,11 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = siluf_(fmaf(v[k], sc[k], sh[k]));
         if (drop_p > 0.f) drop8(v, base + (size_t)p * C, drop_p, drop_seed, drop_off);
+#ifdef GMK_GN_NOSTORE          // timing-only build: what a statistics-only GroupNorm launch would cost (upper bound of fusing the apply)
+        asm volatile("" :: "v"(v[0]), "v"(v[7]));
+#else
         store8(y + base + (size_t)p * C, v);
+#endif
     }
 #if defined(GMK_GN_XCHECK) && GMK_GN_XCHECK == 3
     {   // all diagnostics at the very end, so that the kernel's timing up to its stores is the shipped one
@@ -1051,6 +1073,41 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
     else
         GMK_REQUIRE(false, "gmk_gn_silu_fwd: bad dtype %d", dtype);
     return gmk_check_launch("gmk_gn_silu_fwd");
+}
+
+// Statistics-only GroupNorm: one read of x, mean / rstd and the per-(sample, channel) affine tables of the normalisation,
+// y = silu(x * scale + shift) with scale = rstd * gamma, shift = beta + (xadd - mean) * scale.  The convolution that consumes the
+// normalised tensor applies them in its producer waves (gmk_conv_igemm gn_scale / gn_shift), so the normalised tensor is never
+// written to or read back from HBM (reference sites simple_unet.py:161-163,169-172).
+extern "C" int gmk_gn_stats(const void* x, const float* gamma, const float* beta, float* mean, float* rstd, float* tab_scale,
+                            float* tab_shift, int tab_stride, int B, int HW, int C, int groups, float eps, const float* xadd,
+                            int xadd_stride, int dtype, void* stream) {
+    GMK_REQUIRE(x && gamma && beta && mean && rstd && tab_scale && tab_shift, "gmk_gn_stats: null pointer");
+    GMK_REQUIRE(!xadd || xadd_stride >= C, "gmk_gn_stats: xadd_stride %d < C %d", xadd_stride, C);
+    GMK_REQUIRE(tab_stride >= C, "gmk_gn_stats: tab_stride %d < C %d", tab_stride, C);
+    GMK_REQUIRE(B > 0 && HW > 0 && gn_shape_ok(C, groups), "gmk_gn_stats: unsupported shape B=%d HW=%d C=%d G=%d", B, HW, C, groups);
+    GMK_REQUIRE(dtype == GMK_BF16, "gmk_gn_stats: bf16 only (the fused apply lives in the bf16 halo convolution)");
+    if (C % 64 == 0 && 32 % (C / groups) == 0 && gn_reg_iter(HW, 8) > 0) {
+        const int nvec = 8;
+        const int it = gn_reg_iter(HW, nvec), planes = (HW + it - 1) / it, threads = (planes * nvec + 63) / 64 * 64;
+        const int nblk = B * (C / (nvec * 8));
+#define GMK_GN_STATS_REG(IT)                                                                                                          \
+    gn_silu_fwd_reg_kernel<IT, 8><<<nblk, threads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)nullptr, gamma, beta, mean, rstd, \
+                                                                            HW, C, groups, eps, B, planes, 0.f, 0, 0, xadd, xadd_stride,  \
+                                                                            tab_scale, tab_shift, tab_stride)
+        if (it == 1) GMK_GN_STATS_REG(1);
+        else if (it == 2) GMK_GN_STATS_REG(2);
+        else if (it == 4) GMK_GN_STATS_REG(4);
+        else if (it == 8) GMK_GN_STATS_REG(8);
+        else GMK_GN_STATS_REG(16);
+#undef GMK_GN_STATS_REG
+    } else {
+        const int CS = gn_slab_channels(0, C, groups, HW, 2, false);
+        gn_silu_fwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
+            (const bf16_t*)x, (bf16_t*)nullptr, gamma, beta, mean, rstd, HW, C, groups, eps, nullptr, 0, 0, CS, B, 0.f, 0, 0, xadd,
+            xadd_stride, tab_scale, tab_shift, tab_stride);
+    }
+    return gmk_check_launch("gmk_gn_stats");
 }
 
 extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,

@@ -127,6 +127,12 @@ def pack_conv_weights_multi(arena, packs, table):
 # 27.19 ms/step), and with it a sample's result depends (in the last bits) on which tile neighbours it had.
 GN_STATS = False
 SIDE_DUMMY = os.environ.get("GMK_SIDE_DUMMY", "0") == "1"      # experiment switch, see simple_unet._on_side
+GN_FUSE = os.environ.get("GMK_GN_FUSE", "1") != "0"            # inference: GroupNorm-apply + SiLU inside the consuming convolution (simple_unet._res_fwd)
+# ... where it pays (tools/fuse_ab.py, B x HW = 1 M pixels): at 64 x 64 the statistics-only launch + fused convolution take 1,497 us against
+# 1,658 us for GroupNorm + convolution (-10 %); at 32 x 32 / 28 x 28 the producer waves' transform (224 VALU issue slots per K-step
+# against the ~190 the consumer's MFMA stream leaves free on the shared SIMD) costs what the normalised tensor's round trip saved
+# (758 vs 747 us, 351 vs 341 us), at 16 x 16 more.  GMK_GN_FUSE_MIN_HW overrides the threshold.
+GN_FUSE_MIN_HW = int(os.environ.get("GMK_GN_FUSE_MIN_HW", "2048"))
 FWD_SIDE = os.environ.get("GMK_FWD_SIDE", "0") == "1"          # forward 1x1 skip convolutions on the side stream (simple_unet._res_fwd)
 WGRAD_STREAM = os.environ.get("GMK_WGRAD_STREAM", "1") != "0"    # weight gradients on a side stream beside the data-gradient chain (simple_unet._wgrad)
 
@@ -156,6 +162,31 @@ def gn_silu_fwd(x, gamma, beta, groups, eps=1e-5, dropout=None, xadd=None):
     check(lib.gmk_gn_silu_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), B, H * W, C, groups, eps, _p(part), tp, nt,
                               float(dp), int(dseed), int(doff), _p(xadd), xs, _DT[x.dtype], _s()), "gn_silu_fwd")
     return y, mean, rstd
+
+
+def gn_stats(x, gamma, beta, groups, tab_scale, tab_shift, eps=1e-5, xadd=None):
+    """Statistics-only GroupNorm of x NHWC [B,H,W,C]: fills columns [0, C) of the fp32 table views tab_scale / tab_shift
+    ([B, C] slices of a [B, Ctot] table: unit column stride, row stride Ctot) with the affine form of the normalisation,
+    y = silu(x * scale + shift), for a convolution that applies it itself (conv_igemm gn=).  -> (mean, rstd)"""
+    _chk(x, torch.bfloat16, "x"); _f32(gamma, "gamma"); _f32(beta, "beta")
+    B, H, W, C = x.shape
+    for t in (tab_scale, tab_shift):
+        assert t.dtype == torch.float32 and t.shape == (B, C) and t.stride(1) == 1 and t.is_cuda and t.data_ptr() % 16 == 0
+    assert tab_scale.stride(0) == tab_shift.stride(0)
+    mean = torch.empty((B, groups), device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    xs = _xadd_stride(xadd, B, C)
+    check(lib.gmk_gn_stats(_p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(tab_scale), _p(tab_shift), tab_scale.stride(0), B, H * W, C,
+                           groups, eps, _p(xadd), xs, _DT[x.dtype], _s()), "gn_stats")
+    return mean, rstd
+
+
+def conv_gn_fusable(srcs, cout=128):
+    """Can conv_igemm(srcs, ..., 3, NORMAL, gn=...) apply the GroupNorm of its (bf16) sources itself?"""
+    s0 = srcs[0]
+    c1 = srcs[1].shape[3] if len(srcs) > 1 else 0
+    B, H, W, c0 = s0.shape
+    return s0.dtype == torch.bfloat16 and H * W >= GN_FUSE_MIN_HW and bool(lib.gmk_conv_gn_fusable(B, H, W, c0, c1, cout))
 
 
 def gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=None, dadd2=None, dxsum=None, dropout=None, xadd=None):
@@ -245,7 +276,7 @@ def out_size(mode, hs, ws):
     raise ValueError(mode)
 
 
-def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, emb=None, residual=None, gn_stats=False):
+def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, emb=None, residual=None, gn_stats=False, gn=None):
     """srcs: list of 1-2 NHWC tensors (same B,H,W); w: packed weights [taps][w_rows][sum C]; -> out NHWC [B,ho,wo,cout]."""
     s0 = _chk(srcs[0], name="src0")
     s1 = _chk(srcs[1], s0.dtype, "src1") if len(srcs) > 1 else None
@@ -267,6 +298,13 @@ def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, 
         _f32(bias, "bias"); assert bias.numel() == cout
     if residual is not None:
         _chk(residual, s0.dtype, "residual"); assert residual.shape == out.shape
+    gsc = gsh = None
+    gstride = 0
+    if gn is not None:          # (scale, shift) fp32 [B, c0 + c1] tables of gn_stats: the sources are raw, the kernel normalises them
+        gsc, gsh = gn
+        for t in (gsc, gsh):
+            _f32(t, "gn table"); assert t.shape == (B, c0 + c1)
+        gstride = c0 + c1
     mpix = B * hs * ws if mode == TRANSPOSED2 else B * ho * wo     # algorithmic work: that of the stride-2 conv
     part, tp, nt = None, 0, 0
     if gn_stats and GN_STATS and ksize == 3 and mode in (NORMAL, UPSAMPLE2) and s0.dtype == torch.bfloat16 and 4 <= wo <= 254:
@@ -276,7 +314,7 @@ def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, 
     with _Timed("conv_igemm", 2.0 * mpix * cout * (c0 + c1) * ksize * ksize):
         check(lib.gmk_conv_igemm(_p(s0), _p(s1), c0, c1, B, hs, ws, ho, wo, ksize, mode, _p(w), w_rows, n0, cout,
                                  _p(bias), _p(emb), emb_stride, _p(residual), _p(out), cout, _p(part),
-                                 part.numel() * 4 if part is not None else 0, _DT[s0.dtype], _s()),
+                                 part.numel() * 4 if part is not None else 0, _p(gsc), _p(gsh), gstride, _DT[s0.dtype], _s()),
               "conv_igemm")
     if part is not None and lib.gmk_last_kernel() == 3 and ho * wo >= 32:      # only the 8-compute-wave halo kernel emits statistics
         out._gn_stats = (part, tp, nt)     # consumed by gn_silu_fwd(out, ...)

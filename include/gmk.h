@@ -112,7 +112,18 @@ int gmk_sumpool2x2(const void* x, void* y, int B, int H, int W, int C, int dtype
 int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1, int B, int hs, int ws, int ho, int wo,
                    int ksize, int mode, const void* w, int w_rows, int n0, int cout, const float* bias,
                    const float* emb, int emb_stride, const void* residual, void* out, int out_cstride,
-                   float* gn_stats, int64_t gn_stats_bytes, int dtype, void* stream);
+                   float* gn_stats, int64_t gn_stats_bytes, const float* gn_scale, const float* gn_shift, int gn_stride,
+                   int dtype, void* stream);
+/* gn_scale / gn_shift (optional, fp32 [B][gn_stride], gn_stride >= c0 + c1): the sources are RAW tensors and the convolution
+ * applies nn.GroupNorm + nn.SiLU to them on the way into LDS, y = silu(x * gn_scale[b][k] + gn_shift[b][k]) with the tables of
+ * gmk_gn_stats (simple_unet.py:161-163,169-172: the normalised tensor is never materialised).  Only where
+ * gmk_conv_gn_fusable(...) returns 1; otherwise the call fails. */
+int gmk_conv_gn_fusable(int B, int H, int W, int c0, int c1, int cout);
+/* statistics-only GroupNorm for the above: mean / rstd [B][groups] and the affine tables (columns [0, C) of rows of tab_stride
+ * floats: a concatenated input passes the same table with a column offset); xadd as in gmk_gn_silu_fwd */
+int gmk_gn_stats(const void* x, const float* gamma, const float* beta, float* mean, float* rstd, float* tab_scale,
+                 float* tab_shift, int tab_stride, int B, int HW, int C, int groups, float eps, const float* xadd,
+                 int xadd_stride, int dtype, void* stream);
 /* weight gradient: dw[n][k][tap] (reference layout `[Cout][Cin][k][k]`, fp32, overwritten or accumulated) =
  *   sum_pixels dy[b][oy][ox][n0_dy + n] * srcK[b][sy][sx][k],  same gather as the forward of `mode`.
  * workspace: gmk_conv_wgrad_workspace_bytes(B*ho*wo, ksize*ksize, cout, c0+c1) bytes. */

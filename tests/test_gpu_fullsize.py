@@ -103,3 +103,22 @@ def test_forward_is_bit_reproducible_with_the_skip_convs_on_the_side_stream(net)
     finally:
         ops.FWD_SIDE = keep
     assert all(torch.equal(outs[0], o) for o in outs[1:]) and torch.equal(outs[0], plain)
+
+
+def test_fused_groupnorm_forward_equals_materialised_forward(net):
+    """Inference forward with GroupNorm-apply + SiLU inside the convolutions (ops.GN_FUSE, the default) against the forward that
+    materialises the normalised tensors (the training path's forward): the same bits, at the full batch."""
+    from generative_models_amd import ops
+    x, y, u, _ = data(5)
+    l = u * 24 - 12
+    keep, keep_min = ops.GN_FUSE, ops.GN_FUSE_MIN_HW
+    try:
+        ops.GN_FUSE, ops.GN_FUSE_MIN_HW = True, 0          # fuse wherever the kernel can (the 28 x 28 level here), not only where it pays
+        fused = net.forward_hip(x, l, y, None)
+        ops.GN_FUSE = False
+        plain = net.forward_hip(x, l, y, None)
+        ctx = {}
+        train_fwd = net.forward_hip(x, l, y, None, ctx=ctx)
+    finally:
+        ops.GN_FUSE, ops.GN_FUSE_MIN_HW = keep, keep_min
+    assert torch.equal(fused, plain) and torch.equal(fused, train_fwd)

@@ -531,3 +531,47 @@ def test_fused_attention_forward(ops, N, fp8):
     assert l2 < (8e-2 if fp8 else 5e-3), l2
     assert err(P, Pref) < (1e-1 if fp8 else 1e-2), err(P, Pref)
     assert float((P.float().sum(-1) - 1).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("B,S,two,res", [(40, 28, False, True), (40, 28, True, False), (33, 32, True, True), (64, 16, False, True), (9, 64, False, False)])
+def test_conv_with_fused_groupnorm_is_bit_identical(ops, B, S, two, res):
+    """gmk_gn_stats + gmk_conv_igemm(gn_scale, gn_shift): GroupNorm-apply + SiLU in the convolution's producer waves instead of a
+    materialised normalised tensor (simple_unet.py:161-163,169-172).  Same fp32 arithmetic, same bf16 rounding -> the same bits as
+    gmk_gn_silu_fwd followed by the plain convolution; statistics equal too.  Shapes: tiles that straddle two samples (28, 32),
+    tile = sample (16), 64-pixel rows, one and two sources, with the per-(sample, channel) addend of conv2's GroupNorm."""
+    g = torch.Generator().manual_seed(B + S)
+    C = 128
+    srcs = [(torch.randn((B, S, S, C), generator=g) * 1.3 + 0.2).bfloat16().cuda() for _ in range(2 if two else 1)]
+    ctot = C * len(srcs)
+    gamma = (1 + 0.2 * torch.randn(ctot, generator=g)).cuda(); beta = (0.3 * torch.randn(ctot, generator=g)).cuda()
+    xadd = (0.5 * torch.randn((B, C), generator=g)).cuda() if not two else None
+    w = torch.randn((128, ctot, 3, 3), generator=g).cuda() / (ctot * 9) ** 0.5
+    wf = torch.empty(w.numel(), device="cuda", dtype=torch.bfloat16); ops.pack_conv_weight(w, wf, None)
+    bias = torch.randn(128, generator=g).cuda()
+    resid = torch.randn((B, S, S, 128), generator=g).bfloat16().cuda() if res else None
+    keep_min, ops.GN_FUSE_MIN_HW = ops.GN_FUSE_MIN_HW, 0          # the policy threshold (where fusing pays) is not what is tested here
+    try:
+        assert ops.conv_gn_fusable(srcs)
+        # 14 x 14: a tile of 18 rows can touch three samples -> not fusable
+        assert not ops.conv_gn_fusable([torch.zeros((40, 14, 14, C), device="cuda", dtype=torch.bfloat16)])
+    finally:
+        ops.GN_FUSE_MIN_HW = keep_min
+    gpc = 32 // len(srcs)
+    a, stats = [], []
+    for i, s in enumerate(srcs):
+        y, m, r = ops.gn_silu_fwd(s, gamma[i * C:(i + 1) * C], beta[i * C:(i + 1) * C], gpc, xadd=xadd)
+        a.append(y); stats.append((m, r))
+    ref = ops.conv_igemm(a, wf, 128, 3, ops.NORMAL, (S, S), bias=bias, residual=resid)
+    tsc = torch.empty((B, ctot), device="cuda"); tsh = torch.empty_like(tsc)
+    for i, s in enumerate(srcs):
+        m, r = ops.gn_stats(s, gamma[i * C:(i + 1) * C], beta[i * C:(i + 1) * C], gpc, tsc[:, i * C:(i + 1) * C], tsh[:, i * C:(i + 1) * C], xadd=xadd)
+        assert torch.equal(m, stats[i][0]) and torch.equal(r, stats[i][1])
+    out = ops.conv_igemm(srcs, wf, 128, 3, ops.NORMAL, (S, S), bias=bias, residual=resid, gn=(tsc, tsh))
+    assert torch.equal(out, ref), float((out.float() - ref.float()).abs().max())
+    # and against fp32 torch
+    x = torch.cat([F.silu(F.group_norm(s.float().permute(0, 3, 1, 2) + (xadd[:, :, None, None] if xadd is not None else 0), gpc,
+                                       gamma[i * C:(i + 1) * C], beta[i * C:(i + 1) * C])) for i, s in enumerate(srcs)], 1)
+    t = F.conv2d(x, w.bfloat16().float(), bias, padding=1).permute(0, 2, 3, 1)
+    if resid is not None:
+        t = t + resid.float()
+    assert float((out.float() - t).abs().max() / t.abs().max()) < 1e-2
