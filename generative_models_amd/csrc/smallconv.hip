@@ -101,6 +101,103 @@ __global__ __launch_bounds__(256) void expand3x3_kernel(const float* __restrict_
     }
 }
 
+
+// ---- the same "expand" convolution on the matrix cores, exact fp32 --------------------------------------------------------
+// y^T[c][px] = bias[c] + sum_k W^T[c][k] * patch^T[k][px],  k = s * 9 + t  (K = 9 x image channels = 9 ... 36) as a chain of
+// v_mfma_f32_32x32x2_f32 (exact fp32 fma chain in k order: the same sums in the same order as the kernel above, bit for bit).  Why:
+// the VALU kernel issues 27 image loads and 108 FMAs per 4-channel vector of a 3-channel image and ran at 0.9 TB/s of its only HBM
+// traffic, the 128-channel tensor it writes (1.18 ms at 64 x 64, B = 1024).  Here a wave owns 32 pixels x all 128 channels: lane
+// (pixel r, half h) loads ONE image value per k pair (14 loads per 32 pixels for 3 channels instead of 27 per 2), the weights and
+// the bias sit in registers as MFMA operands for the whole launch, and the D[channel][pixel] orientation lets every lane store 16
+// contiguous bytes after one v_permlane32_swap per dword (bf16) or directly (fp32).
+template <typename T, int CSN, bool FLIP>
+__global__ __launch_bounds__(256) void expand3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, T* __restrict__ out, int H, int W, int C,
+                                                            unsigned npix, unsigned nblocks) {
+    constexpr int K = 9 * CSN, NK = (K + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int HW = H * W;
+    // per-lane k of every step: image plane offset and (dy, dx); k >= K contributes nothing
+    int koff[NK], kdy[NK], kdx[NK];
+    float wa[4][NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const int k = 2 * ks + h;
+        const bool kin = k < K;
+        const int s_ = kin ? k / 9 : 0, t = kin ? k % 9 : 4;
+        const int dy = FLIP ? 1 - t / 3 : t / 3 - 1, dx = FLIP ? 1 - t % 3 : t % 3 - 1;
+        kdy[ks] = kin ? dy : 2 * H;                     // out-of-range row: the value is dropped
+        kdx[ks] = dx;
+        koff[ks] = s_ * HW + dy * W + dx;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int c = cb * 32 + r;
+            wa[cb][ks] = kin ? w[FLIP ? (s_ * C + c) * 9 + t : (c * CSN + s_) * 9 + t] : 0.f;
+        }
+    }
+    f32x16 binit[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) binit[cb][e] = bias ? bias[cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
+
+    for (unsigned blk = blockIdx.x * 4 + wave; blk < nblocks; blk += gridDim.x * 4) {
+        const unsigned g = blk * 32 + r;
+        const bool live = g < npix;
+        const unsigned gg = live ? g : 0;
+        const int b = (int)(gg / (unsigned)HW), pp = (int)(gg - (unsigned)b * (unsigned)HW);
+        const int y = pp / W, x = pp - y * W;
+        const float* ip = in + (size_t)b * CSN * HW + pp;
+        float pv[NK];
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const bool ok = live && (unsigned)(y + kdy[ks]) < (unsigned)H && (unsigned)(x + kdx[ks]) < (unsigned)W;
+            pv[ks] = ok ? ip[koff[ks]] : 0.f;
+        }
+        f32x16 acc[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            acc[cb] = binit[cb];
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cb][ks], pv[ks], acc[cb], 0, 0, 0);
+        }
+        // lane (pixel r, half h) holds channels 32 cb + 8 q4 + 4 h + (0..3), q4 = 0..3
+        T* orow = out + (size_t)g * C;
+        if constexpr (sizeof(T) == 4) {
+            if (live) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 v = {acc[cb][4 * q4], acc[cb][4 * q4 + 1], acc[cb][4 * q4 + 2], acc[cb][4 * q4 + 3]};
+                        *reinterpret_cast<f32x4*>((float*)orow + cb * 32 + 8 * q4 + 4 * h) = v;
+                    }
+            }
+        } else {
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2s;
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                unsigned pk[4][2];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const bf16x4 t = {(bf16_t)acc[cb][4 * q4], (bf16_t)acc[cb][4 * q4 + 1], (bf16_t)acc[cb][4 * q4 + 2], (bf16_t)acc[cb][4 * q4 + 3]};
+                    const auto u = __builtin_bit_cast(u32x2s, t);
+                    pk[q4][0] = u[0]; pk[q4][1] = u[1];
+                }
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4 += 2) {       // after the swap: lanes < 32 hold channels 8 q4 .. 8 q4 + 7, lanes >= 32 the next 8
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[q4][0], pk[q4 + 1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q4][1], pk[q4 + 1][1], false, false);
+                    const u32x4s o = {s0[0], s1[0], s0[1], s1[1]};
+                    if (live) *reinterpret_cast<u32x4s*>((bf16_t*)orow + cb * 32 + 8 * (q4 + h)) = o;
+                }
+            }
+        }
+    }
+}
+
 // ---- weight gradients of both: the C-channel tensor is read ONCE (all image channels accumulate together), the image
 // through L1 -----------------------------------------------------------------------------------------------------------
 //   stem (FLIP = false): dw[c][s][t] = sum_{b,p} x[b,s,p + off(t)]    * dy[b,p,c]
@@ -273,6 +370,18 @@ static void launch_expand(const float* in, const float* w, const float* bias, T*
     const int64_t npix = (int64_t)B * H * W;
     const int ppb = small_ppb(npix), nb = small_blocks(npix);
     const float inv_w = 1.0f / (float)W;
+    // the matrix-core form (exact fp32, bit-identical sums) for 128-channel nets; GMK_DEV_VARIANT 41 keeps the VALU kernel (A/B)
+    if (C == 128 && gmk_kernel_choice(3, "GMK_DEV_VARIANT") != 41) {
+        const unsigned nblocks = (unsigned)((npix + 31) / 32);
+        const unsigned grid = nblocks / 4 + 1 < 2048u ? nblocks / 4 + 1 : 2048u;
+#define GMK_EXPAND_M(CSN) expand3x3_mfma_kernel<T, CSN, FLIP><<<grid, 256, 0, stream>>>(in, w, bias, out, H, W, C, (unsigned)npix, nblocks)
+        if (cs == 1) GMK_EXPAND_M(1);
+        else if (cs == 2) GMK_EXPAND_M(2);
+        else if (cs == 3) GMK_EXPAND_M(3);
+        else GMK_EXPAND_M(4);
+#undef GMK_EXPAND_M
+        return;
+    }
 #define GMK_EXPAND(CSN, VW) expand3x3_kernel<T, CSN, VW, FLIP><<<nb, 256, 0, stream>>>(in, w, bias, out, H, W, C, inv_w, (unsigned)npix, ppb)
     if (cs == 1) GMK_EXPAND(1, 8);
     else if (cs == 2) GMK_EXPAND(2, 8);

@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round-2 judged artefacts.  usage: tools/profile_r02.sh [tag]   (writes gpurun_out/<tag>/..., copies the summaries into profiles/)
+#   r02_<cfg>_train_serial_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the train steps with non-overlapping launches
+#                                             (GMK_WGRAD_STREAM=0): the averages that compare with the bench line's HIP events
+#   r02_bench_kernel_stats.csv                the default `python bench.py` command (all configs, samplers, overlapping streams)
+#   r02_traffic.json                          HBM bytes per launch of every kernel of the headline config, separate --pmc passes
+TAG=${1:-r02}
+OUT=/tmp/gmk_$TAG                 # raw traces are hundreds of MB: they stay on the box; only the summaries travel
+KEEP=gpurun_out/$TAG
+REPO=$(pwd)
+mkdir -p $OUT $KEEP profiles
+cd /tmp && export TMPDIR=/tmp
+cd $REPO
+for cfg in cfg2 cfg1 cfg3; do
+  GMK_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial_$cfg -o serial -- python bench.py --config $cfg --others 0 --sampler_steps 0 --no_profile --no_cpu --steps 10 --warmup 3 > $OUT/serial_$cfg.log 2>&1 || exit 1
+  cp $(find $OUT/serial_$cfg -name "*kernel_stats.csv" | head -1) profiles/r02_${cfg}_train_serial_kernel_stats.csv
+  echo "serial $cfg done"
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python bench.py --no_cpu --sampler_steps 100 > $OUT/prof_bench.log 2>&1 || exit 1
+cp $(find $OUT/bench -name "*kernel_stats.csv" | head -1) profiles/r02_bench_kernel_stats.csv
+echo "bench stats done"
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc/g$i -o pmc -- python bench.py --config cfg2 --others 0 --steps 3 --warmup 1 --sampler_steps 2 --sampler_steps_other 2 --no_cpu --no_profile > $OUT/pmc_g$i.log 2>&1 || exit 1
+  i=$((i+1))
+done
+python tools/traffic_parse.py $OUT/pmc > $OUT/pmc/kernels.json || exit 1
+python - <<PY
+import json, subprocess
+k = json.load(open("$OUT/pmc/kernels.json"))
+out = {"cfg2": {"kernels": k, "provenance": "rocprofv3 --pmc, three separate passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) of "
+                "'bench.py --config cfg2 --others 0 --steps 3 --warmup 1 --sampler_steps 2' (tools/profile_r02.sh); FETCH_SIZE doubled (gfx950, 16-B/lane "
+                "streaming reads: MI355X_MICROARCH.md HBM); bytes averaged over the kernel's launches of 4 train steps + 6 sampler forwards"}}
+json.dump(out, open("profiles/r02_traffic.json", "w"), indent=1)
+PY
+echo "traffic done"
+python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+cp $OUT/bench.json profiles/r02_bench.json
+cp profiles/r02_* $KEEP/
+cp $OUT/*.log $OUT/bench.err $KEEP/ 2>/dev/null
+tail -c 300 $OUT/bench.json
