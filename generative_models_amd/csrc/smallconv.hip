@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void expand3x3_kernel(const float* __restrict_
 
 // ---- the same "expand" convolution on the matrix cores, exact fp32 --------------------------------------------------------
 // y^T[c][px] = bias[c] + sum_k W^T[c][k] * patch^T[k][px],  k = s * 9 + t  (K = 9 x image channels = 9 ... 36) as a chain of
-// v_mfma_f32_32x32x2_f32 (exact fp32 fma chain in k order: the same sums in the same order as the kernel above, bit for bit).  Why:
+// v_mfma_f32_32x32x2_f32 (an exact fp32 fma chain in k order; the bias is one more k entry, added last).  Why:
 // the VALU kernel issues 27 image loads and 108 FMAs per 4-channel vector of a 3-channel image and ran at 0.9 TB/s of its only HBM
 // traffic, the 128-channel tensor it writes (1.18 ms at 64 x 64, B = 1024).  Here a wave owns 32 pixels x all 128 channels: lane
 // (pixel r, half h) loads ONE image value per k pair (14 loads per 32 pixels for 3 channels instead of 27 per 2), the weights and
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void expand3x3_kernel(const float* __restrict_
 template <typename T, int CSN, bool FLIP>
 __global__ __launch_bounds__(256) void expand3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                             const float* __restrict__ bias, T* __restrict__ out, int H, int W, int C,
-                                                            unsigned npix, unsigned nblocks) {
-    constexpr int K = 9 * CSN, NK = (K + 1) / 2;
+                                                            unsigned npix, unsigned nblocks, unsigned in_bytes, unsigned out_bytes) {
+    constexpr int K = 9 * CSN, NK = (K + (FLIP ? 0 : 1) + 1) / 2;     // the stem's bias rides as one more k entry: weight bias[c], patch 1
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int HW = H * W;
@@ -133,50 +133,58 @@ __global__ __launch_bounds__(256) void expand3x3_mfma_kernel(const float* __rest
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             const int c = cb * 32 + r;
-            wa[cb][ks] = kin ? w[FLIP ? (s_ * C + c) * 9 + t : (c * CSN + s_) * 9 + t] : 0.f;
+            wa[cb][ks] = kin ? w[FLIP ? (s_ * C + c) * 9 + t : (c * CSN + s_) * 9 + t] : (!FLIP && k == K && bias) ? bias[c] : 0.f;
         }
     }
-    f32x16 binit[4];
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) binit[cb][e] = bias ? bias[cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
-
-    for (unsigned blk = blockIdx.x * 4 + wave; blk < nblocks; blk += gridDim.x * 4) {
+    constexpr unsigned kBadOff = 0xFFFFFF00u;
+    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)out_bytes, 0x00020000);
+    // the image values of block `blk` for this lane; issued one block ahead so the gathers fly under the previous block's MFMAs
+    auto gather = [&](unsigned blk, float (&pv)[NK]) {
         const unsigned g = blk * 32 + r;
-        const bool live = g < npix;
+        const bool live = blk < nblocks && g < npix;
         const unsigned gg = live ? g : 0;
         const int b = (int)(gg / (unsigned)HW), pp = (int)(gg - (unsigned)b * (unsigned)HW);
         const int y = pp / W, x = pp - y * W;
-        const float* ip = in + (size_t)b * CSN * HW + pp;
+        const int base = b * CSN * HW + pp;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {     // out-of-range offsets read as 0 (buffer semantics): no branches around the loads
+            const int ok = (int)live & (int)((unsigned)(y + kdy[ks]) < (unsigned)H) & (int)((unsigned)(x + kdx[ks]) < (unsigned)W);
+            pv[ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsi, ok ? (unsigned)(base + koff[ks]) * 4u : kBadOff, 0, 0));
+            if (!FLIP && (2 * ks == K || 2 * ks + 1 == K) && 2 * ks + h == K) pv[ks] = 1.f;
+        }
+    };
+    float pn[NK];
+    gather(blockIdx.x * 4 + wave, pn);
+    for (unsigned blk = blockIdx.x * 4 + wave; blk < nblocks; blk += gridDim.x * 4) {
+        const unsigned g = blk * 32 + r;
+        const bool live = g < npix;
         float pv[NK];
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            const bool ok = live && (unsigned)(y + kdy[ks]) < (unsigned)H && (unsigned)(x + kdx[ks]) < (unsigned)W;
-            pv[ks] = ok ? ip[koff[ks]] : 0.f;
-        }
+        for (int ks = 0; ks < NK; ++ks) pv[ks] = pn[ks];
+        gather(blk + gridDim.x * 4, pn);
         f32x16 acc[4];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
-            acc[cb] = binit[cb];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cb][ks], pv[ks], acc[cb], 0, 0, 0);
         }
         // lane (pixel r, half h) holds channels 32 cb + 8 q4 + 4 h + (0..3), q4 = 0..3
-        T* orow = out + (size_t)g * C;
+        const unsigned row_b = g * (unsigned)C * (unsigned)sizeof(T);
+        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2s;
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
         if constexpr (sizeof(T) == 4) {
-            if (live) {
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
+            for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const f32x4 v = {acc[cb][4 * q4], acc[cb][4 * q4 + 1], acc[cb][4 * q4 + 2], acc[cb][4 * q4 + 3]};
-                        *reinterpret_cast<f32x4*>((float*)orow + cb * 32 + 8 * q4 + 4 * h) = v;
-                    }
-            }
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 v = {acc[cb][4 * q4], acc[cb][4 * q4 + 1], acc[cb][4 * q4 + 2], acc[cb][4 * q4 + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rso,
+                                                           live ? row_b + (unsigned)(cb * 32 + 8 * q4 + 4 * h) * 4u : kBadOff, 0, 0);
+                }
         } else {
-            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2s;
-            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 unsigned pk[4][2];
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256) void expand3x3_mfma_kernel(const float* __rest
                     const auto s0 = __builtin_amdgcn_permlane32_swap(pk[q4][0], pk[q4 + 1][0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q4][1], pk[q4 + 1][1], false, false);
                     const u32x4s o = {s0[0], s1[0], s0[1], s1[1]};
-                    if (live) *reinterpret_cast<u32x4s*>((bf16_t*)orow + cb * 32 + 8 * (q4 + h)) = o;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rso, live ? row_b + (unsigned)(cb * 32 + 8 * (q4 + h)) * 2u : kBadOff, 0, 0);
                 }
             }
         }
@@ -371,10 +379,13 @@ static void launch_expand(const float* in, const float* w, const float* bias, T*
     const int ppb = small_ppb(npix), nb = small_blocks(npix);
     const float inv_w = 1.0f / (float)W;
     // the matrix-core form (exact fp32, bit-identical sums) for 128-channel nets; GMK_DEV_VARIANT 41 keeps the VALU kernel (A/B)
-    if (C == 128 && gmk_kernel_choice(3, "GMK_DEV_VARIANT") != 41) {
+    const size_t in_bytes = (size_t)npix * cs * 4, out_bytes = (size_t)npix * C * sizeof(T);
+    if (C == 128 && out_bytes < 0xFFFFFF00ull && gmk_kernel_choice(3, "GMK_DEV_VARIANT") != 41) {
         const unsigned nblocks = (unsigned)((npix + 31) / 32);
-        const unsigned grid = nblocks / 4 + 1 < 2048u ? nblocks / 4 + 1 : 2048u;
-#define GMK_EXPAND_M(CSN) expand3x3_mfma_kernel<T, CSN, FLIP><<<grid, 256, 0, stream>>>(in, w, bias, out, H, W, C, (unsigned)npix, nblocks)
+        // persistent: exactly the resident set (2 workgroups per CU at <= 256 registers), so the per-wave operand setup runs once
+        const unsigned resident = 2u * (unsigned)gmk_cu_limit();
+        const unsigned grid = (nblocks + 3) / 4 < resident ? (nblocks + 3) / 4 : resident;
+#define GMK_EXPAND_M(CSN) expand3x3_mfma_kernel<T, CSN, FLIP><<<grid, 256, 0, stream>>>(in, w, bias, out, H, W, C, (unsigned)npix, nblocks, (unsigned)in_bytes, (unsigned)out_bytes)
         if (cs == 1) GMK_EXPAND_M(1);
         else if (cs == 2) GMK_EXPAND_M(2);
         else if (cs == 3) GMK_EXPAND_M(3);
