@@ -1,0 +1,55 @@
+"""Prints the measured parity numbers DESIGN.md quotes (not a test: `python tests/parity_report.py` on a GPU box).
+
+For every reference-pinned default-init fixture (tests/golden/definit_*.npz, generated from the imported reference by
+oracle/make_golden.py) and both compute modes: max-norm and L2 relative error of the U-Net output with / without labels, of the
+per-sample loss, the worst gradient-norm deviation and the error of the two stored full gradients.
+"""
+import os
+import sys
+from functools import partial
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+
+from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion  # noqa: E402
+from generative_models_amd.diffusion.simple_unet import SimpleUnet  # noqa: E402
+from oracle import unet_ref as U  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def errs(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max()), float((a - b).norm() / b.norm())
+
+
+def main():
+    T = torch.from_numpy
+    for name in ("definit_c128_s28.npz", "definit_c128_s32.npz"):
+        g = np.load(os.path.join(GOLD, name), allow_pickle=True)
+        params = U.reference_init_params(128, 1, seed=int(g["init_seed"]), zero_out_layers=False)
+        for dtype in (torch.float32, torch.bfloat16):
+            net = SimpleUnet(128, 0.0, compute_dtype=dtype)
+            net.load_state_dict(params, strict=True)
+            net = net.cuda()
+            z, l, y = T(g["z"]).cuda(), T(g["logsnr"]).cuda(), T(g["guide"]).cuda()
+            with torch.no_grad():
+                e_v, e_n = errs(net(z, l, guide=y), T(g["v"])), errs(net(z, l), T(g["v_noguide"]))
+            diff = GaussianDiffusion(mean_type="v", num_steps=250)
+            x0, u, eps = (T(g[k]).cuda() for k in ("x0", "u", "eps"))
+            out = diff.train_forward_backward(net=partial(net, guide=y), x=x0, grad_scale=1.0 / x0.shape[0], u=u, eps=eps)
+            e_l = errs(out["loss"], T(g["loss_b"]))
+            names = [str(n) for n in g["grad_names"]]
+            norms = torch.stack([net.grad(n).norm() for n in names]).cpu()
+            ref = T(g["grad_norms"])
+            worst = float(((norms - ref).abs() / ref.abs().clamp_min(1e-3 * float(ref.abs().max()))).max())
+            eg = {k[6:]: errs(net.grad(k[6:]), T(g[k])) for k in g.files if k.startswith("grad__")}
+            print(f"{name} {str(dtype)[6:]:8s} v max {e_v[0]:.2e} L2 {e_v[1]:.2e} | no-label max {e_n[0]:.2e} L2 {e_n[1]:.2e} | "
+                  f"loss max {e_l[0]:.2e} | worst grad-norm dev {worst:.2e} | " +
+                  " ".join(f"{k} max {v[0]:.2e}" for k, v in eg.items()), flush=True)
+
+
+if __name__ == "__main__":
+    main()
