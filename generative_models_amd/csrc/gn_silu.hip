@@ -512,21 +512,23 @@ __device__ __forceinline__ f32x2_t silu_grad2(f32x2_t x, f32x2_t dy, f32x2_t s, 
 // registers (ITER x 16 B per thread), x is parked in LDS (HW x 64 B) on its way through the first sweep, and the second sweep
 // reads x from LDS and dy from registers.  HBM: x, dy, addends once + dx once (the streaming kernel reads x and dy twice).
 // 3 workgroups per CU (LDS), thread = (vec = tid & 3, plane = tid >> 2), pixel p = plane + 64 i.
-template <int ITER, int THREADS>
+// NVEC = 2 (16-channel slabs, 1024 threads, x in 128 KiB of LDS) carries the same scheme to 64 x 64 images, where a 32-channel slab
+// fits neither the registers nor the LDS and the two-sweep streaming kernel used to run (5 passes over HBM instead of 3).
+template <int ITER, int THREADS, int NVEC = 4>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? 3 : 4, 4))) void gn_silu_bwd_hybrid_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ dadd1,
     const bf16_t* __restrict__ dadd2, bf16_t* __restrict__ dx, float* __restrict__ dgp, float* __restrict__ dbp,
     float* __restrict__ dxsum, int dxsum_stride, int HW, int C, int G, int B, float drop_p, uint64_t drop_seed,
     uint64_t drop_off, const float* __restrict__ xadd, int xadd_stride) {
-    constexpr int NVEC = 4, CS = 32;
-    extern __shared__ __attribute__((aligned(16))) char xs_lds[];        // [HW][4] x 16 B
-    constexpr int NW = THREADS / 64, PL = THREADS / 4;      // waves, pixel planes
+    constexpr int CS = NVEC * 8;
+    extern __shared__ __attribute__((aligned(16))) char xs_lds[];        // [HW][NVEC] x 16 B
+    constexpr int NW = THREADS / 64, PL = THREADS / NVEC;      // waves, pixel planes
     __shared__ float red[NW][NVEC][16];
     __shared__ float chg[CS], chb[CS];
     __shared__ float sA[8], sB[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int vec = tid & 3, pl = tid >> 2;
+    const int vec = tid & (NVEC - 1), pl = tid / NVEC;
     int b, slab;
     slab_of_block(blockIdx.x, C / CS, B, b, slab);
     const int cpg = C / G, c0 = slab * CS, g0 = c0 / cpg, gps = CS / cpg;
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
             const int i = i0 + u;
             if (i >= ITER) continue;
             const int p = pl + PL * i;
-            if (p < HW) *reinterpret_cast<u32x4_t*>(xs_lds + ((size_t)p * 4 + vec) * 16) = xr[u];
+            if (p < HW) *reinterpret_cast<u32x4_t*>(xs_lds + ((size_t)p * NVEC + vec) * 16) = xr[u];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const f32x2_t xv = unpack2(xr[u][jj]), dv = unpack2(dr[i][jj]);
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
         const int p = pl + PL * i;
         if (p >= HW) continue;
         const size_t off = base + (size_t)p * C;
-        const u32x4_t xr = *reinterpret_cast<const u32x4_t*>(xs_lds + ((size_t)p * 4 + vec) * 16);
+        const u32x4_t xr = *reinterpret_cast<const u32x4_t*>(xs_lds + ((size_t)p * NVEC + vec) * 16);
         float o[8];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -1149,6 +1151,15 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
         if (HW <= 832) GMK_GN_BWD_HYB(13, 256);      // 28x28: 3 workgroups of 4 waves per CU
         else GMK_GN_BWD_HYB(8, 512);                 // 32x32: 2 workgroups of 8 waves (-13 % against the streaming kernel)
 #undef GMK_GN_BWD_HYB
+    } else if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 16 == 0 && 16 % (C / groups) == 0 && HW > 1024 &&
+               HW <= 4096 && drop_p == 0.f) {
+        // 64 x 64: 16-channel slabs, one workgroup of 16 waves per CU
+        static const hipError_t attr = hipFuncSetAttribute((const void*)gn_silu_bwd_hybrid_kernel<8, 1024, 2>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32);
+        (void)attr;
+        gn_silu_bwd_hybrid_kernel<8, 1024, 2><<<B * (C / 16), 1024, (size_t)HW * 32, gmk_stream(stream)>>>(
+            (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,
+            dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);
     } else if (dtype == GMK_BF16) {
         const int CS = gn_slab_channels(gn_mode, C, groups, HW, 2, true);
         gn_silu_bwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(

@@ -288,6 +288,111 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const float* __restrict__
     }
 }
 
+
+// ---- the same weight gradients on the fp32 matrix cores ---------------------------------------------------------------------
+// dW^T[c][j] = sum_px big[px][c] * patch[px][j],  j = s * 9 + t < 32 (up to 3 image channels): the PIXEL is the contraction index of
+// v_mfma_f32_32x32x2_f32 (exact fp32 products and sums), two pixels per instruction.  A operand: lane (r, h) holds channel
+// 32 cb + r of pixel 2 q + h - a 2- or 4-byte load whose 32 lanes cover 64 / 128 contiguous bytes of the pixel's row; B operand: lane
+// (r, h) holds the image value of tap entry j = r at that pixel (zero outside the image / for j >= K).  A wave walks a contiguous
+// range of pixel pairs with 8 pairs (40 loads) in flight ahead of the 32 MFMAs that consume them and keeps the whole 128 x 32
+// gradient in 64 accumulator registers; the four waves of a workgroup are summed through LDS into ONE partial row, and the grid is
+// exactly the resident set, so `part` has <= 512 rows instead of one per 512-1024 pixels.  The VALU kernel above ran at 0.8-1.0 TB/s
+// (one launch per image channel, 9 LDS reduction rounds each); this one is bound by the MFMA issue rate (4 per pixel pair).
+template <typename T, int CSN, bool FLIP>
+__global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(const float* __restrict__ small, const T* __restrict__ big,
+                                                           float* __restrict__ part, int H, int W, int C, unsigned npix,
+                                                           unsigned small_bytes, unsigned big_bytes, unsigned pairs_per_wave) {
+    constexpr int K = 9 * CSN, U = 8;
+    constexpr unsigned kBadOff = 0xFFFFFF00u;
+    __shared__ float red[4][128 * 32];
+    __shared__ float bred[4][4][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int HW = H * W;
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(small), 0, (int)small_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(big), 0, (int)big_bytes, 0x00020000);
+    const bool kin = r < K;
+    const int s_ = kin ? r / 9 : 0, t = kin ? r % 9 : 4;
+    const int dy = FLIP ? 1 - t / 3 : t / 3 - 1, dx = FLIP ? 1 - t % 3 : t % 3 - 1;
+    const int koff = s_ * HW + dy * W + dx;
+    const unsigned npairs = (npix + 1) / 2;
+    const unsigned q0 = (blockIdx.x * 4 + wave) * pairs_per_wave;
+    const unsigned q1 = q0 + pairs_per_wave < npairs ? q0 + pairs_per_wave : npairs;
+    // walking state of THIS lane's pixel g = 2 q + h (W is even, so a pair never straddles a row)
+    unsigned g = 2 * q0 + h;
+    int b0 = (int)(g / (unsigned)HW), pp = (int)(g - (unsigned)b0 * (unsigned)HW);
+    int y = pp / W, x = pp - y * W;
+    int base = b0 * CSN * HW + pp;
+    float bsum = 0.f;
+    f32x16 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
+
+    auto fetch = [&](unsigned q, float (&av)[4], float& bv) {
+        const int live = (int)(q < q1) & (int)(g < npix);
+        const int ok = live & (int)kin & (int)((unsigned)(y + dy) < (unsigned)H) & (int)((unsigned)(x + dx) < (unsigned)W);
+        bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rss, ok ? (unsigned)(base + koff) * 4u : kBadOff, 0, 0));
+        const unsigned ao = live ? (g * (unsigned)C + (unsigned)r) * (unsigned)sizeof(T) : kBadOff;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            if constexpr (sizeof(T) == 2)
+                av[cb] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsb, ao, cb * 64, 0) << 16);
+            else
+                av[cb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsb, ao, cb * 128, 0));
+        }
+        // next pair of this lane
+        g += 2; base += 2; x += 2;
+        const int wrapx = x >= W;
+        x -= wrapx ? W : 0; y += wrapx;
+        const int wrapy = y >= H;
+        y = wrapy ? 0 : y; base += wrapy ? (CSN - 1) * HW : 0;
+    };
+
+    float an[U][4], bn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) fetch(q0 + u, an[u], bn[u]);
+    for (unsigned q = q0; q < q1; q += U) {
+        float ac[U][4], bc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bc[u] = bn[u];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) ac[u][cb] = an[u][cb];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) fetch(q + U + u, an[u], bn[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (FLIP) bsum += t == 4 ? bc[u] : 0.f;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u][cb], bc[u], acc[cb], 0, 0, 0);
+        }
+    }
+    // lane (j = r, h) holds dW^T[32 cb + (e & 3) + 8 (e >> 2) + 4 h][j]
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave][(cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[cb][e];
+    if (FLIP && kin && t == 4) bred[wave][s_][h] = bsum;
+    __syncthreads();
+    const size_t rowlen = (size_t)CSN * C * 9 + (FLIP ? CSN : 0);
+    float* out = part + (size_t)blockIdx.x * rowlen;
+    for (int idx = tid; idx < CSN * 128 * 9; idx += 256) {
+        int c, j;
+        if (FLIP) { const int s = idx / (128 * 9), rem = idx - s * 128 * 9; c = rem / 9; j = s * 9 + (rem - c * 9); }
+        else { c = idx / K; j = idx - c * K; }
+        out[idx] = (red[0][c * 32 + j] + red[1][c * 32 + j]) + (red[2][c * 32 + j] + red[3][c * 32 + j]);
+    }
+    if (FLIP && tid < CSN) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += bred[w][tid][0] + bred[w][tid][1];
+        out[(size_t)CSN * C * 9 + tid] = sum;
+    }
+}
+
 // ---- head forward (C -> cs): out[b,s,p] = bias[s] + sum_{t,c} a[b,p + off(t),c] * w[s][c][t] ----------------------------
 // One workgroup = one band of image rows.  Pass 1 reads every activation vector of the band (+1 row above/below) once and
 // leaves its 9 per-tap channel sums in LDS (tap[t][q] = sum_c a[q,c] w[s][c][t], reduced over the pixel's lanes with DPP);
@@ -362,6 +467,13 @@ int small_blocks(int64_t npix) {
     return (int)((npix + ppb - 1) / ppb);
 }
 
+// rows of the weight-gradient partials: one per workgroup of the matrix-core kernel, whose grid is the resident set (2 per CU);
+// the VALU kernels accept any row count (their pixels per workgroup follow from it)
+int wgrad_rows(int64_t npix) {
+    const int nb = small_blocks(npix), resident = 2 * gmk_cu_limit();
+    return nb < resident ? nb : resident;
+}
+
 bool small_shape_ok(int B, int cs, int H, int W, int C) {
     return B > 0 && cs >= 1 && cs <= kMaxSmall && H > 0 && W > 0 && (C == 128 || C == 256) && (int64_t)B * H * W < (1ll << 24) &&
            H * W >= 32;
@@ -369,8 +481,8 @@ bool small_shape_ok(int B, int cs, int H, int W, int C) {
 
 }  // namespace
 
-extern "C" int gmk_stem_wgrad_blocks(int64_t n_pixels) { return small_blocks(n_pixels); }
-extern "C" int gmk_head_wgrad_blocks(int64_t n_pixels) { return small_blocks(n_pixels); }
+extern "C" int gmk_stem_wgrad_blocks(int64_t n_pixels) { return wgrad_rows(n_pixels); }
+extern "C" int gmk_head_wgrad_blocks(int64_t n_pixels) { return wgrad_rows(n_pixels); }
 
 template <typename T, bool FLIP>
 static void launch_expand(const float* in, const float* w, const float* bias, T* out, int B, int cs, int H, int W, int C,
@@ -424,10 +536,24 @@ extern "C" int gmk_head_dgrad(const float* dout, const float* w, void* da, int B
 template <typename T, bool FLIP>
 static void launch_wgrad(const float* small, const T* big, float* part, int B, int cs, int H, int W, int C, hipStream_t stream) {
     const int64_t npix = (int64_t)B * H * W;
-    const int nb = small_blocks(npix), ppb = small_ppb(npix);
+    const int nb = wgrad_rows(npix);
+    int ppb = (int)((npix + nb - 1) / nb);
+    ppb = (ppb + 31) & ~31;
     const float inv_w = 1.0f / (float)W;
-    // measured (B=1024, 28x28, 3 image channels): one launch per image channel with 8-channel vectors (the C-channel tensor is
-    // read cs times, 204 us) beats all channels at once with 4-channel vectors (one read, but 27 reduction rounds per block: 279 us)
+    const size_t small_bytes = (size_t)npix * cs * 4, big_bytes = (size_t)npix * C * sizeof(T);
+    if (C == 128 && cs <= 3 && W % 2 == 0 && big_bytes < 0xFFFFFF00ull && gmk_kernel_choice(3, "GMK_DEV_VARIANT") != 41) {
+        const unsigned npairs = (unsigned)((npix + 1) / 2);
+        unsigned ppw = (npairs + (unsigned)nb * 4 - 1) / ((unsigned)nb * 4);
+        ppw = (ppw + 7) & ~7u;                                         // whole groups of 8 pairs
+#define GMK_WGRAD_M(CSN) wgrad3x3_mfma_kernel<T, CSN, FLIP><<<nb, 256, 0, stream>>>(small, big, part, H, W, C, (unsigned)npix, (unsigned)small_bytes, (unsigned)big_bytes, ppw)
+        if (cs == 1) GMK_WGRAD_M(1);
+        else if (cs == 2) GMK_WGRAD_M(2);
+        else GMK_WGRAD_M(3);
+#undef GMK_WGRAD_M
+        return;
+    }
+    // VALU fallback.  Measured (B=1024, 28x28, 3 image channels): one launch per image channel with 8-channel vectors (the C-channel
+    // tensor is read cs times, 204 us) beats all channels at once with 4-channel vectors (one read, but 27 reduction rounds per block: 279 us)
     for (int s0 = 0; s0 < cs; ++s0)
         wgrad3x3_kernel<T, 1, 8, FLIP><<<nb, 256, 0, stream>>>(small, big, part, H, W, C, inv_w, (unsigned)npix, ppb, cs, s0);
 }
