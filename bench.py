@@ -317,6 +317,10 @@ class Bench:
                 line["cpu_baseline"] = cpu
             if others:
                 line["other_configs"] = others
+            if self.world > 1:
+                # the N = 1 line's headline is configs[2]; the single-GPU number of THIS workload is its other_configs entry
+                line["scaling_reference"] = ("weak scaling of the configs[3] per-GPU shard: divide by n_gpus x "
+                                             "other_configs.cfg3.value of the --gpus 1 line (same per-GPU batch and shape)")
             print(json.dumps(line))
         if self.world > 1:
             dist.destroy_process_group()

@@ -649,6 +649,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const f32x2_t xv = unpack2(xr[jj]), dv = unpack2(dr[i][jj]);
+            // (recomputing the sigmoid here instead of caching dy * silu'(g) costs 3-4 % of the kernel: a timing-only build without it)
             const f32x2_t dg = silu_grad2(xv, dv, sv[jj], tv[jj], kNegLog2e);
             const f32x2_t ov = __builtin_elementwise_fma(dg, sv[jj], __builtin_elementwise_fma(xv, npv[jj], qv[jj]));
             o[2 * jj] = ov[0]; o[2 * jj + 1] = ov[1];
@@ -696,215 +697,9 @@ int gn_reg_iter(int HW, int nvec) {
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------------------
-// LDS-resident variants (bf16): one workgroup = one sample x one channel slice, whose data is pulled into LDS ONCE by
-// LDS-DMA (`buffer_load_dwordx4 ... lds`), so statistics and apply read HBM a single time:
-//   forward  (sample, 64 channels):  1 read + 1 write of the tensor   (3-pass kernel: 2 reads + 1 write)
-//   backward (sample, 32 channels):  x, dy, addends read once, dx written once  (3-pass kernel: x and dy twice)
-// MAXHW sizes the static LDS image: 256 pixels (several workgroups per CU) or 1024 pixels (one per CU).
-// ------------------------------------------------------------------------------------------------------
-template <int MAXHW>
-__global__ __launch_bounds__(kThreads) void gn_silu_fwd_lds_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
-                                                                  const float* __restrict__ gamma,
-                                                                  const float* __restrict__ beta, float* __restrict__ mean,
-                                                                  float* __restrict__ rstd, int HW, int C, int G, float eps,
-                                                                  unsigned nbytes) {
-    constexpr int CB = 64, RB = CB * 2;                       // 64 channels = 128 bytes per pixel
-    __shared__ __attribute__((aligned(16))) char img[MAXHW * RB];
-    __shared__ float red[kThreads * 4];
-    __shared__ float smean[16], srstd[16];
-    const int b = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int cpg = C / G;
-    const int gpb = CB / cpg;                                  // groups in this slice (16, 8 or 4)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, (int)nbytes, 0x00020000);
-    // ---- pull the slice into LDS: one DMA instruction = 8 pixels x 128 B, lane-linear
-    const int ninstr = (HW + 7) >> 3;
-    const unsigned base = ((unsigned)b * (unsigned)HW * (unsigned)C + (unsigned)cb * CB) * 2u + (unsigned)(lane & 7) * 16u;
-    for (int i = wave; i < ninstr; i += 4) {
-        const int px = i * 8 + (lane >> 3);
-        const unsigned voff = px < HW ? base + (unsigned)px * (unsigned)C * 2u : 0xFFFFFF00u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (GMK_LDS void*)(img + i * 1024), 16, voff, 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // ---- statistics from LDS: thread = (pixel lane, 8-channel vector)
-    const int vec = tid & 7, pl = tid >> 3;                    // 8 vectors per pixel, 32 pixel lanes
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-    for (int p = pl; p < HW; p += 32) {
-        float v[8];
-        load8(reinterpret_cast<const bf16_t*>(img + p * RB) + vec * 8, v);
-        s0 += (v[0] + v[1]) + (v[2] + v[3]);
-        q0 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-        s1 += (v[4] + v[5]) + (v[6] + v[7]);
-        q1 += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
-    }
-    red[tid * 4 + 0] = s0; red[tid * 4 + 1] = q0; red[tid * 4 + 2] = s1; red[tid * 4 + 3] = q1;
-    __syncthreads();
-    if (tid < gpb) {
-        const int hv_per_g = cpg >> 2;
-        float s = 0.f, q = 0.f;
-        for (int j = 0; j < hv_per_g; ++j) {
-            const int hv = tid * hv_per_g + j, vv = hv >> 1, hf = hv & 1;
-            for (int p = 0; p < 32; ++p) {
-                s += red[(p * 8 + vv) * 4 + hf * 2];
-                q += red[(p * 8 + vv) * 4 + hf * 2 + 1];
-            }
-        }
-        const float n = (float)cpg * (float)HW;
-        const float m = s / n;
-        const float var = fmaxf(q / n - m * m, 0.f);
-        const float r = 1.0f / sqrtf(var + eps);
-        smean[tid] = m; srstd[tid] = r;
-        const int g = cb * gpb + tid;
-        mean[b * G + g] = m; rstd[b * G + g] = r;
-    }
-    __syncthreads();
-    float sc[8], sh[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int cl = vec * 8 + i, c = cb * CB + cl, g = cl / cpg;
-        sc[i] = srstd[g] * gamma[c];
-        sh[i] = beta[c] - smean[g] * sc[i];
-    }
-    bf16_t* yb = y + ((size_t)b * HW) * C + cb * CB + vec * 8;
-    for (int p = pl; p < HW; p += 32) {
-        float v[8];
-        load8(reinterpret_cast<const bf16_t*>(img + p * RB) + vec * 8, v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = siluf_(fmaf(v[i], sc[i], sh[i]));
-        store8(yb + (size_t)p * C, v);
-    }
-}
-
-template <int MAXHW>
-__global__ __launch_bounds__(kThreads) void gn_silu_bwd_lds_kernel(
-    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
-    const bf16_t* __restrict__ dadd1, const bf16_t* __restrict__ dadd2, bf16_t* __restrict__ dx, float* __restrict__ dgp,
-    float* __restrict__ dbp, float* __restrict__ dxsum, int dxsum_stride, int HW, int C, int G, unsigned nbytes) {
-    constexpr int CB = 32, RB = CB * 2;                       // 32 channels = 64 bytes per pixel
-    __shared__ __attribute__((aligned(16))) char imgx[MAXHW * RB];
-    __shared__ __attribute__((aligned(16))) char imgd[MAXHW * RB];
-    __shared__ float red[kThreads * 16];
-    __shared__ float chg[CB], chb[CB];
-    __shared__ float sA[8], sB[8];
-    const int b = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int cpg = C / G;
-    const int gpb = CB / cpg;
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, (int)nbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dy), 0, (int)nbytes, 0x00020000);
-    // one DMA instruction = 16 pixels x 64 B
-    const int ninstr = (HW + 15) >> 4;
-    const unsigned base = ((unsigned)b * (unsigned)HW * (unsigned)C + (unsigned)cb * CB) * 2u + (unsigned)(lane & 3) * 16u;
-    for (int i = wave; i < ninstr; i += 4) {
-        const int px = i * 16 + (lane >> 2);
-        const unsigned voff = px < HW ? base + (unsigned)px * (unsigned)C * 2u : 0xFFFFFF00u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (GMK_LDS void*)(imgx + i * 1024), 16, voff, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (GMK_LDS void*)(imgd + i * 1024), 16, voff, 0, 0, 0);
-    }
-    const int vec = tid & 3, pl = tid >> 2;                    // 4 vectors per pixel, 64 pixel lanes
-    float gam[8], bet[8], mu[8], rs[8];
-    int grp[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int cl = vec * 8 + i, c = cb * CB + cl;
-        grp[i] = cl / cpg;
-        gam[i] = gamma[c]; bet[i] = beta[c];
-        const int g = cb * gpb + grp[i];
-        mu[i] = mean[b * G + g]; rs[i] = rstd[b * G + g];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    float ag[8], ab[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
-    for (int p = pl; p < HW; p += 64) {
-        float xv[8], dv[8];
-        load8(reinterpret_cast<const bf16_t*>(imgx + p * RB) + vec * 8, xv);
-        load8(reinterpret_cast<const bf16_t*>(imgd + p * RB) + vec * 8, dv);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float xh = (xv[i] - mu[i]) * rs[i];
-            const float g = fmaf(xh, gam[i], bet[i]);
-            const float s = sigmoidf_(g);
-            const float dg = dv[i] * s * (1.f + g * (1.f - s));
-            ag[i] = fmaf(dg, xh, ag[i]);
-            ab[i] += dg;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { red[tid * 16 + i] = ag[i]; red[tid * 16 + 8 + i] = ab[i]; }
-    __syncthreads();
-    if (tid < CB) {
-        const int vv = tid >> 3, i = tid & 7;
-        float a = 0.f, bb = 0.f;
-        for (int p = 0; p < 64; ++p) {
-            a += red[(p * 4 + vv) * 16 + i];
-            bb += red[(p * 4 + vv) * 16 + 8 + i];
-        }
-        chg[tid] = a; chb[tid] = bb;
-        dgp[(size_t)b * C + cb * CB + tid] = a;
-        dbp[(size_t)b * C + cb * CB + tid] = bb;
-    }
-    __syncthreads();
-    if (tid < gpb) {
-        float A = 0.f, Bq = 0.f;
-        for (int j = 0; j < cpg; ++j) {
-            const int cl = tid * cpg + j;
-            A = fmaf(gamma[cb * CB + cl], chb[cl], A);
-            Bq = fmaf(gamma[cb * CB + cl], chg[cl], Bq);
-        }
-        const float inv_n = 1.f / ((float)cpg * (float)HW);
-        sA[tid] = A * inv_n; sB[tid] = Bq * inv_n;
-    }
-    __syncthreads();
-    float cA[8], cB[8], xs[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { cA[i] = sA[grp[i]]; cB[i] = sB[grp[i]]; xs[i] = 0.f; }
-    const size_t gbase = ((size_t)b * HW) * C + cb * CB + vec * 8;
-    for (int p = pl; p < HW; p += 64) {
-        float xv[8], dv[8], o[8];
-        load8(reinterpret_cast<const bf16_t*>(imgx + p * RB) + vec * 8, xv);
-        load8(reinterpret_cast<const bf16_t*>(imgd + p * RB) + vec * 8, dv);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float xh = (xv[i] - mu[i]) * rs[i];
-            const float g = fmaf(xh, gam[i], bet[i]);
-            const float s = sigmoidf_(g);
-            const float dg = dv[i] * s * (1.f + g * (1.f - s));
-            o[i] = rs[i] * (dg * gam[i] - cA[i] - xh * cB[i]);
-        }
-        if (dadd1) {
-            float t[8];
-            load8(dadd1 + gbase + (size_t)p * C, t);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] += t[i];
-        }
-        if (dadd2) {
-            float t[8];
-            load8(dadd2 + gbase + (size_t)p * C, t);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] += t[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xs[i] += o[i];
-        store8(dx + gbase + (size_t)p * C, o);
-    }
-    if (dxsum) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) red[tid * 16 + i] = xs[i];
-        __syncthreads();
-        if (tid < CB) {
-            const int vv = tid >> 3, i = tid & 7;
-            float a = 0.f;
-            for (int p = 0; p < 64; ++p) a += red[(p * 4 + vv) * 16 + i];
-            dxsum[(size_t)b * dxsum_stride + cb * CB + tid] = a;
-        }
-    }
-}
+// (LDS-resident single-read variants of both kernels - the sample slice pulled into LDS by LDS-DMA - were built and measured 0-50 %
+// slower than the streaming kernels at 28x28 / 14x14 / 7x7: one or few resident workgroups per CU serialise their load / compute /
+// store phases.  Removed in round 2; the register / hybrid kernels above are the single-read forms that pay.)
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void chansum_kernel(const T* __restrict__ x, float* __restrict__ out,
@@ -1024,22 +819,8 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
     GMK_REQUIRE(x && y && gamma && beta && mean && rstd, "gmk_gn_silu_fwd: null pointer");
     GMK_REQUIRE(B > 0 && HW > 0 && gn_shape_ok(C, groups), "gmk_gn_silu_fwd: unsupported shape B=%d HW=%d C=%d G=%d", B,
                 HW, C, groups);
-    // GMK_GN_KERNEL=2 selects the LDS-resident single-read kernels (kept for experiments: measured on MI355X they are
-    // 0-50 % SLOWER than the streaming kernels at 28x28 / 14x14 / 7x7 — one or few resident workgroups per CU serialise their
-    // load / compute / store phases, while the streaming kernels' second sweep is served from L2 / Infinity Cache)
     const int gn_mode = gmk_kernel_choice(2, "GMK_GN_KERNEL");
-    const int lds_ok = gn_mode == 2 && drop_p == 0.f && !xadd;
-    const int lds_max_hw = 1024;
-    const int64_t nbytes = (int64_t)B * HW * C * 2;
-    if (dtype == GMK_BF16 && lds_ok && !stats_part && C % 64 == 0 && HW <= lds_max_hw && nbytes < 0xFFFF0000ll) {
-        dim3 grid(B, C / 64);
-        if (HW <= 256)
-            gn_silu_fwd_lds_kernel<256><<<grid, kThreads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, mean,
-                                                                                rstd, HW, C, groups, eps, (unsigned)nbytes);
-        else
-            gn_silu_fwd_lds_kernel<1024><<<grid, kThreads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta,
-                                                                                 mean, rstd, HW, C, groups, eps, (unsigned)nbytes);
-    } else if (dtype == GMK_BF16 && !stats_part && (gn_mode == 0 || gn_mode == 5 || gn_mode == 6) && C % 64 == 0 &&
+    if (dtype == GMK_BF16 && !stats_part && (gn_mode == 0 || gn_mode == 5 || gn_mode == 6) && C % 64 == 0 &&
                32 % (C / groups) == 0 && gn_reg_iter(HW, 8) > 0) {
         const int nvec = gn_mode == 5 ? 4 : 8;                 // 32- or 64-channel slabs (64 = whole 128-B lines)
         const int it = gn_reg_iter(HW, nvec), planes = (HW + it - 1) / it, threads = (planes * nvec + 63) / 64 * 64;
@@ -1124,24 +905,8 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
     GMK_REQUIRE(B > 0 && HW > 0 && gn_shape_ok(C, groups), "gmk_gn_silu_bwd: unsupported shape B=%d HW=%d C=%d G=%d", B,
                 HW, C, groups);
     GMK_REQUIRE(!dxsum || dxsum_stride >= C, "gmk_gn_silu_bwd: dxsum_stride %d < C %d", dxsum_stride, C);
-    // GMK_GN_KERNEL=2 selects the LDS-resident single-read kernels (kept for experiments: measured on MI355X they are
-    // 0-50 % SLOWER than the streaming kernels at 28x28 / 14x14 / 7x7 — one or few resident workgroups per CU serialise their
-    // load / compute / store phases, while the streaming kernels' second sweep is served from L2 / Infinity Cache)
     const int gn_mode = gmk_kernel_choice(2, "GMK_GN_KERNEL");
-    const int lds_ok = gn_mode == 2 && drop_p == 0.f && !xadd;
-    const int lds_max_hw = 1024;
-    const int64_t nbytes = (int64_t)B * HW * C * 2;
-    if (dtype == GMK_BF16 && lds_ok && C % 32 == 0 && HW <= lds_max_hw && nbytes < 0xFFFF0000ll) {
-        dim3 grid(B, C / 32);
-        if (HW <= 256)
-            gn_silu_bwd_lds_kernel<256><<<grid, kThreads, 0, gmk_stream(stream)>>>(
-                (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2,
-                (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, (unsigned)nbytes);
-        else
-            gn_silu_bwd_lds_kernel<1024><<<grid, kThreads, 0, gmk_stream(stream)>>>(
-                (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2,
-                (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, (unsigned)nbytes);
-    } else if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 32 == 0 && 32 % (C / groups) == 0 && HW >= 512 &&
+    if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 32 == 0 && 32 % (C / groups) == 0 && HW >= 512 &&
                HW <= 1024 && drop_p == 0.f) {
         const size_t lds = (size_t)HW * 64;
 #define GMK_GN_BWD_HYB(IT, TH)                                                                                                      \

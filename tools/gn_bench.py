@@ -1,5 +1,5 @@
 """Time the GroupNorm+SiLU forward/backward kernels per workgroup-slab mode (gmk_set_kernel_choice gn = 1 whole sample,
-3 = 32-channel slabs, 4 = 64-channel slabs, 2 = LDS-resident) and check that the modes agree."""
+3 = 32-channel slabs, 4 = 64-channel slabs, 0 = automatic: register / hybrid single-read kernels) and check that the modes agree."""
 import sys
 import torch
 sys.path.insert(0, ".")
