@@ -458,6 +458,96 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a, 
     }
 }
 
+
+// ---- head forward on the bf16 matrix cores (bf16 activations) ----------------------------------------------------------------
+// Pass 1 of the kernel above is a GEMM: Tap[j][q] = sum_c w[j][c] a[q][c], j = (image channel, tap) <= 27 rows, 128-deep.  Here it IS
+// one: v_mfma_f32_32x32x16_bf16 with the fp32 weights split into bf16 hi + lo parts (two MFMAs per k-step, the weight error drops to
+// 2^-17; the activations are bf16 already), the weights resident in registers as A operands, a lane's B operand = the 16 bytes of
+// its pixel's k-slice straight from HBM.  All image channels come out of ONE read of the activations (the VALU kernel re-read the band
+// once per image channel), D[j][q] lands a lane's 16 tap sums for its own pixel, which go to the LDS planes; pass 2 is unchanged.
+// One workgroup of 8 waves = one band of rows (+1 row above / below) of one image.
+__global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const bf16_t* __restrict__ a, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int cs, int H,
+                                                           int W, int band, int nbands, unsigned a_bytes) {
+    constexpr int C = 128;
+    constexpr unsigned kBadOff = 0xFFFFFF00u;
+    extern __shared__ __attribute__((aligned(16))) float tapl[];   // [9 cs][(band+2)*W]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x / nbands, r0 = (blockIdx.x % nbands) * band;
+    const int rows = min(band, H - r0);
+    const int e0 = max(r0 - 1, 0), e1 = min(r0 + rows + 1, H);       // rows whose activations feed this band
+    const int next = (e1 - e0) * W, plane = (band + 2) * W;
+    const int K = 9 * cs;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a), 0, (int)a_bytes, 0x00020000);
+    // A operands: row j = r, k = 16 ks + 8 h + e
+    bf16x8 whi[8], wlo[8];
+    {
+        const int sj = r / 9, tj = r - sj * 9;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float wv = r < K ? w[((size_t)sj * C + 16 * ks + 8 * h + e) * 9 + tj] : 0.f;
+                const bf16_t hi = (bf16_t)wv;
+                whi[ks][e] = hi;
+                wlo[ks][e] = (bf16_t)(wv - (float)hi);
+            }
+    }
+    const unsigned pix0 = ((unsigned)b * H + e0) * W;               // first pixel of the region
+    const int nblk = (next + 31) >> 5;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
+    auto fetch = [&](int blk, u32x4s (&bf)[8]) {
+        const int q = blk * 32 + r;
+        const unsigned off = (blk < nblk && q < next) ? ((pix0 + (unsigned)q) * C + 8u * h) * 2u : kBadOff;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsa, off, ks * 32, 0);
+    };
+    u32x4s bn[8];
+    fetch(wave, bn);
+    for (int blk = wave; blk < nblk; blk += 8) {
+        u32x4s bc[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bc[ks] = bn[ks];
+        fetch(blk + 8, bn);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 bv = __builtin_bit_cast(bf16x8, bc[ks]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[ks], bv, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[ks], bv, acc, 0, 0, 0);
+        }
+        const int q = blk * 32 + r;
+        if (q < next) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (j < K) tapl[j * plane + q] = acc[e];
+            }
+        }
+    }
+    __syncthreads();
+    const int per = rows * W;
+    for (int o = tid; o < cs * per; o += 512) {
+        const int sc = o / per, rem = o - sc * per;
+        const int oyl = rem / W, ox = rem - oyl * W, oy = r0 + oyl;
+        float sum = bias[sc];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy + ky - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox + kx - 1;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    sum += tapl[(sc * 9 + ky * 3 + kx) * plane + (iy - e0) * W + ix];
+            }
+        }
+        out[((size_t)(b * cs + sc) * H + oy) * W + ox] = sum;
+    }
+}
+
 int small_ppb(int64_t npix) {          // pixels per workgroup of the streaming kernels
     return npix > 4096 * 256 ? 1024 : 512;
 }
@@ -582,6 +672,26 @@ extern "C" int gmk_head_fwd(const void* a, const float* w, const float* bias, fl
                             int C, int dtype, void* stream) {
     GMK_REQUIRE(a && w && bias && out, "gmk_head_fwd: null pointer");
     GMK_REQUIRE(small_shape_ok(B, cout, H, W, C), "gmk_head_fwd: unsupported shape");
+    const size_t a_bytes = (size_t)B * H * W * C * 2;
+    if (dtype == GMK_BF16 && C == 128 && cout <= 3 && a_bytes < 0xFFFFFF00ull && gmk_kernel_choice(3, "GMK_DEV_VARIANT") != 41) {
+        // matrix-core kernel: all image channels from one read; 9 * cout fp32 planes of (band + 2) rows in <= 124 KiB of LDS
+        int mb = (int)(126976 / ((size_t)36 * cout * W)) - 2;
+        if (mb >= 1) {
+            if (mb >= H) mb = H;
+            else {                       // equal bands
+                const int n = (H + mb - 1) / mb;
+                mb = (H + n - 1) / n;
+            }
+            const int nb2 = (H + mb - 1) / mb;
+            const size_t lds2 = (size_t)9 * cout * (mb + 2) * W * 4;
+            static const hipError_t attr = hipFuncSetAttribute((const void*)head_fwd_mfma_kernel,
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            (void)attr;
+            head_fwd_mfma_kernel<<<B * nb2, 512, lds2, gmk_stream(stream)>>>((const bf16_t*)a, w, bias, out, cout, H, W, mb, nb2,
+                                                                            (unsigned)a_bytes);
+            return gmk_check_launch("gmk_head_fwd");
+        }
+    }
     // band of rows per workgroup: 9 fp32 planes of (band + 2) rows within 48 KiB of LDS, at least 4 workgroups per CU's worth of bands
     int band = 49152 / (36 * W) - 2;
     GMK_REQUIRE(band >= 1, "gmk_head_fwd: image too wide (W=%d)", W);
