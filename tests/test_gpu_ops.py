@@ -143,7 +143,7 @@ def test_conv_fwd_dgrad_wgrad(ops, dtype, mode, two, ks, S, B):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cs,S,B", [(1, 28, 3), (3, 16, 2)])
+@pytest.mark.parametrize("cs,S,B", [(1, 28, 3), (3, 16, 2), (3, 14, 3), (2, 32, 1), (1, 7, 5), (4, 8, 2)])
 def test_stem_head(ops, dtype, cs, S, B):
     C = 128
     x = rnd(B, cs, S, S, seed=40).clamp(-1, 1)
