@@ -65,6 +65,7 @@ struct ConvParams {
     int n0;
     const float* bias; const float* emb; int emb_stride;
     const void* residual; void* out; int out_cstride;
+    void* out2;   // LDS-DMA kernel only: a second 128-channel output block (weight rows n0 + 128 ...) from the same pass over the source
     int M;   // B*ho*wo
     unsigned nb0, nb1, nbw, nbo;   // byte sizes of src0 / src1 / w / out for the buffer descriptors of the LDS-DMA kernel
 };
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
     constexpr int KCH = 128 / ES;
     constexpr int NS = 3, A_BYTES = 32768, STAGE = 49152;
     constexpr int kEpiStores = ES == 2 ? 8 : 16;
+    static_assert(6 + kEpiStores == (ES == 2 ? 14 : 22), "wait_step's vmcnt literals");
     __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
 
     const int tid = threadIdx.x;
@@ -328,6 +330,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.c1 ? p.src1 : p.src0), 0, (int)(p.c1 ? p.nb1 : p.nb0), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.nbw, 0x00020000);
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.nbo, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rso2 = __builtin_amdgcn_make_buffer_rsrc(p.out2 ? p.out2 : p.out, 0, (int)p.nbo, 0x00020000);
+    const int NH = p.out2 ? 2 : 1;          // output blocks per pixel tile (virtual tile = tile * NH + block)
     const __amdgpu_buffer_rsrc_t rsr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
 
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
     const int ntaps = g.ksize * g.ksize;     // 1 or 9 (a 1x1 conv uses tap slot 0: pad 0, offsets (0,0))
 
     // DMA of K-step (tap, kc) into ring slot `stage`; `tap` is a compile-time constant at every call site
-    auto issue = [&](int stage, const unsigned (&pix)[4], int tap, int kc) {
+    auto issue = [&](int stage, const unsigned (&pix)[4], int tap, int kc, unsigned wblock = 0u) {
         const int kelem = kc * KCH;
         const bool second = kelem >= p.c0;
         const unsigned cs_b = (unsigned)(second ? p.c1 : p.c0) * ES;         // bytes per source pixel
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
                                                          __umul24(pix[i], cs_b) + koff_b + a_ch[i], 0, 0, 0);
         }
         GMK_LDS char* lds_b = (GMK_LDS char*)(smem + stage * STAGE + A_BYTES + wave * 2048);
-        const unsigned wk = ((unsigned)tap * (unsigned)p.w_tap_stride + (unsigned)kelem) * ES;
+        const unsigned wk = ((unsigned)tap * (unsigned)p.w_tap_stride + (unsigned)kelem) * ES + wblock;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(lds_b + i * 1024), 16, w_off[i] + wk, 0, 0, 0);
@@ -407,7 +411,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
             bias_r[j][e] = p.bias ? p.bias[nblk + wn * 64 + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
 
     // ---- epilogue straight from the accumulators
-    auto epilogue = [&](int tile) {
+    auto epilogue = [&](int tile, int block = 0) {
+        const __amdgpu_buffer_rsrc_t rso_b = block ? rso2 : rso;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = tile * 256 + wm * 64 + i * 32 + r;
@@ -466,14 +471,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
                         const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q4][1], pk[q4 + 1][1], false, false);
                         u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                         const unsigned off = live ? row_b + (unsigned)(cb + 8 * (q4 + h)) * ES : kBadOff;
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rso, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rso_b, off, 0, 0);
                     }
                 } else {
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
                         f32x4 t = {v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]};
                         const unsigned off = live ? row_b + (unsigned)(cb + 8 * q4 + 4 * h) * ES : kBadOff;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rso, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rso_b, off, 0, 0);
                     }
                 }
             }
@@ -483,9 +488,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
     int st = 0;          // ring slot of the K-step computed next
     int sq = 2;          // ring slot the next issue goes to
     int fresh = 0;       // K-steps still to run with the epilogue's stores younger than their data
-    int tile = blockIdx.x;
-    if (tile < ntiles) {
-        resolve_tile(tile);
+    // virtual tiles: (pixel tile, output block); a workgroup runs the NH blocks of its tile back to back, so the second block's
+    // source DMA hits the lines the first one just pulled through this XCD's L2
+    const unsigned wblock_b = (unsigned)kBN * (unsigned)p.ktot * ES;
+    const int nvt = ntiles * NH;
+    int vt = blockIdx.x * NH;
+    if (vt < nvt) {
+        resolve_tile(vt / NH);
         unsigned pix0[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) pix0[i] = pixi[i][0];
@@ -502,7 +511,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
         }
         __builtin_amdgcn_s_barrier();
     };
-    for (; tile < ntiles; tile += gridDim.x) {
+    while (vt < nvt) {
+        const int tile = vt / NH, block = vt - tile * NH;
+        const unsigned wb = block ? wblock_b : 0u;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -517,22 +528,24 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
                 for (int i = 0; i < 4; ++i) pix[i] = pixi[i][tap];
                 for (int kc = (tap == 0 ? 2 : 0); kc < kpt; ++kc) {
                     wait_step();
-                    issue(sq, pix, tap, kc);
+                    issue(sq, pix, tap, kc, wb);
                     compute(st);
                     st = st == 2 ? 0 : st + 1;
                     sq = sq == 2 ? 0 : sq + 1;
                 }
             }
         }
-        // the last two K-steps of this tile run while the first two of the next tile are issued
-        const int next = tile + gridDim.x;
-        const bool more = next < ntiles;
-        if (more) resolve_tile(next);
+        // the last two K-steps of this virtual tile run while the first two of the next one are issued
+        const int nvt_next = block + 1 < NH ? vt + 1 : (tile + (int)gridDim.x) * NH;
+        const bool more = nvt_next < nvt;
+        const int ntile = nvt_next / NH;
+        const unsigned nwb = (nvt_next - ntile * NH) ? wblock_b : 0u;
+        if (more && ntile != tile) resolve_tile(ntile);
         unsigned pix0[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) pix0[i] = pixi[i][0];
         wait_step();
-        if (more) issue(sq, pix0, 0, 0);
+        if (more) issue(sq, pix0, 0, 0, nwb);
         compute(st);
         st = st == 2 ? 0 : st + 1;
         sq = sq == 2 ? 0 : sq + 1;
@@ -542,14 +555,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        if (more) issue(sq, pix0, 0, 1);
+        if (more) issue(sq, pix0, 0, 1, nwb);
         compute(st);
         st = st == 2 ? 0 : st + 1;
         sq = sq == 2 ? 0 : sq + 1;
         asm volatile("" ::: "memory");
-        epilogue(tile);
+        epilogue(tile, block);
         asm volatile("" ::: "memory");
         fresh = 2;
+        vt = nvt_next;
     }
 }
 
@@ -859,11 +873,11 @@ extern "C" int gmk_pack_conv_weights_multi(const float* arena, void* packs, int 
     return gmk_check_launch("gmk_pack_conv_weights_multi");
 }
 
-extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1, int B, int hs, int ws, int ho, int wo,
-                              int ksize, int mode, const void* w, int w_rows, int n0, int cout, const float* bias,
-                              const float* emb, int emb_stride, const void* residual, void* out, int out_cstride,
-                              float* gn_stats, int64_t gn_stats_bytes, const float* gn_scale, const float* gn_shift, int gn_stride,
-                              int dtype, void* stream) {
+static int conv_igemm_impl(const void* src0, const void* src1, int c0, int c1, int B, int hs, int ws, int ho, int wo,
+                           int ksize, int mode, const void* w, int w_rows, int n0, int cout, const float* bias,
+                           const float* emb, int emb_stride, const void* residual, void* out, void* out2, int out_cstride,
+                           float* gn_stats, int64_t gn_stats_bytes, const float* gn_scale, const float* gn_shift, int gn_stride,
+                           int dtype, void* stream) {
     GMK_REQUIRE(src0 && w && out, "gmk_conv_igemm: null pointer");
     GMK_REQUIRE(dtype == GMK_BF16 || dtype == GMK_F32, "gmk_conv_igemm: bad dtype %d", dtype);
     GMK_REQUIRE(ksize == 1 || ksize == 3, "gmk_conv_igemm: ksize %d", ksize);
@@ -879,7 +893,7 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
     GMK_REQUIRE(!emb || emb_stride >= cout, "gmk_conv_igemm: emb_stride");
     p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.ktot = c0 + c1;
     p.w = w; p.w_tap_stride = (int64_t)w_rows * (c0 + c1); p.n0 = n0;
-    p.bias = bias; p.emb = emb; p.emb_stride = emb_stride; p.residual = residual; p.out = out;
+    p.bias = bias; p.emb = emb; p.emb_stride = emb_stride; p.residual = residual; p.out = out; p.out2 = nullptr;
     p.out_cstride = out_cstride; p.M = B * ho * wo;
     // kernel choice: 0 = automatic, 1 = register-staged 128x128, 2 = LDS-DMA im2col 256x128, 3 = LDS halo (3x3 s1 bf16)
     const int force = gmk_kernel_choice(0, "GMK_CONV_KERNEL");
@@ -907,6 +921,14 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
     const bool fits = nb0 < lim && nb1 < lim && nbw < lim && nbo < lim && (int64_t)B * hs * ws < 0x00FFFFFF &&
                       (int64_t)c0 * es <= 4096 && (int64_t)c1 * es <= 4096;
     const bool dma = fits && (force == 2 || (force != 1 && p.M >= 256 * 512));
+    if (out2 && !dma) {        // the pair form lives in the LDS-DMA kernel only: small problems run as two plain launches
+        const int rc = conv_igemm_impl(src0, src1, c0, c1, B, hs, ws, ho, wo, ksize, mode, w, w_rows, n0, cout, bias, emb, emb_stride,
+                                       residual, out, nullptr, out_cstride, nullptr, 0, nullptr, nullptr, 0, dtype, stream);
+        if (rc) return rc;
+        return conv_igemm_impl(src0, src1, c0, c1, B, hs, ws, ho, wo, ksize, mode, w, w_rows, n0 + cout, cout, bias, emb, emb_stride,
+                               residual, out2, nullptr, out_cstride, nullptr, 0, nullptr, nullptr, 0, dtype, stream);
+    }
+    p.out2 = out2;
     gmk_note_kernel(dma ? 2 : 1);
     if (dma) {
         p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1; p.nbw = (unsigned)nbw; p.nbo = (unsigned)nbo;
@@ -921,6 +943,23 @@ extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1
         else conv_igemm_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(p);
     }
     return gmk_check_launch("gmk_conv_igemm");
+}
+
+extern "C" int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1, int B, int hs, int ws, int ho, int wo,
+                              int ksize, int mode, const void* w, int w_rows, int n0, int cout, const float* bias,
+                              const float* emb, int emb_stride, const void* residual, void* out, int out_cstride,
+                              float* gn_stats, int64_t gn_stats_bytes, const float* gn_scale, const float* gn_shift, int gn_stride,
+                              int dtype, void* stream) {
+    return conv_igemm_impl(src0, src1, c0, c1, B, hs, ws, ho, wo, ksize, mode, w, w_rows, n0, cout, bias, emb, emb_stride, residual,
+                           out, nullptr, out_cstride, gn_stats, gn_stats_bytes, gn_scale, gn_shift, gn_stride, dtype, stream);
+}
+
+extern "C" int gmk_conv1x1_pair(const void* src, int c, int B, int H, int W, const void* w, int w_rows, int n0, void* out_a,
+                                void* out_b, int dtype, void* stream) {
+    GMK_REQUIRE(src && w && out_a && out_b, "gmk_conv1x1_pair: null pointer");
+    GMK_REQUIRE(n0 >= 0 && n0 + 256 <= w_rows, "gmk_conv1x1_pair: rows n0 .. n0 + 255 outside the %d packed rows", w_rows);
+    return conv_igemm_impl(src, nullptr, c, 0, B, H, W, H, W, 1, GMK_CONV_NORMAL, w, w_rows, n0, 128, nullptr, nullptr, 0, nullptr,
+                           out_a, out_b, 128, nullptr, 0, nullptr, nullptr, 0, dtype, stream);
 }
 
 // 1 if gmk_conv_igemm(ksize 3, GMK_CONV_NORMAL, bf16) of this shape runs on the halo kernel AND can apply a GroupNorm to its source

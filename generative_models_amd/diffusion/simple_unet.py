@@ -476,12 +476,10 @@ class SimpleUnet(nn.Module):
             _, wds = self._packs[f"{name}.skip_connection"]
         outs = []
         gw, gb = G[f"{name}.in_layers.0.weight"], G[f"{name}.in_layers.0.bias"]
+        dskips = ops.conv1x1_pair(dout, wds, 2 * C) if two else (dout,)      # both halves from one read of dout
         for i, s in enumerate(srcs):
             da = ops.conv_igemm([dh], wd1, len(srcs) * C, 3, ops.NORMAL, (H, W), n0=i * C)
-            if two:
-                dskip = ops.conv_igemm([dout], wds, 2 * C, 1, ops.NORMAL, (H, W), n0=i * C)
-            else:
-                dskip = dout
+            dskip = dskips[i]
             add2 = extra_add[i] if extra_add is not None else None
             ssum = torch.empty((B, C), device=dout.device, dtype=torch.float32)
             ds, dgp, dbp = ops.gn_silu_bwd(da, s, P[f"{name}.in_layers.0.weight"][i * C:(i + 1) * C],

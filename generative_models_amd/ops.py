@@ -321,6 +321,20 @@ def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, 
     return out
 
 
+def conv1x1_pair(src, w, w_rows, n0=0):
+    """Two 128-channel 1x1 convolutions of one source (packed weight rows n0.. and n0+128..) from one pass over it: the skip
+    connection's data gradient for both halves of a concatenated input.  -> (out_a, out_b), NHWC [B,H,W,128] each."""
+    s0 = _chk(src, name="src")
+    B, H, W, c = s0.shape
+    _chk(w, s0.dtype, "w")
+    assert w.numel() == w_rows * c and n0 + 256 <= w_rows
+    oa = torch.empty((B, H, W, 128), device=s0.device, dtype=s0.dtype)
+    ob = torch.empty_like(oa)
+    with _Timed("conv_igemm", 2.0 * B * H * W * 256 * c):
+        check(lib.gmk_conv1x1_pair(_p(s0), c, B, H, W, _p(w), w_rows, n0, _p(oa), _p(ob), _DT[s0.dtype], _s()), "conv1x1_pair")
+    return oa, ob
+
+
 _WS = {}
 
 

@@ -119,6 +119,12 @@ int gmk_conv_igemm(const void* src0, const void* src1, int c0, int c1, int B, in
  * gmk_gn_stats (simple_unet.py:161-163,169-172: the normalised tensor is never materialised).  Only where
  * gmk_conv_gn_fusable(...) returns 1; otherwise the call fails. */
 int gmk_conv_gn_fusable(int B, int H, int W, int c0, int c1, int cout);
+/* 1x1 convolution with TWO 128-channel output blocks (packed weight rows n0 .. n0+127 -> out_a, n0+128 .. n0+255 -> out_b, both
+ * NHWC [B][H][W][128]) from ONE pass over the source: the data gradient of the up-path ResBlocks' 1x1 skip_connection
+ * (simple_unet.py:176, Conv2d(2C, C, 1)) with respect to the two halves of its concatenated input (torch.cat, :141-147).
+ * Two gmk_conv_igemm calls would read the output gradient twice. */
+int gmk_conv1x1_pair(const void* src, int c, int B, int H, int W, const void* w, int w_rows, int n0, void* out_a, void* out_b,
+                     int dtype, void* stream);
 /* statistics-only GroupNorm for the above: mean / rstd [B][groups] and the affine tables (columns [0, C) of rows of tab_stride
  * floats: a concatenated input passes the same table with a column offset); xadd as in gmk_gn_silu_fwd */
 int gmk_gn_stats(const void* x, const float* gamma, const float* beta, float* mean, float* rstd, float* tab_scale,

@@ -533,6 +533,26 @@ def test_fused_attention_forward(ops, N, fp8):
     assert float((P.float().sum(-1) - 1).abs().max()) < 2e-2
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S", [(3, 8), (160, 32)])
+def test_conv1x1_pair_equals_two_launches(ops, dtype, B, S):
+    """gmk_conv1x1_pair (both halves of the skip connection's data gradient from one read of the output gradient) against two
+    gmk_conv_igemm launches with n0 = 0 / 128: the same bits.  (160, 32) runs on the LDS-DMA kernel (two output blocks per pixel
+    tile), (3, 8) takes the two-launch route inside the library."""
+    from generative_models_amd._lib import lib
+    C = 128
+    dy = q(rnd(B, S, S, C, seed=70), dtype).cuda().to(dtype)
+    w = (rnd(2 * C, C, seed=71) / 11).cuda().to(dtype)          # packed [1 tap][256 rows][128]
+    a, b = ops.conv1x1_pair(dy, w, 2 * C)
+    kernel = lib.gmk_last_kernel()
+    ra = ops.conv_igemm([dy], w, 2 * C, 1, ops.NORMAL, (S, S), n0=0)
+    rb = ops.conv_igemm([dy], w, 2 * C, 1, ops.NORMAL, (S, S), n0=C)
+    assert torch.equal(a, ra) and torch.equal(b, rb)
+    assert kernel == (2 if B * S * S >= 256 * 512 else 1)
+    ref = dy.float().reshape(-1, C) @ w.float().t()
+    assert rel_err(torch.cat([a, b], -1).reshape(-1, 2 * C), ref.cpu()) < TOL[dtype]
+
+
 @pytest.mark.parametrize("B,S,two,res", [(40, 28, False, True), (40, 28, True, False), (33, 32, True, True), (64, 16, False, True), (9, 64, False, False)])
 def test_conv_with_fused_groupnorm_is_bit_identical(ops, B, S, two, res):
     """gmk_gn_stats + gmk_conv_igemm(gn_scale, gn_shift): GroupNorm-apply + SiLU in the convolution's producer waves instead of a
