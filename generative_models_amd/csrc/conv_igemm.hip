@@ -736,9 +736,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 // Workgroup = 64 float4 columns x 4 slab groups (group g sums slabs g, g+4, ... with four independent 16-byte loads in flight per
 // thread; ~9 MB in flight over the grid), the four partial sums meet in LDS in a fixed order: deterministic, and at HBM speed
 // where one-float-per-thread chains were latency-bound (30 -> 17 us for the 128 x 590 KB slabs of one 3x3 convolution).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                          int nsplit, int taps, int cout, int ktot) {
-    __shared__ f32x4 part[3][64];
+template <int NG>       // slab groups per workgroup (64 threads each): 4 for the long 3x3 rows, 16 where the row is short (1x1: 8192 float4
+                        // columns = 128 workgroups only, which 4 groups left latency-bound: 60 us for 64 MB)
+__global__ __launch_bounds__(64 * NG) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                               int nsplit, int taps, int cout, int ktot) {
+    __shared__ f32x4 part[NG - 1][64];
     const int64_t per = (int64_t)taps * cout * ktot;          // multiple of 4 (ktot is a multiple of 64)
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int64_t idx = ((int64_t)blockIdx.x * 64 + lane) * 4;
@@ -747,17 +749,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
     for (int u = 0; u < 4; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (live) {
-        for (int s = grp; s < nsplit; s += 16) {
+        for (int s = grp; s < nsplit; s += 4 * NG) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (s + 4 * u < nsplit) a[u] += *reinterpret_cast<const f32x4*>(slab + (int64_t)(s + 4 * u) * per + idx);
+                if (s + NG * u < nsplit) a[u] += *reinterpret_cast<const f32x4*>(slab + (int64_t)(s + NG * u) * per + idx);
         }
     }
     const f32x4 mine = (a[0] + a[1]) + (a[2] + a[3]);
     if (grp > 0) part[grp - 1][lane] = mine;
     __syncthreads();
     if (grp == 0 && live) {
-        const f32x4 tot = (mine + part[0][lane]) + (part[1][lane] + part[2][lane]);
+        f32x4 tot = mine;
+#pragma unroll
+        for (int g2 = 0; g2 < NG - 1; ++g2) tot += part[g2][lane];
         const int ci = (int)(idx % ktot);
         const int64_t t2 = idx / ktot;
         const int co = (int)(t2 % cout);
@@ -765,6 +769,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) dw[((int64_t)co * ktot + ci + e) * taps + tap] = tot[e];
     }
+}
+
+static void launch_wgrad_reduce(const float* slab, float* dw, int nsplit, int taps, int cout, int ktot, hipStream_t stream) {
+    const int64_t per = (int64_t)taps * cout * ktot;
+    const int blocks = (int)((per / 4 + 63) / 64);
+    if (blocks < 512 && nsplit >= 64) wgrad_reduce_kernel<16><<<blocks, 1024, 0, stream>>>(slab, dw, nsplit, taps, cout, ktot);
+    else wgrad_reduce_kernel<4><<<blocks, 256, 0, stream>>>(slab, dw, nsplit, taps, cout, ktot);
 }
 
 // w [Cout][Cin][k][k] fp32 -> w_fwd [tap][Cout][Cin], w_dgrad [taps-1-tap][Cin][Cout]
@@ -808,7 +819,9 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const float* __
 
 int wgrad_nsplit(int64_t n_pixels, int taps, int cout, int ktot, int* chunk) {
     const int64_t tiles = (int64_t)taps * (cout / 128) * (ktot / 128);
-    int64_t ns = (1024 + tiles - 1) / tiles;
+    // 1x1 (HBM-bound): 512 workgroups = one resident round (2 per CU), more slabs only feed the reduce (375 + 60 -> 335 + 11 us at
+    // 32 x 32, B = 2048); 3x3 stride-2 (MFMA-bound): two rounds balance better (432 vs 496 us)
+    int64_t ns = ((taps == 1 ? 512 : 1024) + tiles - 1) / tiles;
     const int64_t max_ns = (n_pixels + 63) / 64;
     if (ns > max_ns) ns = max_ns;
     if (ns < 1) ns = 1;
@@ -1001,9 +1014,7 @@ extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, 
         if (ns2 > 0) {
             int rc2 = gmk_check_launch("gmk_conv_wgrad(slots)");
             if (rc2) return rc2;
-            const int64_t per2 = (int64_t)taps * cout * (c0 + c1);
-            wgrad_reduce_kernel<<<(int)((per2 / 4 + 63) / 64), 256, 0, gmk_stream(stream)>>>((const float*)workspace, dw, ns2, taps,
-                                                                                            cout, c0 + c1);
+            launch_wgrad_reduce((const float*)workspace, dw, ns2, taps, cout, c0 + c1, gmk_stream(stream));
             return gmk_check_launch("gmk_conv_wgrad(reduce)");
         }
     }
@@ -1020,7 +1031,6 @@ extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, 
     else conv_wgrad_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(p);
     int rc = gmk_check_launch("gmk_conv_wgrad");
     if (rc) return rc;
-    const int64_t per = (int64_t)taps * cout * p.ktot;
-    wgrad_reduce_kernel<<<(int)((per / 4 + 63) / 64), 256, 0, gmk_stream(stream)>>>(p.slab, dw, ns, taps, cout, p.ktot);
+    launch_wgrad_reduce(p.slab, dw, ns, taps, cout, p.ktot, gmk_stream(stream));
     return gmk_check_launch("gmk_conv_wgrad(reduce)");
 }
