@@ -142,8 +142,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 struct ColsumTable {
     const float* part[16]; long long stride[16]; float* out[16]; int R[16]; int C[16];
 };
-__global__ __launch_bounds__(256) void colsum_multi_kernel(const ColsumTable t) {
-    __shared__ float red[8][33];
+// 32 columns x 32 row lanes per workgroup: a [2048 x 128] partial is 64 rows per thread, four loads in flight (8 row lanes made it 256
+// rows per thread on 64 workgroups: 35 us per launch, latency-bound)
+__global__ __launch_bounds__(1024) void colsum_multi_kernel(const ColsumTable t) {
+    __shared__ float red[32][33];
     const int k = blockIdx.y;
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -155,13 +157,13 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(const ColsumTable t) 
     if (c < C) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int r = rl;
-        for (; r + 24 < R; r += 32) {
+        for (; r + 96 < R; r += 128) {
             s0 += part[(long long)r * stride + c];
-            s1 += part[(long long)(r + 8) * stride + c];
-            s2 += part[(long long)(r + 16) * stride + c];
-            s3 += part[(long long)(r + 24) * stride + c];
+            s1 += part[(long long)(r + 32) * stride + c];
+            s2 += part[(long long)(r + 64) * stride + c];
+            s3 += part[(long long)(r + 96) * stride + c];
         }
-        for (; r < R; r += 8) s0 += part[(long long)r * stride + c];
+        for (; r < R; r += 32) s0 += part[(long long)r * stride + c];
         s = (s0 + s1) + (s2 + s3);
     }
     red[rl][cl] = s;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(const ColsumTable t) 
     if (rl == 0 && c < C) {
         float v = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v += red[i][cl];
+        for (int i = 0; i < 32; ++i) v += red[i][cl];
         t.out[k][c] = v;
     }
 }
@@ -271,7 +273,7 @@ extern "C" int gmk_colsum_multi(int n, const float* const* part, const int64_t* 
         t.part[k] = part[k]; t.stride[k] = stride[k]; t.out[k] = out[k]; t.R[k] = R[k]; t.C[k] = C[k];
         if (C[k] > cmax) cmax = C[k];
     }
-    colsum_multi_kernel<<<dim3((cmax + 31) / 32, n), 256, 0, gmk_stream(stream)>>>(t);
+    colsum_multi_kernel<<<dim3((cmax + 31) / 32, n), 1024, 0, gmk_stream(stream)>>>(t);
     return gmk_check_launch("gmk_colsum_multi");
 }
 
