@@ -8,6 +8,9 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  (FIRST: libgmk.so must bind to the HIP runtime torch has loaded - two libamdhip64 copies in one process
+#                      do not share a device: a library loaded before torch reports "no ROCm-capable device" at its first launch)
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "gmk.h")
