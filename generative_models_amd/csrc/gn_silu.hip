@@ -820,7 +820,8 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
     GMK_REQUIRE(B > 0 && HW > 0 && gn_shape_ok(C, groups), "gmk_gn_silu_fwd: unsupported shape B=%d HW=%d C=%d G=%d", B,
                 HW, C, groups);
     const int gn_mode = gmk_kernel_choice(2, "GMK_GN_KERNEL");
-    if (dtype == GMK_BF16 && !stats_part && (gn_mode == 0 || gn_mode == 5 || gn_mode == 6) && C % 64 == 0 &&
+    // (at 7x7 / 8x8 the whole-sample streaming kernel wins: 19 vs 26 us at 8x8, B = 2048 - the slabs are too small to pay for a workgroup each)
+    if (dtype == GMK_BF16 && !stats_part && (gn_mode == 5 || gn_mode == 6 || (gn_mode == 0 && HW > 64)) && C % 64 == 0 &&
                32 % (C / groups) == 0 && gn_reg_iter(HW, 8) > 0) {
         const int nvec = gn_mode == 5 ? 4 : 8;                 // 32- or 64-channel slabs (64 = whole 128-B lines)
         const int it = gn_reg_iter(HW, nvec), planes = (HW + it - 1) / it, threads = (planes * nvec + 63) / 64 * 64;
@@ -870,7 +871,7 @@ extern "C" int gmk_gn_stats(const void* x, const float* gamma, const float* beta
     GMK_REQUIRE(tab_stride >= C, "gmk_gn_stats: tab_stride %d < C %d", tab_stride, C);
     GMK_REQUIRE(B > 0 && HW > 0 && gn_shape_ok(C, groups), "gmk_gn_stats: unsupported shape B=%d HW=%d C=%d G=%d", B, HW, C, groups);
     GMK_REQUIRE(dtype == GMK_BF16, "gmk_gn_stats: bf16 only (the fused apply lives in the bf16 halo convolution)");
-    if (C % 64 == 0 && 32 % (C / groups) == 0 && gn_reg_iter(HW, 8) > 0) {
+    if (C % 64 == 0 && 32 % (C / groups) == 0 && HW > 64 && gn_reg_iter(HW, 8) > 0) {      // same choice as gmk_gn_silu_fwd: same statistics bits
         const int nvec = 8;
         const int it = gn_reg_iter(HW, nvec), planes = (HW + it - 1) / it, threads = (planes * nvec + 63) / 64 * 64;
         const int nblk = B * (C / (nvec * 8));
@@ -906,14 +907,16 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
                 HW, C, groups);
     GMK_REQUIRE(!dxsum || dxsum_stride >= C, "gmk_gn_silu_bwd: dxsum_stride %d < C %d", dxsum_stride, C);
     const int gn_mode = gmk_kernel_choice(2, "GMK_GN_KERNEL");
-    if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 32 == 0 && 32 % (C / groups) == 0 && HW >= 512 &&
+    if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 32 == 0 && 32 % (C / groups) == 0 && HW > (gn_mode == 7 ? 511 : 64) &&
                HW <= 1024 && drop_p == 0.f) {
         const size_t lds = (size_t)HW * 64;
 #define GMK_GN_BWD_HYB(IT, TH)                                                                                                      \
     gn_silu_bwd_hybrid_kernel<IT, TH><<<B * (C / 32), TH, lds, gmk_stream(stream)>>>(                                                \
         (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,       \
         dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride)
-        if (HW <= 832) GMK_GN_BWD_HYB(13, 256);      // 28x28: 3 workgroups of 4 waves per CU
+        if (HW <= 256) GMK_GN_BWD_HYB(4, 256);       // 14x14 (-16 % against the streaming kernel), 16x16 (-10 %); at 7x7 / 8x8 the whole-sample
+                                                     // streaming kernel is as fast or faster (42 vs 46 us at 8x8, B = 2048)
+        else if (HW <= 832) GMK_GN_BWD_HYB(13, 256); // 28x28: 3 workgroups of 4 waves per CU
         else GMK_GN_BWD_HYB(8, 512);                 // 32x32: 2 workgroups of 8 waves (-13 % against the streaming kernel)
 #undef GMK_GN_BWD_HYB
     } else if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 16 == 0 && 16 % (C / groups) == 0 && HW > 1024 &&

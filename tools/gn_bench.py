@@ -24,7 +24,7 @@ def timed(fn, n=20):
 
 
 for (B, S, C, G) in ((1024, 28, 128, 32), (1024, 28, 128, 16), (1024, 14, 128, 32), (1024, 7, 128, 32), (2048, 32, 128, 32),
-                     (1000, 28, 128, 32), (1024, 64, 128, 32), (512, 64, 128, 32)):
+                     (1000, 28, 128, 32), (1024, 64, 128, 32), (512, 64, 128, 32), (2048, 16, 128, 32), (1024, 32, 128, 32), (2048, 8, 128, 32)):
     g = torch.Generator(device="cpu").manual_seed(0)
     x = torch.randn(B, S, S, C, generator=g).to(dev, torch.bfloat16)
     dy = torch.randn(B, S, S, C, generator=g).to(dev, torch.bfloat16)
