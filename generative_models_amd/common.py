@@ -27,9 +27,13 @@ def prefix_dict(name, d):
     return {name + key: d[key] for key in d}
 
 
+_WORD_STARTS = re.compile(r"(?<=.)(?=[A-Z][a-z])|(?<=[a-z0-9])(?=[A-Z])")
+
+
 def convert_camel_to_snake(name):
-    s1 = re.sub("(.)([A-Z][a-z]+)", r"\1_\2", name)
-    return re.sub("([a-z0-9])([A-Z])", r"\1_\2", s1).lower()
+    """'DiffusionModel' -> 'diffusion_model', 'VQVAE' -> 'vqvae', 'RNNModel' -> 'rnn_model': the registry-key rule of gms/common.py:33-35
+    (an underscore in front of every capital that starts a lower-case word or follows a lower-case letter / digit)."""
+    return _WORD_STARTS.sub("_", name).lower()
 
 
 class GM(nn.Module):
@@ -45,73 +49,81 @@ class GM(nn.Module):
     def save(self, path, test_x=None, test_y=None):
         torch.save(self.state_dict(), Path(path) / "model.pt")
 
-    def train_step(self, x, y):
-        """Default step for models that only define `loss` (gms/common.py:158-169)."""
-        assert hasattr(self, "loss"), (
-            "you are using the default train_step. this requires you to define a loss function that returns loss, metrics")
+    def _default_optimizer(self):
         if self.optimizer is None:
             self.optimizer = torch.optim.Adam(self.parameters(), self.G.lr)
-        self.optimizer.zero_grad()
-        loss, metrics = self.loss(x, y)
-        loss.backward()
-        self.optimizer.step()
+        return self.optimizer
+
+    def train_step(self, x, y):
+        """Default step for plugins that only define `loss(x, y) -> (loss, metrics)` (gms/common.py:158-169): Adam on all parameters,
+        created on first use."""
+        if not hasattr(self, "loss"):
+            raise AssertionError("the default train_step needs a `loss(x, y)` method that returns (loss, metrics)")
+        opt = self._default_optimizer()
+        opt.zero_grad()
+        objective, metrics = self.loss(x, y)
+        objective.backward()
+        opt.step()
         return metrics
 
     def evaluate(self, writer, x, y, epoch):
         assert False, "you need to implement the evaluate method. make some samples or something."
 
 
+_NOT_PLUGIN_FILES = ("__init__", "main", "common")          # the reference's filter on file names (gms/common.py:45)
+
+
+def _plugin_modules(package):
+    """Dotted names of the package's modules that may define a plugin: file name passes the reference's filter AND the source
+    contains a class deriving from something called *GM* (so that discovery does not import kernels / bindings needlessly)."""
+    root = Path(importlib.import_module(package).__file__).parent
+    for path in sorted(root.rglob("*.py")):
+        if any(word in path.name for word in _NOT_PLUGIN_FILES):
+            continue
+        try:
+            source = path.read_text()
+        except OSError:
+            continue
+        if re.search(r"^\s*class\s+\w+\(.*GM\w*\)", source, flags=re.M):
+            yield ".".join(path.relative_to(root.parent).with_suffix("").parts)
+
+
 def discover_models(package="generative_models_amd"):
-    """{snake_case(class name): class} for every GM subclass found in the package's modules whose file name does
-    not contain '__init__', 'main' or 'common' (the reference's filter, gms/common.py:45).  The reference CLI
+    """{snake_case(class name): class} for every GM subclass defined in the package (gms/common.py:38-55).  The reference CLI
     spelling `--model=diffusion` (run_all.sh:16) is registered as an alias of `diffusion_model`."""
-    models = {}
-    pkg = importlib.import_module(package)
-    root = Path(pkg.__file__).parent
-    for file in sorted(root.rglob("*.py")):
-        if "__init__" in file.name or "main" in file.name or "common" in file.name:
-            continue
-        rel = file.relative_to(root.parent)
-        modname = str(rel).replace("/", ".")[: -len(".py")]
-        if not _defines_gm(file):
-            continue
-        module = importlib.import_module(modname)
-        for key in dir(module):
-            obj = getattr(module, key)
-            if type(obj) == type and issubclass(obj, GM) and obj is not GM:
-                models[convert_camel_to_snake(key)] = obj
-    if "diffusion_model" in models:
-        models["diffusion"] = models["diffusion_model"]
-    return models
-
-
-def _defines_gm(file):
-    """Only import modules that can define a plugin (keeps discovery from importing kernels/bindings needlessly)."""
-    try:
-        text = file.read_text()
-    except OSError:
-        return False
-    return re.search(r"^\s*class\s+\w+\(.*GM\w*\)", text, flags=re.M) is not None
+    found = {}
+    for modname in _plugin_modules(package):
+        for attr, obj in vars(importlib.import_module(modname)).items():
+            if isinstance(obj, type) and obj is not GM and issubclass(obj, GM):
+                found[convert_camel_to_snake(attr)] = obj
+    if "diffusion_model" in found:
+        found["diffusion"] = found["diffusion_model"]
+    return found
 
 
 def to_numpy(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x
 
 
+def _parse_bool(text):
+    return bool(("False", "True").index(text))          # anything else is a ValueError, as in the reference
+
+
+def _parse_int(text):
+    return float(text) if ("e" in text or "." in text) else int(text)
+
+
 def args_type(default):
-    """Flag parser chosen from the default's type (gms/common.py:85-92): bools are 'True'/'False', ints accept
-    '1e3'-style floats, Paths are expanded."""
-    if isinstance(default, bool):
-        return lambda x: bool(["False", "True"].index(x))
-    if isinstance(default, int):
-        return lambda x: float(x) if ("e" in x or "." in x) else int(x)
-    if isinstance(default, Path):
-        return lambda x: Path(x).expanduser()
+    """Flag parser chosen from the default's type (gms/common.py:85-92): bools are the words 'True' / 'False', ints also accept
+    '1e3'-style floats, Paths are expanded, everything else is parsed by its own type."""
+    for kind, parser in ((bool, _parse_bool), (int, _parse_int), (Path, lambda text: Path(text).expanduser())):
+        if isinstance(default, kind):
+            return parser
     return type(default)
 
 
 def count_vars(module):
-    return sum([np.prod(p.shape) for p in module.parameters()])
+    return sum(int(np.prod(p.shape)) for p in module.parameters())
 
 
 class NullWriter:
@@ -152,24 +164,26 @@ def write_gridvid(writer, tag, x, epoch):
     return vid
 
 
-def dump_logger(logger, writer, i, G):
-    """Print + write the epoch means and hps.yaml (gms/common.py:65-82).  The git hash is best-effort: the
-    reference requires a checkout; outside one it is recorded as 'unknown'."""
-    print("=" * 30)
-    print(i)
-    for key in logger:
-        val = np.mean(logger[key])
-        writer.add_scalar(key, val, i)
-        print(key, val)
-    G.full_cmd = "python " + " ".join(sys.argv)
+def _git_head():
     try:
-        G.commit_hash = subprocess.check_output(["git", "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode("ascii").strip()
+        return subprocess.check_output(["git", "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode("ascii").strip()
     except Exception:
-        G.commit_hash = "unknown"
-    print(G.full_cmd)
-    Path(G.logdir).mkdir(parents=True, exist_ok=True)
-    with open(Path(G.logdir) / "hps.yaml", "w") as f:
-        yaml.dump(dict(G), f, width=float("inf"))
-    print("=" * 30)
+        return "unknown"       # the reference requires a checkout; outside one the field is still written
+
+
+def dump_logger(logger, writer, i, G):
+    """End-of-epoch report (gms/common.py:65-82): the mean of every logged series goes to the writer and to stdout, the flags (with
+    the command line and the git hash) to <logdir>/hps.yaml; returns a fresh logger."""
+    rule = "=" * 30
+    means = {key: np.mean(series) for key, series in logger.items()}
+    for key, val in means.items():
+        writer.add_scalar(key, val, i)
+    G.full_cmd = "python " + " ".join(sys.argv)
+    G.commit_hash = _git_head()
+    print("\n".join([rule, str(i)] + [f"{key} {val}" for key, val in means.items()] + [G.full_cmd]))
+    logdir = Path(G.logdir)
+    logdir.mkdir(parents=True, exist_ok=True)
+    (logdir / "hps.yaml").write_text(yaml.dump(dict(G), width=float("inf")))
+    print(rule)
     writer.flush()
-    return defaultdict(lambda: [])
+    return defaultdict(list)
