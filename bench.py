@@ -198,16 +198,22 @@ class Bench:
         dom = max(by, key=lambda k: by[k][0])          # dominant kernel = largest total HIP-event time
         ms, fl, n = by[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        traffic, source = None, None
+        traffic, source, pmc = None, None, None
         tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")     # HBM bytes per launch from separate rocprofv3 --pmc passes
         if os.path.exists(tfile):
             rec = json.load(open(tfile)).get(key, {})
-            traffic = rec.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+            kern = rec.get("kernels", {})
+            traffic = kern.get(dom, {}).get("hbm_bytes_per_launch")
             source = rec.get("provenance")
+            # MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE) of the two MFMA kernels from the same passes:
+            # achieved = peak x busy x (shader clock / 2.4 GHz), and the board's power cap trades one against the other
+            pmc = {k: {"mfma_busy_frac": kern[k]["mfma_busy_frac"], "sclk_ghz": kern[k].get("sclk_ghz_est")}
+                   for k in (dom, "conv_wgrad_slots_ws_kernel") if k in kern and "mfma_busy_frac" in kern[k]}
         step_s = elapsed * nprof / steps
         share = lambda v: round(v[0] * 1e-3 / step_s, 3)
         return {"kernel": dom, "what": KERNEL_DESC.get(dom, ""), "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_provenance": source,
+                "pmc": pmc,
                 "launches_per_step": n // nprof, "avg_launch_us": round(ms * 1e3 / n, 2), "share_of_step_time": share(by[dom]),
                 "profiled_steps": nprof,
                 "other_kernels": {k: {"achieved": round(v[1] / (v[0] * 1e-3) / 1e12, 2), "avg_launch_us": round(v[0] * 1e3 / v[2], 2),

@@ -16,9 +16,14 @@ def short(name):
 
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
+clk = collections.defaultdict(lambda: [0.0, 0.0])          # kernel -> [GRBM_GUI_ACTIVE cycles (sum over the 8 XCDs), dispatch ns]
 for f in sorted(glob.glob(f"{out}/g*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and "End_Timestamp" in r:
+            clk[k][0] += float(r["Counter_Value"])
+            clk[k][1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
 res = {}
 for k, c in agg.items():
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
@@ -34,5 +39,10 @@ for k, c in agg.items():
         e["gui_active"] = sum(c.get("GRBM_GUI_ACTIVE", [0])) / max(1, len(c.get("GRBM_GUI_ACTIVE", [0])))
         if e["gui_active"] > 0:
             e["mfma_busy_frac"] = round(e["mfma_busy_cycles"] / (e["gui_active"] / 8 * 1024), 3)   # 8 XCDs summed; 256 CUs x 4 SIMDs
+        if clk[k][1] > 0:
+            # shader clock while the kernel ran: active cycles per XCD / dispatch time (the counter window is a few us longer than the
+            # dispatch, so this overstates short kernels; meaningful for launches of >= 100 us)
+            e["sclk_ghz_est"] = round(clk[k][0] / 8 / clk[k][1], 3)
+            e["avg_dispatch_us_under_pmc"] = round(clk[k][1] / max(1, len(c.get("GRBM_GUI_ACTIVE", [0]))) / 1e3, 1)
     res[k] = e
 print(json.dumps(res, indent=1))
