@@ -30,7 +30,8 @@ import json, subprocess
 k = json.load(open("$OUT/pmc/kernels.json"))
 out = {"cfg2": {"kernels": k, "provenance": "rocprofv3 --pmc, three separate passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) of "
                 "'bench.py --config cfg2 --others 0 --steps 3 --warmup 1 --sampler_steps 2' (tools/profile_r02.sh); FETCH_SIZE doubled (gfx950, 16-B/lane "
-                "streaming reads: MI355X_MICROARCH.md HBM); bytes averaged over the kernel's launches of 4 train steps + 6 sampler forwards"}}
+                "streaming reads: MI355X_MICROARCH.md HBM); bytes averaged over the kernel's launches of 4 train steps + 6 sampler forwards; "
+                "sclk_ghz_est = GRBM_GUI_ACTIVE per XCD / dispatch time of the same pass (tools/traffic_parse.py)"}}
 json.dump(out, open("profiles/r02_traffic.json", "w"), indent=1)
 PY
 echo "traffic done"
