@@ -450,7 +450,10 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
     const bool ws = forced != 2;
     if (ws) {
         int ns3 = gmk_cu_limit() / ((cout / 64) * (ktot / 64));
-        if (ns3 >= 8) ns3 &= ~7;          // workgroups that stream the same dY / X are ns3 block ids apart: a multiple of 8 keeps them on one XCD
+        if (ns3 >= 8) {                   // workgroups that stream the same dY / X are ns3 block ids apart: a multiple of 8 keeps them on one XCD
+            const int all8 = ns3 & ~7, two = ns3 & ~3;       // (a multiple of 4: on two XCDs) - taken when the CU limit of a data-parallel
+            ns3 = all8 * 16 < ns3 * 15 ? two : all8;      // run (248) would otherwise leave 10 % of the CUs without a workgroup (1.18 -> 1.25 PFLOP/s at 64 x 64)
+        }
         if (ns3 < 1) ns3 = 1;
         if (nchunks < 8 * ns3) ns3 = nchunks / 8 > 0 ? nchunks / 8 : 1;
         const int cps3 = (nchunks + ns3 - 1) / ns3;
