@@ -29,9 +29,6 @@
 // D[channel][pixel] orientation + v_permlane32_swap widening as conv_igemm_dma_kernel).
 #include "gmk_common.h"
 
-#ifndef GMK_HALO_STORE_AUX
-#define GMK_HALO_STORE_AUX 0      // cache policy of the wave-specialised kernel's output stores (experiments: 16 = sc1, write-through)
-#endif
 
 namespace {
 
@@ -58,7 +55,6 @@ struct HaloParams {
     float* stats;                              // optional GroupNorm partial sums [ntiles][8][2][Cout/4][2] (see gmk.h)
     int stats_groups;                          // Cout/4
     int variant;                               // GMK_DEV_VARIANT (experiments)
-    unsigned long long* stamps;                // diagnostic builds only (variant 99): s_memtime per tile, [wg][16 tiles][4]
     float inv_hp2, inv_h, inv_we, inv_w;       // reciprocals for exact small-integer division
 };
 
@@ -363,13 +359,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     issue_w(0, 0, 0);
     issue_w(1, 1, 0);
 
-    int tile_it = 0;
-    auto stamp = [&](int k) {
-        if (p.stamps && tid == 0 && tile_it < 16)
-            p.stamps[((size_t)blockIdx.x * 16 + tile_it) * 4 + k] = __builtin_amdgcn_s_memtime();
-    };
     for (; tile < p.ntiles; tile += gridDim.x) {
-        stamp(0);
         resolve_centres(tile);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -417,14 +407,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                 sq = sq == 2 ? 0 : sq + 1;
             }
             hbuf ^= 1;
-            if (ph == 0) stamp(1);
         }
         asm volatile("" ::: "memory");
-        stamp(2);
         epilogue(tile);
         asm volatile("" ::: "memory");
-        stamp(3);
-        ++tile_it;
         fresh = 2;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the speculative DMA before the LDS is released
@@ -439,7 +425,7 @@ template <int N> struct IntTag { static constexpr int value = N; };
 // 128-pixel x 64-channel quarter of the tile (8 accumulators).  Why: in the kernel above every wave pays the issue cost
 // of 3 LDS-DMA instructions (60-185 cycles each), 16 ds_read_b128 and ~25 address VALU per K-step next to its 16 MFMAs,
 // and with two such waves per SIMD the issue port, not the MFMA pipe, sets the K-step (1430-1570 cycles against 1024 of
-// MFMA time: tools/halo_stamps.py).  Here a SIMD hosts one consumer (32 MFMAs + 24 ds_read_b128 per K-step: 0.75 reads
+// MFMA time, measured with per-tile s_memtime stamps in round 1).  Here a SIMD hosts one consumer (32 MFMAs + 24 ds_read_b128 per K-step: 0.75 reads
 // per MFMA instead of 1) and one producer, w and w+4 share a SIMD, and the consumer's epilogue stores no longer sit in the
 // same vmcnt queue as the DMA (no `fresh` bookkeeping).  One s_barrier per K-step, crossed by all 8 waves.
 template <bool kPrefetchW, int kShape = 32, bool kFuse = false>
@@ -742,24 +728,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     // at barrier q the weight tile of step q+1 (the first 4 ops of step q-1) must have landed — the consumers read its
                     // first fragments before barrier q+1; only the 2 halo pieces issued behind it may still fly.  Tap 0 also needs
                     // the phase's whole halo (all older).
-                    const bool warmed = last_ph && p.residual != nullptr && p.variant != 5;     // tap 7 carried 2 extra (L2 warm-up) loads
+                    const bool warmed = last_ph && p.residual != nullptr;     // tap 7 carried 2 extra (L2 warm-up) loads
                     if (kPrefetchW) {
-                        if ((p.variant >= 20 && p.variant <= 22) || tap == 0 || (tap == 8 && !warmed)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (tap == 0 || (tap == 8 && !warmed)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                     } else {      // only the weight tile of THIS step (issued two steps ago) has to be there
-                        if (p.variant >= 20 && p.variant <= 22) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        else if (tap == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        if (tap == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                         else if (tap == 1 || (tap == 8 && !warmed)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     }
                     if (tap == 0) asm volatile("" :: "v"(pf0), "v"(pf1));         // the warm-up loads' registers stay reserved until here
                     __builtin_amdgcn_s_barrier();
-                    const bool no_w = p.variant == 20 || p.variant == 22, no_f = p.variant == 21 || p.variant == 22;   // timing ablations
-                    if (!no_w) {
-                        if (tap < 7) issue_w(sq, tap + 2, ph, ch);
-                        else issue_w(sq, tap - 7, ph_next, last_ph ? nch : ch);      // the first two weight tiles of the next job
-                    }
-                    if (tap < 7 && !no_f) {
+                    if (tap < 7) issue_w(sq, tap + 2, ph, ch);
+                    else issue_w(sq, tap - 7, ph_next, last_ph ? nch : ch);      // the first two weight tiles of the next job
+                    if (tap < 7) {
                         if (last_ph) resolve_piece(ntile, tap);                  // the next fills belong to the next job's tile (or are zeros)
                         issue_fill(hbuf ^ 1, ph_next, tap);
                     }
@@ -975,7 +957,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     const auto s0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
                     const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rso, live ? row_b + (unsigned)(cb * 16) * ES : kBadOff, 0, GMK_HALO_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rso, live ? row_b + (unsigned)(cb * 16) * ES : kBadOff, 0, 0);
                 }
                 (void)embp;
             }
@@ -1044,18 +1026,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
     // weight-fragment reads of group 0 stand between the wave and its first MFMA.  Two fragment sets alternate per group.
     bf16x8 px[2][4], wt[2][2];
     int rowb[4], sw[4];
-#ifndef GMK_ABLATE
-#define GMK_ABLATE 0
-#endif
-    constexpr bool no_rd = GMK_ABLATE == 23, no_mm = GMK_ABLATE == 24;      // timing-only diagnostic builds (-DGMK_ABLATE=..)
     int st = 0, hbuf = 0;
-    int tile_it = 0;
-    auto stamp = [&](int k) {
-        if (p.stamps && tid == 0 && tile_it < 16)
-            p.stamps[((size_t)blockIdx.x * 16 + tile_it) * 4 + k] = __builtin_amdgcn_s_memtime();
-    };
     auto load_wt = [&](int stg, int kg, int set) {
-        if (no_rd) return;
         const char* Wb = smem + stg * kWST + b_off;
         const int coff = ((kg * 2 + h) ^ swz) << 4;
         wt[set][0] = *reinterpret_cast<const bf16x8*>(Wb + coff);
@@ -1066,7 +1038,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
     auto run_job = [&](auto ni_tag, int tile, int next_boff) {
         constexpr int NI = decltype(ni_tag)::value;
         auto pre = [&](int hb, int tap) {             // addresses of `tap` + its group-0 pixel fragments -> set 0
-            if (no_rd) return;
             const char* Hb = smem + hb * kHB;
             const int tapoff = (tap / 3 - 1) * WE + (tap % 3 - 1), tapoff_n = (tap / 3 - 1) * W + (tap % 3 - 1);
 #pragma unroll
@@ -1081,7 +1052,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 px[0][i] = *reinterpret_cast<const bf16x8*>(Hb + rowb[i] + ((h ^ sw[i]) << 4));
         };
         auto load_px = [&](int hb, int kg, int set) {
-            if (no_rd) return;
             const char* Hb = smem + hb * kHB;
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -1117,11 +1087,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         };
         auto mfma_group = [&](int set, auto fresh_tag) __attribute__((always_inline)) {
             constexpr bool kFresh = decltype(fresh_tag)::value != 0;      // first MFMAs of a job: C = 0, no accumulator re-zeroing anywhere
-            if (no_mm) {
-#pragma unroll
-                for (int i = 0; i < NI; ++i) asm volatile("" :: "v"(px[set][i]), "v"(wt[set][i & 1]));
-                return;
-            }
             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -1218,13 +1183,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q4][1], pk[q4 + 1][1], false, false);
                         u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                         const unsigned off = live ? row_b + (unsigned)(cb + 8 * (q4 + h)) * ES : kBadOff;
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rso, off, 0, GMK_HALO_STORE_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rso, off, 0, 0);
                     }
                 }
             }
         };
 
-        stamp(0);
         // phase 0 is peeled: its first MFMA group starts the accumulators from C = 0 (a compile-time property of the copy; a run-time
         // select of the C operand costs a second set of accumulator registers)
         auto phase = [&](auto first_tag, int ph) __attribute__((always_inline)) {
@@ -1259,12 +1223,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 __builtin_amdgcn_sched_barrier(0);
             }
             hbuf ^= 1;
-            if (ph == 0) stamp(1);
         };
         phase(IntTag<1>{}, 0);
         for (int ph = 1; ph < nph; ++ph) phase(IntTag<0>{}, ph);
         asm volatile("" ::: "memory");
-        stamp(2);
         // the epilogue is bound by store issue: it also re-zeroes the accumulators (and the caller resolves the next tile's pixel
         // rows) in that shadow, so the next tile starts on its first barrier
         epilogue();
@@ -1289,27 +1251,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         if (nhc != hc) set_geometry(nhc);                  // whole -> half happens at most once, before the last job
         resolve_centres(ntile);
         asm volatile("" ::: "memory");
-        stamp(3);
-        ++tile_it;
     }
-#ifdef GMK_TS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every output store of this wave is complete
-    if (lane == 0) atomicMax(&g_ts.end[ts_slot(p.out)], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#endif
 }
 
 }  // namespace
 
-// Returns 1 (8-compute-wave kernel) or 2 (wave-specialised kernel) if a halo kernel was launched, 0 if the problem is not eligible (caller falls back), <0 / >0 on error.
-int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int B, int H, int W, const void* w, int w_rows,
-                         int n0, int cout, const float* bias, const float* emb, int emb_stride, const void* residual,
-                         void* out, int out_cstride, int min_tiles, int upsample, float* stats, int64_t stats_bytes,
-                         const float* gn_scale, const float* gn_shift, int gn_stride, hipStream_t stream) {
+// The ONE eligibility rule of the halo kernels (gmk_conv3x3_halo_try launches by it, gmk_conv_gn_fusable answers by it): geometry of
+// the tiling, LDS capacity, 32-bit buffer offsets, enough tiles to fill the chip; fused_gn adds the conditions of the in-kernel
+// GroupNorm-apply (plain 3x3 only, a tile of R rows of the global row list touches at most two samples).
+int gmk_halo_geometry(int B, int H, int W, int c0, int c1, int w_rows, int cout, int out_cstride, int min_tiles, int upsample,
+                      int fused_gn, HaloGeometry* g) {
     if (c0 % 64 || c1 % 64 || cout % 128) return 0;
     if (W < 4 || W > 254 || H < 2) return 0;
     const int R = 256 / W;
     if (R < 1) return 0;
-    const int TP = R * W;
     const int crossings = H % R == 0 ? 0 : (R - 1 + H - 1) / H;   // image boundaries a tile of R rows can span (none if tiles align)
     const int ner = R + 2 + 2 * crossings;
     if (ner * (W + 2) > kHaloSlots) return 0;
@@ -1323,6 +1278,25 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     if (nb0 >= lim || nb1 >= lim || nbw >= lim || nbo >= lim || M >= 0x00FFFFFF || c0 > 2048 || c1 > 2048) return 0;
     const int64_t ntiles = (rows_total + R - 1) / R;
     if (ntiles < min_tiles) return 0;                         // not enough tiles to fill the chip: im2col kernels
+    if (fused_gn && (upsample || R > H)) return 0;
+    if (g) {
+        g->R = R; g->TP = R * W; g->rows_total = rows_total; g->M = M; g->ntiles = ntiles;
+        g->nb0 = nb0; g->nb1 = nb1; g->nbw = nbw; g->nbo = nbo;
+    }
+    return 1;
+}
+
+// Returns 1 (8-compute-wave kernel) or 2 (wave-specialised kernel) if a halo kernel was launched, 0 if the problem is not eligible (caller falls back), <0 / >0 on error.
+int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int B, int H, int W, const void* w, int w_rows,
+                         int n0, int cout, const float* bias, const float* emb, int emb_stride, const void* residual,
+                         void* out, int out_cstride, int min_tiles, int upsample, float* stats, int64_t stats_bytes,
+                         const float* gn_scale, const float* gn_shift, int gn_stride, hipStream_t stream) {
+    HaloGeometry g;
+    if (!gmk_halo_geometry(B, H, W, c0, c1, w_rows, cout, out_cstride, min_tiles, upsample, gn_scale != nullptr, &g)) return 0;
+    if (gn_scale && (!gn_shift || gn_stride < c0 + c1)) return 0;
+    const int R = g.R, TP = g.TP;
+    const int64_t rows_total = g.rows_total, M = g.M, ntiles = g.ntiles;
+    const int64_t nb0 = g.nb0, nb1 = g.nb1, nbw = g.nbw, nbo = g.nbo;
     HaloParams p;
     p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.ktot = c0 + c1;
     p.shift = upsample ? 1 : 0; p.pmask = upsample == 2 ? 1 : 0;      // upsample: 1 nearest x2, 2 zero-stuffed x2 (transposed conv)
@@ -1332,13 +1306,8 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     p.M = (int)M;
     p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1; p.nbw = (unsigned)nbw; p.nbo = (unsigned)nbo;
     p.gn_scale = gn_scale; p.gn_shift = gn_shift; p.gn_stride = gn_stride;
-    // fused GroupNorm-apply: plain 3x3 only, and a tile (R rows of the global row list) may touch at most two samples
-    if (gn_scale && (upsample || R > H || !gn_shift || gn_stride < c0 + c1)) return 0;
     p.stats = nullptr; p.stats_groups = out_cstride / 4;
-    const int dev = gmk_kernel_choice(3, "GMK_DEV_VARIANT");    // low byte: code variant; 0x100: write per-tile s_memtime stamps
-    p.variant = dev & 0xFF;
-    p.stamps = nullptr;
-    if ((dev & 0x100) && stats && stats_bytes >= 256 * 16 * 4 * 8) { p.stamps = (unsigned long long*)stats; stats = nullptr; }
+    p.variant = gmk_kernel_choice(3, "GMK_DEV_VARIANT") & 0xFF;      // code variant (A/B switches, see below)
     if (stats && cout == out_cstride && stats_bytes >= ntiles * 8 * 2 * (int64_t)(out_cstride / 4) * 2 * 4 && H * W >= 32) p.stats = stats;
     p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 2); p.inv_w = 1.0f / (float)W;
     const int ncu = gmk_cu_limit();

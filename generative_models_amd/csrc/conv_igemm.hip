@@ -977,17 +977,10 @@ extern "C" int gmk_conv1x1_pair(const void* src, int c, int B, int H, int W, con
 
 // 1 if gmk_conv_igemm(ksize 3, GMK_CONV_NORMAL, bf16) of this shape runs on the halo kernel AND can apply a GroupNorm to its source
 extern "C" int gmk_conv_gn_fusable(int B, int H, int W, int c0, int c1, int cout) {
-    if (c0 % 64 || c1 % 64 || cout % 128 || W < 4 || W > 254 || H < 2) return 0;
-    const int R = 256 / W;
-    if (R < 1 || R > H) return 0;
-    const int crossings = H % R == 0 ? 0 : (R - 1 + H - 1) / H;
-    if ((R + 2 + 2 * crossings) * (W + 2) > 448) return 0;
-    const int64_t rows_total = (int64_t)B * H, M = rows_total * W;
-    const int64_t lim = 0xFFFF0000ll;
-    if (M * c0 * 2 >= lim || M * c1 * 2 >= lim || M * cout * 2 >= lim || M >= 0x00FFFFFF) return 0;
-    if ((rows_total + R - 1) / R < 32) return 0;
     const int force = gmk_kernel_choice(0, "GMK_CONV_KERNEL");
-    return force == 0 || force == 3;
+    if (force != 0 && force != 3) return 0;
+    // the same rule gmk_conv_igemm applies when it hands the launch to the halo kernel (weights [9][cout][c0 + c1], dense output)
+    return gmk_halo_geometry(B, H, W, c0, c1, cout, cout, cout, force == 3 ? 1 : 32, 0, 1, nullptr);
 }
 
 extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B,

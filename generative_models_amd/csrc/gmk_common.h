@@ -37,19 +37,15 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
                          void* out, int out_cstride, int min_tiles, int upsample, float* stats, int64_t stats_bytes,
                          const float* gn_scale, const float* gn_shift, int gn_stride, hipStream_t stream);
 
+struct HaloGeometry { int R, TP; int64_t rows_total, M, ntiles, nb0, nb1, nbw, nbo; };
+int gmk_halo_geometry(int B, int H, int W, int c0, int c1, int w_rows, int cout, int out_cstride, int min_tiles, int upsample,
+                      int fused_gn, HaloGeometry* g);      // conv_halo.hip: 1 if the halo kernels take this problem (g filled), else 0
+
 // conv_wgrad_slots.hip: 3x3 stride-1 bf16 weight gradient over padded slots; returns the number of slabs written or 0
 int gmk_wgrad_slots_nsplit(int cout, int ktot);
 int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B, int H,
                              int W, int cout, float* slab, int64_t slab_bytes, int forced, int upsample, hipStream_t stream);
 
-#ifdef GMK_TS
-// diagnostic builds (tools/kernel_overlap.py): per-tensor time stamps (s_memrealtime, 100 MHz, chip-wide): the producing halo
-// convolution leaves the time its last store was complete, the consuming GroupNorm the time each workgroup started
-constexpr int kTsSlots = 256, kTsBlocks = 2048;
-struct GmkTs { unsigned long long end[kTsSlots]; unsigned long long start[kTsSlots][kTsBlocks]; };
-extern __device__ GmkTs g_ts;
-__device__ __forceinline__ int ts_slot(const void* p) { return (int)(((uintptr_t)p >> 12) & (kTsSlots - 1)); }
-#endif
 
 static inline hipStream_t gmk_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int gmk_esize(int dtype) { return dtype == GMK_BF16 ? 2 : 4; }
@@ -127,13 +123,10 @@ __device__ __forceinline__ void philox4x32(uint64_t ctr, uint64_t seed, uint32_t
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // [0, 1)
 
 
-// Cross-lane steps WITHOUT ds_bpermute.  `__shfl_xor` lowers to ds_bpermute_b32, which runs through the LDS crossbar.  Round 1 saw a
-// wave reduction built on it come out wrong in situ (GroupNorm statistics of one 64-channel slab, about every second U-Net forward)
-// while workgroups of conv_igemm_kernel (64 KiB LDS, ds_write_b128 staging) were resident on the same CU from another HIP
-// stream; DESIGN.md section 5 has what is and is not established about it (tools/side_stream_det.py reproduces it on a
-// -DGMK_SHFL_BPERMUTE build, tools/gn_xcheck.py compares both reductions on the same registers inside one kernel).  DPP inside a
+// Cross-lane reductions WITHOUT ds_bpermute (`__shfl_xor` lowers to ds_bpermute_b32, which runs through the LDS crossbar): DPP inside a
 // 16-lane row and v_permlane{16,32}_swap across rows never touch the LDS pipeline, pair the same lanes as the xor butterfly
-// (bit-identical sums), and are faster - that is reason enough to use them everywhere.
+// (bit-identical sums) and are faster.  DESIGN.md section 5 records the round-1/2 investigation of a GroupNorm miscompare that only a
+// ds_bpermute build showed, including what the ISA of both builds looks like; no kernel in csrc/ uses ds_bpermute.
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -147,13 +140,7 @@ __device__ __forceinline__ void halves_swap32(float& a, float& b) { asm volatile
 // sum over the lanes whose index differs in bits >= log2(FROM) (FROM = 1: whole wave; FROM = 8: lanes sharing lane & 7); every
 // lane ends with its total.  Same pairing as the butterfly `for off = 32 .. FROM: v += shfl_xor(v, off)`.
 template <int FROM>
-__device__ __forceinline__ float lanes_sum_from_bpermute(float v) {      // the ds_bpermute butterfly: diagnostic builds only
-#pragma unroll
-    for (int off = 32; off >= FROM; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-template <int FROM>
-__device__ __forceinline__ float lanes_sum_from_dpp(float v) {
+__device__ __forceinline__ float lanes_sum_from(float v) {
     float a = v, b = v;
     halves_swap32(a, b); v = a + b;
     a = v; b = v;
@@ -163,14 +150,6 @@ __device__ __forceinline__ float lanes_sum_from_dpp(float v) {
     if (FROM <= 2) v += dpp_f32<0x4E>(v);       // quad_perm [2,3,0,1]
     if (FROM <= 1) v += dpp_f32<0xB1>(v);       // quad_perm [1,0,3,2]
     return v;
-}
-template <int FROM>
-__device__ __forceinline__ float lanes_sum_from(float v) {
-#ifdef GMK_SHFL_BPERMUTE
-    return lanes_sum_from_bpermute<FROM>(v);
-#else
-    return lanes_sum_from_dpp<FROM>(v);
-#endif
 }
 // 64-lane wave sum / max (every lane ends with the result)
 __device__ __forceinline__ float wave_sum(float v) { return lanes_sum_from<1>(v); }

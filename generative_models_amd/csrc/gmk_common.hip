@@ -61,15 +61,3 @@ int gmk_cu_limit(void) {
 }
 extern "C" int gmk_get_cu_limit(void) { return gmk_cu_limit(); }
 
-#ifdef GMK_TS
-__device__ GmkTs g_ts;
-extern "C" int gmk_debug_ts(void* host_out, int reset) {      // host_out: sizeof(GmkTs) bytes
-    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ts), sizeof(GmkTs));
-    if (e == hipSuccess && reset) {
-        void* p = nullptr;
-        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_ts));
-        if (e == hipSuccess) e = hipMemset(p, 0, sizeof(GmkTs));
-    }
-    return (int)e;
-}
-#endif

@@ -280,19 +280,6 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
 // ------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-#ifdef GMK_GN_XCHECK
-__device__ unsigned g_gn_xcheck[16 + 8 * 16];       // [0] mismatching lanes, [1] waves checked, then 8 records of 16 words
-#if GMK_GN_XCHECK == 3
-// stage checksums per (launch slot, workgroup): [0] xor of the loaded input dwords, [1] xor of the per-lane partial sums,
-// [2] xor of the reduced totals the wave hands to LDS, [3] xor of the group statistics read back from LDS
-constexpr int kXSlots = 64, kXBlocks = 4096;
-__device__ unsigned g_gn_stage[kXSlots * kXBlocks * 4];
-#ifndef GMK_GN_XSTAGE_EARLY
-#define GMK_GN_XSTAGE_EARLY 0
-#endif
-__device__ unsigned g_gn_late[kXSlots * kXBlocks];      // GMK_GN_XSTAGE_EARLY: input checksum recomputed at the kernel's end
-#endif
-#endif
 
 __device__ __forceinline__ void unpack8(const u32x4_t r, float (&v)[8]) {
 #pragma unroll
@@ -321,9 +308,6 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
     const int vec = tid & (NVEC - 1), pl = tid >> LOGV;
     int b, slab;
     slab_of_block(blockIdx.x, C / CS, B, b, slab);
-#ifdef GMK_TS
-    if (tid == 0 && blockIdx.x < kTsBlocks) g_ts.start[ts_slot(x)][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-#endif
     const int cpg = C / G, c0 = slab * CS, g0 = c0 / cpg, gps = CS / cpg;
     const size_t base = (size_t)b * HW * C + c0 + vec * 8;
     u32x4_t raw[ITER];
@@ -332,20 +316,8 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
     for (int i = 0; i < ITER; ++i) {
         const int p = pl + i * planes;
         ok[i] = pl < planes && p < HW;
-#ifdef GMK_GN_LOAD_SC          // experiment: system-scope loads (bypass this CU's L1 and this XCD's L2)
-        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(raw[i]) : "v"(ok[i] ? x + base + (size_t)p * C : x) : "memory");
-#else
         raw[i] = ok[i] ? *reinterpret_cast<const u32x4_t*>(x + base + (size_t)p * C) : u32x4_t{0u, 0u, 0u, 0u};
-#endif
     }
-#ifdef GMK_GN_LOAD_SC
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < ITER; ++i) asm volatile("" : "+v"(raw[i]));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < ITER; ++i) if (!ok[i]) raw[i] = u32x4_t{0u, 0u, 0u, 0u};
-#endif
     float ea[8];           // per-(sample, channel) addend applied to x on load (conv bias + embedding broadcast of the producer)
 #pragma unroll
     for (int k = 0; k < 8; ++k) ea[k] = xadd ? xadd[(size_t)b * xadd_stride + c0 + vec * 8 + k] : 0.f;
@@ -361,67 +333,11 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
         s1 += (v[4] + v[5]) + (v[6] + v[7]);
         q1 += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
     }
-#if defined(GMK_GN_XCHECK) && GMK_GN_XCHECK == 3
-    unsigned xk_in = 0, xk_part, xk_tot = 0, xk_stat = 0;
-#pragma unroll
-    for (int i = 0; i < ITER; ++i) xk_in ^= raw[i][0] ^ (raw[i][1] * 3u) ^ (raw[i][2] * 5u) ^ (raw[i][3] * 7u);
-    xk_part = __builtin_bit_cast(unsigned, s0) ^ (__builtin_bit_cast(unsigned, q0) * 3u) ^ (__builtin_bit_cast(unsigned, s1) * 5u) ^
-              (__builtin_bit_cast(unsigned, q1) * 7u);
-#if GMK_GN_XSTAGE_EARLY        // leave the first two checksums in memory BEFORE the cross-lane reduction touches anything
-    {
-        const unsigned slot_e = (unsigned)(((uintptr_t)mean >> 9) & (kXSlots - 1));
-        unsigned* re = g_gn_stage + ((size_t)slot_e * kXBlocks + (blockIdx.x & (kXBlocks - 1))) * 4;
-        atomicXor(re + 0, xk_in); atomicXor(re + 1, xk_part);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#endif
-#endif
     // keep the pixels PACKED across the reduction (the apply sweep unpacks again): otherwise the compiler carries all 8*ITER
     // floats through the barrier and the register count halves the occupancy
 #pragma unroll
     for (int i = 0; i < ITER; ++i) asm volatile("" : "+v"(raw[i]));
-#if defined(GMK_GN_XCHECK) && GMK_GN_XCHECK == 2
-    // diagnostic build 2 (least perturbing): the reduction as shipped / as -DGMK_SHFL_BPERMUTE selects, then ONE DPP compare per
-    // total: after a correct butterfly lanes l and l ^ 8 hold bit-identical totals (a + b == b + a at every stage)
     s0 = vec_lane_sum<NVEC>(s0); q0 = vec_lane_sum<NVEC>(q0); s1 = vec_lane_sum<NVEC>(s1); q1 = vec_lane_sum<NVEC>(q1);
-    {
-        const float o[4] = {dpp_f32<0x128>(s0), dpp_f32<0x128>(q0), dpp_f32<0x128>(s1), dpp_f32<0x128>(q1)};
-        if (o[0] != s0 || o[1] != q0 || o[2] != s1 || o[3] != q1) {
-            const unsigned n = atomicAdd(&g_gn_xcheck[0], 1u);
-            if (n < 8) {
-                unsigned* r = g_gn_xcheck + 16 + n * 16;
-                r[0] = blockIdx.x; r[1] = tid; r[2] = HW; r[3] = NVEC;
-                const float mine[4] = {s0, q0, s1, q1};
-                for (int k = 0; k < 4; ++k) { r[4 + k] = __builtin_bit_cast(unsigned, mine[k]); r[8 + k] = __builtin_bit_cast(unsigned, o[k]); r[12 + k] = 0; }
-            }
-        }
-        if (lane == 0) atomicAdd(&g_gn_xcheck[1], 1u);
-    }
-#elif defined(GMK_GN_XCHECK)
-    {   // diagnostic build: both reductions on the SAME per-lane inputs; any lane where they disagree is recorded (first 8 in full)
-        const float in[4] = {s0, q0, s1, q1};
-        float vb[4], vd[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { vb[k] = lanes_sum_from_bpermute<NVEC>(in[k]); vd[k] = lanes_sum_from_dpp<NVEC>(in[k]); }
-        const bool bad = vb[0] != vd[0] || vb[1] != vd[1] || vb[2] != vd[2] || vb[3] != vd[3];
-        if (bad) {
-            const unsigned n = atomicAdd(&g_gn_xcheck[0], 1u);
-            if (n < 8) {
-                unsigned* r = g_gn_xcheck + 16 + n * 16;
-                r[0] = blockIdx.x; r[1] = tid; r[2] = HW; r[3] = NVEC;
-                for (int k = 0; k < 4; ++k) { r[4 + k] = __builtin_bit_cast(unsigned, vb[k]); r[8 + k] = __builtin_bit_cast(unsigned, vd[k]); r[12 + k] = __builtin_bit_cast(unsigned, in[k]); }
-            }
-        }
-        atomicAdd(&g_gn_xcheck[1], lane == 0 ? 1u : 0u);       // waves checked
-        s0 = vb[0]; q0 = vb[1]; s1 = vb[2]; q1 = vb[3];          // the kernel goes on with the ds_bpermute results
-    }
-#else
-    s0 = vec_lane_sum<NVEC>(s0); q0 = vec_lane_sum<NVEC>(q0); s1 = vec_lane_sum<NVEC>(s1); q1 = vec_lane_sum<NVEC>(q1);
-#endif
-#if defined(GMK_GN_XCHECK) && GMK_GN_XCHECK == 3
-    if (lane < NVEC) xk_tot = __builtin_bit_cast(unsigned, s0) ^ (__builtin_bit_cast(unsigned, q0) * 3u) ^ (__builtin_bit_cast(unsigned, s1) * 5u) ^
-                              (__builtin_bit_cast(unsigned, q1) * 7u);
-#endif
     if (lane < NVEC) { red[wave][lane][0] = s0; red[wave][lane][1] = q0; red[wave][lane][2] = s1; red[wave][lane][3] = q1; }
     __syncthreads();
     if (tid < gps) {
@@ -463,30 +379,8 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = siluf_(fmaf(v[k], sc[k], sh[k]));
         if (drop_p > 0.f) drop8(v, base + (size_t)p * C, drop_p, drop_seed, drop_off);
-#ifdef GMK_GN_NOSTORE          // timing-only build: what a statistics-only GroupNorm launch would cost (upper bound of fusing the apply)
-        asm volatile("" :: "v"(v[0]), "v"(v[7]));
-#else
         store8(y + base + (size_t)p * C, v);
-#endif
     }
-#if defined(GMK_GN_XCHECK) && GMK_GN_XCHECK == 3
-    {   // all diagnostics at the very end, so that the kernel's timing up to its stores is the shipped one
-        if (tid < 8) xk_stat = __builtin_bit_cast(unsigned, smean[tid]) ^ (__builtin_bit_cast(unsigned, srstd[tid]) * 3u);
-        const unsigned slot = (unsigned)(((uintptr_t)mean >> 9) & (kXSlots - 1));
-        unsigned* r = g_gn_stage + ((size_t)slot * kXBlocks + (blockIdx.x & (kXBlocks - 1))) * 4;
-#if !GMK_GN_XSTAGE_EARLY
-        atomicXor(r + 0, xk_in); atomicXor(r + 1, xk_part);
-#else
-        // the same two checksums recomputed from the registers as they are NOW (after the reduction, the barriers and the apply sweep)
-        unsigned late = 0;
-#pragma unroll
-        for (int i = 0; i < ITER; ++i) late ^= raw[i][0] ^ (raw[i][1] * 3u) ^ (raw[i][2] * 5u) ^ (raw[i][3] * 7u);
-        atomicXor(g_gn_late + ((size_t)slot * kXBlocks + (blockIdx.x & (kXBlocks - 1))), late);
-#endif
-        if (lane < NVEC) atomicXor(r + 2, xk_tot * (unsigned)(wave * 8 + lane + 1));
-        if (tid < 8) atomicXor(r + 3, xk_stat * (unsigned)(tid + 1));
-    }
-#endif
 }
 
 // (A backward kernel with the same residency — x and dy packed in registers, both sweeps from them — was built and measured
@@ -980,34 +874,3 @@ extern "C" int gmk_sumpool2x2(const void* x, void* y, int B, int H, int W, int C
     return gmk_check_launch("gmk_sumpool2x2");
 }
 
-#ifdef GMK_GN_XCHECK
-// diagnostic builds only (tools/gn_xcheck.py): copy out / reset the cross-check record of gn_silu_fwd_reg_kernel
-extern "C" int gmk_debug_gn_xcheck(unsigned* host_out, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gn_xcheck), sizeof(unsigned) * (16 + 8 * 16));
-    if (e == hipSuccess && reset) {
-        static const unsigned zeros[16 + 8 * 16] = {};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_gn_xcheck), zeros, sizeof(zeros));
-    }
-    return (int)e;
-}
-#if GMK_GN_XCHECK == 3
-extern "C" int gmk_debug_gn_late(unsigned* host_out, int reset) {       // host_out: kXSlots * kXBlocks words
-    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gn_late), sizeof(unsigned) * kXSlots * kXBlocks);
-    if (e == hipSuccess && reset) {
-        void* p = nullptr;
-        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_gn_late));
-        if (e == hipSuccess) e = hipMemset(p, 0, sizeof(unsigned) * kXSlots * kXBlocks);
-    }
-    return (int)e;
-}
-extern "C" int gmk_debug_gn_stage(unsigned* host_out, int reset) {      // host_out: kXSlots * kXBlocks * 4 words
-    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gn_stage), sizeof(unsigned) * kXSlots * kXBlocks * 4);
-    if (e == hipSuccess && reset) {
-        void* p = nullptr;
-        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_gn_stage));
-        if (e == hipSuccess) e = hipMemset(p, 0, sizeof(unsigned) * kXSlots * kXBlocks * 4);
-    }
-    return (int)e;
-}
-#endif
-#endif

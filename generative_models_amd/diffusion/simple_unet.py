@@ -438,8 +438,6 @@ class SimpleUnet(nn.Module):
             self._side = torch.cuda.Stream(device=tensors[0].device)
         side = self._side
         side.wait_stream(torch.cuda.current_stream())
-        if ops.SIDE_DUMMY:          # experiment (tools/side_stream_det.py): a no-op kernel as the first dispatch behind the event marker
-            ops.rng_uniform((4,), 0, 0, tensors[0].device)
         with torch.cuda.stream(side):
             fn()
         for t in tensors:

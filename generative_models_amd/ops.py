@@ -126,7 +126,6 @@ def pack_conv_weights_multi(arena, packs, table):
 # measured on MI355X the DPP reductions in the conv epilogue cost as much as the statistics pass they save (27.25 vs
 # 27.19 ms/step), and with it a sample's result depends (in the last bits) on which tile neighbours it had.
 GN_STATS = False
-SIDE_DUMMY = os.environ.get("GMK_SIDE_DUMMY", "0") == "1"      # experiment switch, see simple_unet._on_side
 GN_FUSE = os.environ.get("GMK_GN_FUSE", "1") != "0"            # inference: GroupNorm-apply + SiLU inside the consuming convolution (simple_unet._res_fwd)
 # ... where it pays (tools/fuse_ab.py, B x HW = 1 M pixels): at 64 x 64 the statistics-only launch + fused convolution take 1,497 us against
 # 1,658 us for GroupNorm + convolution (-10 %); at 32 x 32 / 28 x 28 the producer waves' transform (224 VALU issue slots per K-step

@@ -1,9 +1,7 @@
 """Repeats one U-Net forward (B=1024, 1x28x28, bf16) with the side stream on and compares the outputs bit for bit.
 
-This is the reproducer of the ds_bpermute fault noted in csrc/gmk_common.h: with libgmk built with -DGMK_SHFL_BPERMUTE (wave
-reductions on `__shfl_xor` = ds_bpermute_b32) about half of the forwards differ from the first one (one 64-channel GroupNorm
-slab of one or two samples gets slightly wrong statistics in up.seq.0.0, while the 1x1 skip convolution runs beside it on the
-side stream); with the DPP / permlane reductions every run is identical.  Usage: python tools/side_stream_det.py [runs]"""
+Rounds 1-2 used it to chase a miscompare that only a build with ds_bpermute wave reductions showed; the
+shipped kernels (DPP / permlane reductions) give identical runs, and tests/test_gpu_fullsize.py keeps that as a regression test.  Usage: python tools/side_stream_det.py [runs]"""
 import sys
 import torch
 sys.path.insert(0, ".")
