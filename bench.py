@@ -45,7 +45,7 @@ CONFIGS = {      # name -> (in_channels, size, per-GPU batch, attention, BASELIN
     "cfg1": (1, 28, 1024, 0, "configs[1]: DDPM MNIST 28x28x1, bs=1024, T=1000, bf16, 1xMI355X"),
     "cfg2": (3, 32, 2048, 0, "configs[2]: DDPM 32x32x3, bs=2048, T=1000, 1xMI355X"),
     "cfg3": (3, 64, 1024, 0, "configs[3]: DDPM 64x64x3, bs=8192 over 8 GPUs = 1024 per GPU"),
-    "cfg4": (3, 64, 512, 1, "configs[4]: DDPM 64x64x3 + self-attention, bs=4096 over 8 GPUs = 512 per GPU"),
+    "cfg4": (3, 64, 512, 2, "configs[4]: DDPM 64x64x3 + self-attention (fp8 MFMA), bs=4096 over 8 GPUs = 512 per GPU"),
 }
 KERNEL_DESC = {
     "conv3x3_halo_ws_kernel": "3x3 stride-1 bf16 convolution, LDS-resident halo, wave-specialised (forward + data gradients)",
@@ -259,7 +259,7 @@ class Bench:
         prof = None if a.no_profile else []
         elapsed, nprof = self.timed_steps(model, batches, steps, prof)
         ips = self.world * B * steps / elapsed
-        out = {"workload": f"DDPM train step, {cin}x{S}x{S} images, SimpleUnet C=128{' + self-attention' if attention else ''}, "
+        out = {"workload": f"DDPM train step, {cin}x{S}x{S} images, SimpleUnet C=128{' + self-attention' + (' (fp8 QK^T / PV)' if attention == 2 else '') if attention else ''}, "
                            f"per-GPU batch {B}, T=1000 (BASELINE.json {what})",
                "value": round(ips, 1), "unit": "images/s", "steps": steps, "warmup": warmup,
                "ms_per_step": round(elapsed / steps * 1e3, 3), "global_batch": self.world * B}

@@ -70,7 +70,10 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 
 __device__ __forceinline__ int div_small(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
 
+template <typename T>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p) {
+    typedef typename Frag16<T>::type frag_t;
+    typedef typename Frag16<T>::half_type half_t;
     constexpr int ES = 2;
     __shared__ __attribute__((aligned(16))) char smem[kWOFF + 3 * kWST];
 
@@ -205,17 +208,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
         }
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
-            bf16x8 px[2], wt[2];
-            px[0] = *reinterpret_cast<const bf16x8*>(Hb + rowb[0] + (((kg * 2 + h) ^ sw[0]) << 4));
-            px[1] = *reinterpret_cast<const bf16x8*>(Hb + rowb[1] + (((kg * 2 + h) ^ sw[1]) << 4));
+            frag_t px[2], wt[2];
+            px[0] = *reinterpret_cast<const frag_t*>(Hb + rowb[0] + (((kg * 2 + h) ^ sw[0]) << 4));
+            px[1] = *reinterpret_cast<const frag_t*>(Hb + rowb[1] + (((kg * 2 + h) ^ sw[1]) << 4));
             const int coff = ((kg * 2 + h) ^ swz) << 4;
-            wt[0] = *reinterpret_cast<const bf16x8*>(Wb + coff);
-            wt[1] = *reinterpret_cast<const bf16x8*>(Wb + 4096 + coff);
+            wt[0] = *reinterpret_cast<const frag_t*>(Wb + coff);
+            wt[1] = *reinterpret_cast<const frag_t*>(Wb + 4096 + coff);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[j], px[i], acc[j][i], 0, 0, 0);
+                    acc[j][i] = mfma_32x32x16<T>(wt[j], px[i], acc[j][i]);
         }
     };
 
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                 if (p.residual) {
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-                        const bf16x4 rb = __builtin_bit_cast(bf16x4, resv[i][j][q4]);
+                        const half_t rb = __builtin_bit_cast(half_t, resv[i][j][q4]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[4 * q4 + e] += (float)rb[e];
                     }
@@ -295,9 +298,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                 unsigned pk[4][2];
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    bf16x4 t = {(bf16_t)v[4 * q4], (bf16_t)v[4 * q4 + 1], (bf16_t)v[4 * q4 + 2], (bf16_t)v[4 * q4 + 3]};
-                    const auto u = __builtin_bit_cast(u32x2_t, t);
-                    pk[q4][0] = u[0]; pk[q4][1] = u[1];
+                    pk[q4][0] = pack_pair<T>(sat16<T>(v[4 * q4]), sat16<T>(v[4 * q4 + 1]));
+                    pk[q4][1] = pack_pair<T>(sat16<T>(v[4 * q4 + 2]), sat16<T>(v[4 * q4 + 3]));
                 }
                 if (p.stats) {
                     // per-lane sum / sum of squares of the ROUNDED values of each 4-channel unit, reduced over the group's
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                     float lo[4][2], hi[4][2];
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-                        const bf16x4 t = __builtin_bit_cast(bf16x4, (u32x2_t){pk[q4][0], pk[q4][1]});
+                        const half_t t = __builtin_bit_cast(half_t, (u32x2_t){pk[q4][0], pk[q4][1]});
                         const float a0 = (float)t[0], a1 = (float)t[1], a2 = (float)t[2], a3 = (float)t[3];
                         const float sm = live ? (a0 + a1) + (a2 + a3) : 0.f;
                         const float sq = live ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.f;
@@ -428,8 +430,10 @@ template <int N> struct IntTag { static constexpr int value = N; };
 // MFMA time, measured with per-tile s_memtime stamps in round 1).  Here a SIMD hosts one consumer (32 MFMAs + 24 ds_read_b128 per K-step: 0.75 reads
 // per MFMA instead of 1) and one producer, w and w+4 share a SIMD, and the consumer's epilogue stores no longer sit in the
 // same vmcnt queue as the DMA (no `fresh` bookkeeping).  One s_barrier per K-step, crossed by all 8 waves.
-template <bool kPrefetchW, int kShape = 32, bool kFuse = false>
+template <typename T, bool kPrefetchW, int kShape = 32, bool kFuse = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParams p) {
+    typedef typename Frag16<T>::type frag_t;
+    typedef typename Frag16<T>::half_type half_t;
     constexpr int ES = 2;
     __shared__ __attribute__((aligned(16))) char smem[kWOFF + 3 * kWST];
 
@@ -593,7 +597,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 u32x4 o;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    const float x0 = __builtin_bit_cast(float, raw[w] << 16), x1 = __builtin_bit_cast(float, raw[w] & 0xFFFF0000u);
+                    float x0, x1;
+                    unpack_pair<T>(raw[w], x0, x1);
                     const int h0 = (2 * w) >> 2, l0 = (2 * w) & 3, l1 = l0 + 1;
                     float a0, c0, a1, c1;
                     if (kSel == 0) { a0 = Csc[0][h0][l0]; c0 = Csh[0][h0][l0]; a1 = Csc[0][h0][l1]; c1 = Csh[0][h0][l1]; }
@@ -605,9 +610,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     const float t0 = fmaf(x0, a0, c0), t1 = fmaf(x1, a1, c1);
                     const float y0 = t0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t0 * kNegLog2e));
                     const float y1 = t1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t1 * kNegLog2e));
-                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-                    const bf16x2 pk = {(bf16_t)y0, (bf16_t)y1};
-                    o[w] = valid ? __builtin_bit_cast(unsigned, pk) : 0u;
+                    o[w] = valid ? pack_pair<T>(y0, y1) : 0u;
                 }
                 return o;
             };
@@ -807,14 +810,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         f32x4 acc[8][4];          // [channel block][pixel block]
         const int swz = (r16 >> 1) & 7;          // weight rows 16 cb + r16: (row >> 1) & 7 does not depend on cb
         int b_off = 0;                           // LDS offset of this lane's weight row 0 of the job's channel range
-        bf16x8 px[2][4], wt[2][2];
+        frag_t px[2][4], wt[2][2];
         int rowb[4], sw[4];
         int st = 0, hbuf = 0;
         auto load_wt = [&](int stg, int k2, int pair, int set) {
             const char* Wb = smem + stg * kWST + b_off + pair * 4096;
             const int coff = ((k2 * 4 + q) ^ swz) << 4;
-            wt[set][0] = *reinterpret_cast<const bf16x8*>(Wb + coff);
-            wt[set][1] = *reinterpret_cast<const bf16x8*>(Wb + 2048 + coff);
+            wt[set][0] = *reinterpret_cast<const frag_t*>(Wb + coff);
+            wt[set][1] = *reinterpret_cast<const frag_t*>(Wb + 2048 + coff);
         };
         auto run_job = [&](auto ncb_tag, int tile, int chalf, int next_boff) {
             constexpr int NCB = decltype(ncb_tag)::value;          // 8: whole job, 4: half job
@@ -833,7 +836,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 const char* Hb = smem + hb * kHB;
 #pragma unroll
                 for (int i = i0; i < i1; ++i)
-                    px[set][i] = *reinterpret_cast<const bf16x8*>(Hb + rowb[i] + (((k2 * 4 + q) ^ sw[i]) << 4));
+                    px[set][i] = *reinterpret_cast<const frag_t*>(Hb + rowb[i] + (((k2 * 4 + q) ^ sw[i]) << 4));
             };
             auto mfma_group = [&](int pair, int wset, int pset, auto fresh_tag) __attribute__((always_inline)) {
                 constexpr bool kFresh = decltype(fresh_tag)::value != 0;
@@ -842,7 +845,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        acc[2 * pair + j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[wset][j], px[pset][i], kFresh ? z : acc[2 * pair + j][i], 0, 0, 0);
+                        acc[2 * pair + j][i] = mfma_16x16x32<T>(wt[wset][j], px[pset][i], kFresh ? z : acc[2 * pair + j][i]);
             };
             auto phase = [&](auto first_tag, int ph) __attribute__((always_inline)) {
                 constexpr int kFirst = decltype(first_tag)::value;
@@ -946,14 +949,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         const u32x4 R = rres[cb];
                         const auto s0 = __builtin_amdgcn_permlane16_swap(R[0], R[2], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(R[1], R[3], false, false);
-                        const bf16x4 ra = __builtin_bit_cast(bf16x4, (u32x2_t){s0[0], s1[0]});      // pixel block 2 ip
-                        const bf16x4 rb = __builtin_bit_cast(bf16x4, (u32x2_t){s0[1], s1[1]});      // pixel block 2 ip + 1
+                        const half_t ra = __builtin_bit_cast(half_t, (u32x2_t){s0[0], s1[0]});      // pixel block 2 ip
+                        const half_t rb = __builtin_bit_cast(half_t, (u32x2_t){s0[1], s1[1]});      // pixel block 2 ip + 1
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v0[e] += (float)ra[e]; v1[e] += (float)rb[e]; }
                     }
-                    const bf16x4 t0 = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3]};
-                    const bf16x4 t1 = {(bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
-                    const auto u0 = __builtin_bit_cast(u32x2_t, t0), u1 = __builtin_bit_cast(u32x2_t, t1);
+                    const u32x2_t u0 = {pack_pair<T>(sat16<T>(v0[0]), sat16<T>(v0[1])), pack_pair<T>(sat16<T>(v0[2]), sat16<T>(v0[3]))};
+                    const u32x2_t u1 = {pack_pair<T>(sat16<T>(v1[0]), sat16<T>(v1[1])), pack_pair<T>(sat16<T>(v1[2]), sat16<T>(v1[3]))};
                     const auto s0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
                     const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
@@ -1024,14 +1026,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
     // Software pipeline of one K-step (tap): the pixel-fragment reads of group 0 and all address arithmetic of tap t+1 are
     // issued before the last MFMA group of tap t (the halo does not change inside a phase), so after the barrier only the two
     // weight-fragment reads of group 0 stand between the wave and its first MFMA.  Two fragment sets alternate per group.
-    bf16x8 px[2][4], wt[2][2];
+    frag_t px[2][4], wt[2][2];
     int rowb[4], sw[4];
     int st = 0, hbuf = 0;
     auto load_wt = [&](int stg, int kg, int set) {
         const char* Wb = smem + stg * kWST + b_off;
         const int coff = ((kg * 2 + h) ^ swz) << 4;
-        wt[set][0] = *reinterpret_cast<const bf16x8*>(Wb + coff);
-        wt[set][1] = *reinterpret_cast<const bf16x8*>(Wb + 4096 + coff);
+        wt[set][0] = *reinterpret_cast<const frag_t*>(Wb + coff);
+        wt[set][1] = *reinterpret_cast<const frag_t*>(Wb + 4096 + coff);
     };
 
     // one job = nph phases x 9 taps + epilogue; NI = pixel blocks per wave (4: whole job, 2: half job)
@@ -1049,13 +1051,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i)
-                px[0][i] = *reinterpret_cast<const bf16x8*>(Hb + rowb[i] + ((h ^ sw[i]) << 4));
+                px[0][i] = *reinterpret_cast<const frag_t*>(Hb + rowb[i] + ((h ^ sw[i]) << 4));
         };
         auto load_px = [&](int hb, int kg, int set) {
             const char* Hb = smem + hb * kHB;
 #pragma unroll
             for (int i = 0; i < NI; ++i)
-                px[set][i] = *reinterpret_cast<const bf16x8*>(Hb + rowb[i] + (((kg * 2 + h) ^ sw[i]) << 4));
+                px[set][i] = *reinterpret_cast<const frag_t*>(Hb + rowb[i] + (((kg * 2 + h) ^ sw[i]) << 4));
         };
         auto interleave_reads = [&]() {       // whole job: (MFMA, 2 VALU, read) x 4, (MFMA, read) x 2, MFMA x 2;  half job: half of each
 #pragma unroll
@@ -1092,7 +1094,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[set][j], px[set][i], kFresh ? z : acc[j][i], 0, 0, 0);
+                    acc[j][i] = mfma_32x32x16<T>(wt[set][j], px[set][i], kFresh ? z : acc[j][i]);
         };
         auto epilogue = [&]() {
             // every global load of the epilogue is issued up front, in as few and as wide instructions as possible: the bias once
@@ -1161,8 +1163,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                             const u32x4 R = rres[i & 1][j][qq];
                             const auto s0 = __builtin_amdgcn_permlane32_swap(R[0], R[2], false, false);
                             const auto s1 = __builtin_amdgcn_permlane32_swap(R[1], R[3], false, false);
-                            const bf16x4 ra = __builtin_bit_cast(bf16x4, (u32x2_t){s0[0], s1[0]});      // block q4 = 2qq
-                            const bf16x4 rb = __builtin_bit_cast(bf16x4, (u32x2_t){s0[1], s1[1]});      // block q4 = 2qq + 1
+                            const half_t ra = __builtin_bit_cast(half_t, (u32x2_t){s0[0], s1[0]});      // block q4 = 2qq
+                            const half_t rb = __builtin_bit_cast(half_t, (u32x2_t){s0[1], s1[1]});      // block q4 = 2qq + 1
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 v[8 * qq + e] += (float)ra[e];
@@ -1173,9 +1175,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     unsigned pk[4][2];
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-                        bf16x4 t = {(bf16_t)v[4 * q4], (bf16_t)v[4 * q4 + 1], (bf16_t)v[4 * q4 + 2], (bf16_t)v[4 * q4 + 3]};
-                        const auto u = __builtin_bit_cast(u32x2_t, t);
-                        pk[q4][0] = u[0]; pk[q4][1] = u[1];
+                        pk[q4][0] = pack_pair<T>(sat16<T>(v[4 * q4]), sat16<T>(v[4 * q4 + 1]));
+                        pk[q4][1] = pack_pair<T>(sat16<T>(v[4 * q4 + 2]), sat16<T>(v[4 * q4 + 3]));
                     }
 #pragma unroll
                     for (int q4 = 0; q4 < 4; q4 += 2) {
@@ -1290,7 +1291,7 @@ int gmk_halo_geometry(int B, int H, int W, int c0, int c1, int w_rows, int cout,
 int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int B, int H, int W, const void* w, int w_rows,
                          int n0, int cout, const float* bias, const float* emb, int emb_stride, const void* residual,
                          void* out, int out_cstride, int min_tiles, int upsample, float* stats, int64_t stats_bytes,
-                         const float* gn_scale, const float* gn_shift, int gn_stride, hipStream_t stream) {
+                         const float* gn_scale, const float* gn_shift, int gn_stride, int dtype, hipStream_t stream) {
     HaloGeometry g;
     if (!gmk_halo_geometry(B, H, W, c0, c1, w_rows, cout, out_cstride, min_tiles, upsample, gn_scale != nullptr, &g)) return 0;
     if (gn_scale && (!gn_shift || gn_stride < c0 + c1)) return 0;
@@ -1319,19 +1320,23 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
         if (ntiles > G && rem > 0 && 2 * rem <= G && p.variant != 4 && p.variant != 6) { p.nfull = (int)ntiles - rem; p.nhalf = 2 * rem; }
     }
     const bool use16 = p.variant != 32 && (p.variant == 16 || (p.variant == 0 && (p.ktot >= 256 || W >= 32 || W <= 16)));
-    if (gn_scale) {                 // fused GroupNorm-apply + SiLU in the producer waves (statistics tables from gmk_gn_stats)
-        if (use16) conv3x3_halo_ws_kernel<true, 16, true><<<grid, 512, 0, stream>>>(p);
-        else conv3x3_halo_ws_kernel<true, 32, true><<<grid, 512, 0, stream>>>(p);
-        return 2;
-    }
-    if (p.variant == 4 && !p.stats) conv3x3_halo_ws_kernel<false><<<grid, 512, 0, stream>>>(p);
-    // MFMA shape of the consumers: bit-identical results either way; v_mfma_f32_16x16x32_bf16 measured +2 ... +4 % at K = 2304, at
+    // MFMA shape of the consumers: bit-identical results either way; v_mfma_f32_16x16x32 measured +2 ... +4 % at K = 2304, at
     // 64- / 32- / 14-pixel rows, and -2 % at 28 x 28 with K = 1152 (tools/halo_ab.py).  GMK_DEV_VARIANT 16 / 32 force one form.
-    else if (!p.stats && use16) conv3x3_halo_ws_kernel<true, 16><<<grid, 512, 0, stream>>>(p);
-    else if (p.variant != 1 && p.variant != 3 && !p.stats) conv3x3_halo_ws_kernel<true, 32><<<grid, 512, 0, stream>>>(p);     // 1, 3: the 8-compute-wave kernel
-    else {
-        conv3x3_halo_kernel<<<grid, 512, 0, stream>>>(p);
-        return 1;
-    }
-    return 2;
+    // kind: 0 the 8-compute-wave kernel (variants 1, 3, or statistics wanted), 1 fused GroupNorm-apply + SiLU in the producer waves
+    // (tables from gmk_gn_stats), 2 variant 4 (no weight prefetch), 3 the wave-specialised kernel
+    const int kind = gn_scale ? 1 : (p.variant == 4 && !p.stats) ? 2 : (!p.stats && (use16 || (p.variant != 1 && p.variant != 3))) ? 3 : 0;
+    auto launch = [&](auto tag) {
+        typedef decltype(tag) T;
+        if (kind == 1) {
+            if (use16) conv3x3_halo_ws_kernel<T, true, 16, true><<<grid, 512, 0, stream>>>(p);
+            else conv3x3_halo_ws_kernel<T, true, 32, true><<<grid, 512, 0, stream>>>(p);
+        } else if (kind == 2) conv3x3_halo_ws_kernel<T, false><<<grid, 512, 0, stream>>>(p);
+        else if (kind == 3) {
+            if (use16) conv3x3_halo_ws_kernel<T, true, 16><<<grid, 512, 0, stream>>>(p);
+            else conv3x3_halo_ws_kernel<T, true, 32><<<grid, 512, 0, stream>>>(p);
+        } else conv3x3_halo_kernel<T><<<grid, 512, 0, stream>>>(p);
+    };
+    if (dtype == GMK_F16) launch(f16_t{});
+    else launch(bf16_t{});
+    return kind == 0 ? 1 : 2;
 }

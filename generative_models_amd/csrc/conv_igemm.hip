@@ -181,16 +181,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         for (int kg = 0; kg < 4; ++kg) {
             const int coff = ((kg * 2 + h) ^ swz) << 4;
             if constexpr (ES == 2) {
-                bf16x8 a[2], b[2];
-                a[0] = *reinterpret_cast<const bf16x8*>(Ab + a_off + coff);
-                a[1] = *reinterpret_cast<const bf16x8*>(Ab + a_off + 4096 + coff);
-                b[0] = *reinterpret_cast<const bf16x8*>(Bb + b_off + coff);
-                b[1] = *reinterpret_cast<const bf16x8*>(Bb + b_off + 4096 + coff);
+                typedef typename Frag16<T>::type frag_t;
+                frag_t a[2], b[2];
+                a[0] = *reinterpret_cast<const frag_t*>(Ab + a_off + coff);
+                a[1] = *reinterpret_cast<const frag_t*>(Ab + a_off + 4096 + coff);
+                b[0] = *reinterpret_cast<const frag_t*>(Bb + b_off + coff);
+                b[1] = *reinterpret_cast<const frag_t*>(Bb + b_off + 4096 + coff);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_32x32x16<T>(a[i], b[j], acc[i][j]);
             } else {
                 f32x4 a[2], b[2];
                 a[0] = *reinterpret_cast<const f32x4*>(Ab + a_off + coff);
@@ -249,6 +250,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += t[e];
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sat16<T>(v[e]);
         store4((T*)p.out + o, v);
     }
 }
@@ -375,16 +378,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
         for (int kg = 0; kg < 4; ++kg) {
             const int coff = ((kg * 2 + h) ^ swz) << 4;
             if constexpr (ES == 2) {
-                bf16x8 px[2], wt[2];
-                px[0] = *reinterpret_cast<const bf16x8*>(Sb + a_off + coff);
-                px[1] = *reinterpret_cast<const bf16x8*>(Sb + a_off + 4096 + coff);
-                wt[0] = *reinterpret_cast<const bf16x8*>(Sb + b_off + coff);
-                wt[1] = *reinterpret_cast<const bf16x8*>(Sb + b_off + 4096 + coff);
+                typedef typename Frag16<T>::type frag_t;
+                frag_t px[2], wt[2];
+                px[0] = *reinterpret_cast<const frag_t*>(Sb + a_off + coff);
+                px[1] = *reinterpret_cast<const frag_t*>(Sb + a_off + 4096 + coff);
+                wt[0] = *reinterpret_cast<const frag_t*>(Sb + b_off + coff);
+                wt[1] = *reinterpret_cast<const frag_t*>(Sb + b_off + 4096 + coff);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[j], px[i], acc[j][i], 0, 0, 0);
+                        acc[j][i] = mfma_32x32x16<T>(wt[j], px[i], acc[j][i]);
             } else {
                 f32x4 px[2], wt[2];
                 px[0] = *reinterpret_cast<const f32x4*>(Sb + a_off + coff);
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
                         float t[4];
                         if constexpr (ES == 2) {
                             const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rsr, off, 0, 0);
-                            const bf16x4 rb = __builtin_bit_cast(bf16x4, raw);
+                            const auto rb = __builtin_bit_cast(typename Frag16<T>::half_type, raw);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) t[e] = (float)rb[e];
                         } else {
@@ -455,13 +459,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
                     }
                 }
                 if constexpr (ES == 2) {
-                    // pack to bf16: group q4 = channels cb + 8*q4 + 4*h + {0..3}  ->  2 dwords
+                    // pack to 16 bits: group q4 = channels cb + 8*q4 + 4*h + {0..3}  ->  2 dwords
                     unsigned pk[4][2];
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-                        bf16x4 t = {(bf16_t)v[4 * q4], (bf16_t)v[4 * q4 + 1], (bf16_t)v[4 * q4 + 2], (bf16_t)v[4 * q4 + 3]};
-                        const auto u = __builtin_bit_cast(u32x2_t, t);
-                        pk[q4][0] = u[0]; pk[q4][1] = u[1];
+                        pk[q4][0] = pack_pair<T>(sat16<T>(v[4 * q4]), sat16<T>(v[4 * q4 + 1]));
+                        pk[q4][1] = pack_pair<T>(sat16<T>(v[4 * q4 + 2]), sat16<T>(v[4 * q4 + 3]));
                     }
                     // exchange between lane l (h=0) and l+32 (h=1): afterwards h=0 holds channels cb+8q..cb+8q+7 of
                     // group pair (q, q+1) and h=1 holds cb+8(q+1)..cb+8(q+1)+7: 16 contiguous bytes per lane
@@ -579,8 +582,12 @@ struct WgradParams {
     int M, chunk;       // pixels, pixels per split (multiple of 64)
 };
 
-template <typename T>
+// T: type of dy (and of the MFMA operands); TX: storage type of the activation operand.  TX = f16_t with T = bf16_t is the train
+// step's case (fp16 forward activations, bf16 gradients): the gathered activation vectors are re-rounded to bf16 in the staging
+// registers (the value set of bf16 x bf16 products the MFMA needs; 3 VALU per dword, next to 16-byte loads), nothing else changes.
+template <typename T, typename TX = T>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
+    static_assert(sizeof(T) == sizeof(TX), "mixed operand widths");
     constexpr int ES = sizeof(T);
     constexpr int KP = ES == 2 ? 64 : 32;  // pixels per K-step (a 16 KB tile of 128 channels)
     constexpr int ROWB = 128 * ES;         // bytes per pixel row of a tile (128 channels)
@@ -600,9 +607,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int ncib = p.ktot / 128;
     const int cib = blockIdx.z % ncib, cob = blockIdx.z / ncib;
     const int kelem0 = cib * 128;
-    const T* src; int cs, ci_off;
-    if (kelem0 < p.c0) { src = (const T*)p.src0; cs = p.c0; ci_off = kelem0; }
-    else { src = (const T*)p.src1; cs = p.c1; ci_off = kelem0 - p.c0; }
+    const TX* src; int cs, ci_off;
+    if (kelem0 < p.c0) { src = (const TX*)p.src0; cs = p.c0; ci_off = kelem0; }
+    else { src = (const TX*)p.src1; cs = p.c1; ci_off = kelem0 - p.c0; }
     const T* dy = (const T*)p.dy + cob * 128;
 
     const int pix_begin = blockIdx.x * p.chunk;
@@ -635,6 +642,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
                 if (ty >= 0 && ty < g.lim_h && tx >= 0 && tx < g.lim_w && !((ty | tx) & g.mask)) {
                     const int64_t pix = ((int64_t)b * g.hs + (ty >> g.shift)) * g.ws + (tx >> g.shift);
                     vx = *reinterpret_cast<const u32x4*>(src + pix * cs + ci_off + sc * EPC);
+                    if constexpr (!__is_same(T, TX)) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            float lo, hi;
+                            unpack_pair<TX>(vx[d], lo, hi);
+                            vx[d] = pack_pair<T>(lo, hi);
+                        }
+                    }
                 }
             }
             ry[i] = vy; rx[i] = vx;
@@ -779,8 +794,8 @@ static void launch_wgrad_reduce(const float* slab, float* dw, int nsplit, int ta
 }
 
 // w [Cout][Cin][k][k] fp32 -> w_fwd [tap][Cout][Cin], w_dgrad [taps-1-tap][Cin][Cout]
-template <typename T>
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ wf,
+template <typename T, typename TF = T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, TF* __restrict__ wf,
                                                          T* __restrict__ wd, int cout, int cin, int taps) {
     const int64_t n = (int64_t)cout * cin * taps;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -789,15 +804,15 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     const int64_t t2 = idx / taps;
     const int ci = (int)(t2 % cin);
     const int co = (int)(t2 / cin);
-    const T v = (T)w[idx];
-    if (wf) wf[((int64_t)tap * cout + co) * cin + ci] = v;
-    if (wd) wd[((int64_t)(taps - 1 - tap) * cin + ci) * cout + co] = v;
+    if (wf) wf[((int64_t)tap * cout + co) * cin + ci] = (TF)w[idx];
+    if (wd) wd[((int64_t)(taps - 1 - tap) * cin + ci) * cout + co] = (T)w[idx];
 }
 
 // every convolution of the net in one launch: entry e packs arena[w_off ..] into packs[f_off ..] / packs[d_off ..]
 struct PackTable {
     int n;
     int w_off[40], f_off[40], cout[40], cin[40], taps[40];
+    unsigned long long fwd_f16;          // bit e: entry e's forward pack is fp16 (16-bit packs only; the data-gradient pack is always T)
 };
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const float* __restrict__ arena, T* __restrict__ packs, const PackTable t) {
@@ -807,12 +822,14 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const float* __
     const float* w = arena + t.w_off[e];
     T* wf = packs + t.f_off[e];
     T* wd = wf + n;
+    const bool f16 = sizeof(T) == 2 && ((t.fwd_f16 >> e) & 1ull);
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
         const int tap = idx % taps;
         const int t2 = idx / taps;
         const int ci = t2 % cin, co = t2 / cin;
         const T v = (T)w[idx];
-        wf[(tap * cout + co) * cin + ci] = v;
+        if (f16) reinterpret_cast<f16_t*>(wf)[(tap * cout + co) * cin + ci] = (f16_t)w[idx];
+        else wf[(tap * cout + co) * cin + ci] = v;
         wd[((taps - 1 - tap) * cin + ci) * cout + co] = v;
     }
 }
@@ -848,6 +865,12 @@ extern "C" int64_t gmk_conv_wgrad_workspace_bytes(int64_t n_pixels, int taps, in
 extern "C" int gmk_pack_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int cout, int cin, int ksize, int dtype,
                                     void* stream) {
     GMK_REQUIRE(w && (w_fwd || w_dgrad), "gmk_pack_conv_weight: null pointer");
+    if (dtype == GMK_F16) {      // an fp16 pack: the forward operand of the 16-bit mode
+        GMK_REQUIRE(cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "gmk_pack_conv_weight: bad shape");
+        const int64_t n16 = (int64_t)cout * cin * ksize * ksize;
+        pack_weight_kernel<f16_t><<<(int)((n16 + 255) / 256), 256, 0, gmk_stream(stream)>>>(w, (f16_t*)w_fwd, (f16_t*)w_dgrad, cout, cin, ksize * ksize);
+        return gmk_check_launch("gmk_pack_conv_weight");
+    }
     GMK_REQUIRE(cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "gmk_pack_conv_weight: bad shape");
     const int taps = ksize * ksize;
     const int64_t n = (int64_t)cout * cin * taps;
@@ -864,13 +887,19 @@ extern "C" int gmk_pack_conv_weight(const float* w, void* w_fwd, void* w_dgrad, 
 }
 
 extern "C" int gmk_pack_conv_weights_multi(const float* arena, void* packs, int count, const int* w_off, const int* pack_off,
-                                           const int* cout, const int* cin, const int* ksize, int dtype, void* stream) {
+                                           const int* cout, const int* cin, const int* ksize, const int* fwd_f16, int dtype,
+                                           void* stream) {
     GMK_REQUIRE(arena && packs && w_off && pack_off && cout && cin && ksize, "gmk_pack_conv_weights_multi: null pointer");
     GMK_REQUIRE(count > 0 && count <= 40, "gmk_pack_conv_weights_multi: 1..40 tensors per call, got %d", count);
     PackTable t;
     t.n = count;
+    t.fwd_f16 = 0;
     int nmax = 0;
     for (int e = 0; e < count; ++e) {
+        if (fwd_f16 && fwd_f16[e]) {
+            GMK_REQUIRE(dtype == GMK_BF16, "gmk_pack_conv_weights_multi: fp16 forward packs go with bf16 data-gradient packs");
+            t.fwd_f16 |= 1ull << e;
+        }
         GMK_REQUIRE(cout[e] > 0 && cin[e] > 0 && (ksize[e] == 1 || ksize[e] == 3) && w_off[e] >= 0 && pack_off[e] >= 0,
                     "gmk_pack_conv_weights_multi: bad entry %d", e);
         t.w_off[e] = w_off[e]; t.f_off[e] = pack_off[e]; t.cout[e] = cout[e]; t.cin[e] = cin[e]; t.taps[e] = ksize[e] * ksize[e];
@@ -892,7 +921,7 @@ static int conv_igemm_impl(const void* src0, const void* src1, int c0, int c1, i
                            float* gn_stats, int64_t gn_stats_bytes, const float* gn_scale, const float* gn_shift, int gn_stride,
                            int dtype, void* stream) {
     GMK_REQUIRE(src0 && w && out, "gmk_conv_igemm: null pointer");
-    GMK_REQUIRE(dtype == GMK_BF16 || dtype == GMK_F32, "gmk_conv_igemm: bad dtype %d", dtype);
+    GMK_REQUIRE(dtype == GMK_BF16 || dtype == GMK_F16 || dtype == GMK_F32, "gmk_conv_igemm: bad dtype %d", dtype);
     GMK_REQUIRE(ksize == 1 || ksize == 3, "gmk_conv_igemm: ksize %d", ksize);
     GMK_REQUIRE(c0 > 0 && c0 % 128 == 0 && c1 >= 0 && c1 % 128 == 0 && (c1 == 0 || src1),
                 "gmk_conv_igemm: source channels must be multiples of 128 (c0=%d c1=%d)", c0, c1);
@@ -913,10 +942,10 @@ static int conv_igemm_impl(const void* src0, const void* src1, int c0, int c1, i
     // the transposed form (data gradient of the stride-2 conv) is the plain 3x3 conv of the zero-stuffed gradient: on the halo
     // kernel 3/4 of the resident pixels are zeros, but it still beats the im2col gather by 1.7x (215 vs 360 us at 28x28)
     const bool stuffed = mode == GMK_CONV_TRANSPOSED2 && !((ho | wo) & 1);
-    if ((force == 0 || force == 3) && dtype == GMK_BF16 && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2 || stuffed) && ksize == 3) {
+    if ((force == 0 || force == 3) && gmk_is16(dtype) && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2 || stuffed) && ksize == 3) {
         const int rc = gmk_conv3x3_halo_try(src0, src1, c0, c1, B, ho, wo, w, w_rows, n0, cout, bias, emb, emb_stride, residual,
                                             out, out_cstride, force == 3 ? 1 : 32, stuffed ? 2 : mode == GMK_CONV_UPSAMPLE2, gn_stats,
-                                            gn_stats_bytes, gn_scale, gn_shift, gn_stride, gmk_stream(stream));
+                                            gn_stats_bytes, gn_scale, gn_shift, gn_stride, dtype, gmk_stream(stream));
         if (rc == 1 || rc == 2) {
             gmk_note_kernel(stuffed ? 5 : rc == 2 ? 4 : 3);       // 5: a halo kernel on the zero-stuffed source (transposed conv)
             return gmk_check_launch("gmk_conv_igemm(halo)");
@@ -949,10 +978,12 @@ static int conv_igemm_impl(const void* src0, const void* src1, int c0, int c1, i
         const int ntiles = (p.M + 255) / 256;
         dim3 grid(ntiles < ncu ? ntiles : ncu, cout / kBN);
         if (dtype == GMK_BF16) conv_igemm_dma_kernel<bf16_t><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+        else if (dtype == GMK_F16) conv_igemm_dma_kernel<f16_t><<<grid, 512, 0, gmk_stream(stream)>>>(p);
         else conv_igemm_dma_kernel<float><<<grid, 512, 0, gmk_stream(stream)>>>(p);
     } else {
         dim3 grid((p.M + kBM - 1) / kBM, cout / kBN);
         if (dtype == GMK_BF16) conv_igemm_kernel<bf16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
+        else if (dtype == GMK_F16) conv_igemm_kernel<f16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
         else conv_igemm_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(p);
     }
     return gmk_check_launch("gmk_conv_igemm");
@@ -985,9 +1016,12 @@ extern "C" int gmk_conv_gn_fusable(int B, int H, int W, int c0, int c1, int cout
 
 extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B,
                               int hs, int ws, int ho, int wo, int ksize, int mode, float* dw, int cout, void* workspace,
-                              int64_t workspace_bytes, int dtype, void* stream) {
+                              int64_t workspace_bytes, int dtype, int x_dtype, void* stream) {
     GMK_REQUIRE(dy && src0 && dw && workspace, "gmk_conv_wgrad: null pointer");
     GMK_REQUIRE(dtype == GMK_BF16 || dtype == GMK_F32, "gmk_conv_wgrad: bad dtype %d", dtype);
+    GMK_REQUIRE(x_dtype == dtype || (dtype == GMK_BF16 && x_dtype == GMK_F16),
+                "gmk_conv_wgrad: activations of type %d with gradients of type %d (same type, or fp16 activations with bf16 gradients)", x_dtype, dtype);
+    const bool xf16 = x_dtype == GMK_F16;
     GMK_REQUIRE(ksize == 1 || ksize == 3, "gmk_conv_wgrad: ksize %d", ksize);
     GMK_REQUIRE(c0 > 0 && c0 % 128 == 0 && c1 >= 0 && c1 % 128 == 0 && (c1 == 0 || src1),
                 "gmk_conv_wgrad: source channels must be multiples of 128 (c0=%d c1=%d)", c0, c1);
@@ -1003,7 +1037,7 @@ extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, 
     const int wforce = gmk_kernel_choice(1, "GMK_WGRAD_KERNEL");
     if (wforce != 1 && dtype == GMK_BF16 && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2) && ksize == 3) {
         const int ns2 = gmk_conv_wgrad_slots_try(dy, dy_cstride, src0, src1, c0, c1, B, ho, wo, cout, (float*)workspace,
-                                                 workspace_bytes, wforce, mode == GMK_CONV_UPSAMPLE2, gmk_stream(stream));
+                                                 workspace_bytes, wforce, mode == GMK_CONV_UPSAMPLE2, xf16, gmk_stream(stream));
         if (ns2 > 0) {
             int rc2 = gmk_check_launch("gmk_conv_wgrad(slots)");
             if (rc2) return rc2;
@@ -1020,7 +1054,8 @@ extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, 
     p.slab = (float*)workspace;
     gmk_note_kernel(11);
     dim3 grid(ns, taps, (cout / 128) * (p.ktot / 128));
-    if (dtype == GMK_BF16) conv_wgrad_kernel<bf16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
+    if (dtype == GMK_BF16 && xf16) conv_wgrad_kernel<bf16_t, f16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
+    else if (dtype == GMK_BF16) conv_wgrad_kernel<bf16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
     else conv_wgrad_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(p);
     int rc = gmk_check_launch("gmk_conv_wgrad");
     if (rc) return rc;

@@ -22,6 +22,8 @@
 // instructions (X chunk c+3 + its mirror-or-dummy, dY chunk c+2 x2), so `s_waitcnt vmcnt(4)` retires exactly what
 // the step needs; one raw s_barrier per step.  Split-K over slot ranges into fp32 slabs; the deterministic reduce of
 // conv_igemm.hip converts to the reference's [Cout][Cin][3][3] layout.
+#include <type_traits>
+
 #include "gmk_common.h"
 
 namespace {
@@ -233,7 +235,12 @@ template <int LOOK> struct SlotWsLds {
     static constexpr int kAhead = LOOK == 1 ? 4 : 3;          // X ring: chunks c-LOOK .. c+LOOK+AHEAD must fit 8
 };
 
-template <int LOOK>
+// kXF16: the activation operand X is stored as fp16 (forward activations of the 16-bit mode) while dY is bf16.  The producers then
+// bring the X chunk through registers instead of LDS-DMA: two 16-byte global loads per lane and step, issued AHEAD steps early like the
+// DMA they replace and counted by the same `s_waitcnt vmcnt`; when they have landed each dword is re-rounded fp16 -> bf16 (3 VALU) and
+// written with ds_write_b128 to the place the DMA would have filled (and to the mirror copy - one load serves both).  The consumers,
+// the dY path and the LDS layout are unchanged: the MFMA sees bf16 x bf16 as before.
+template <int LOOK, bool kXF16 = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotParams p) {
     __shared__ __attribute__((aligned(16))) char smem[SlotWsLds<LOOK>::kBytes];
     constexpr unsigned kBadPix = 0x00FFFFFFu;
@@ -311,6 +318,86 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (GMK_LDS void*)(dst + 1024), 16, __umul24(p1, ys_b) + yoff_b + lc, 0, 0, 0);
             ++yc;
         };
+        if constexpr (kXF16) {
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+            constexpr int NSET = AHEAD - 1;                  // register sets: AHEAD - 2 blocks in flight + the one being written
+            const char* xsrc = (const char*)(second ? p.src1 : p.src0);
+            u32x4 xr[NSET][2];
+            unsigned xvalid[NSET];                           // bit u: this lane's slot of load u is a pixel (else border: zeros)
+            int xrp[NSET];                                   // ring position the set goes to (wave-uniform)
+            auto load_x = [&](u32x4 (&r)[2], unsigned& valid, int& rp) {      // 2 global loads (inline asm: they stay in flight across barriers)
+                unsigned pix0 = kBadPix, pix1 = kBadPix;
+                if (xc >= 0) {
+                    int r1 = xrow, x1 = xxe;
+                    advance(r1, x1, d8r, d8x);
+                    pix0 = pixel(xrow, xxe, p.xshift); pix1 = pixel(r1, x1, p.xshift);
+                    advance(xrow, xxe, d64r, d64x);
+                }
+                valid = (pix0 != kBadPix ? 1u : 0u) | (pix1 != kBadPix ? 2u : 0u);
+                const char* a0 = xsrc + (pix0 != kBadPix ? __umul24(pix0, xs_b) + xoff_b + lc : 0u);
+                const char* a1 = xsrc + (pix1 != kBadPix ? __umul24(pix1, xs_b) + xoff_b + lc : 0u);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[0]) : "v"(a0) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[1]) : "v"(a1) : "memory");
+                rp = xc & 7;
+                ++xc;
+            };
+            auto store_x = [&](u32x4 (&r)[2], unsigned valid, int rp) {       // fp16 -> bf16, ds_write_b128 (+ mirror)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    asm volatile("" : "+v"(r[u]));
+                    u32x4 o;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        float lo, hi;
+                        unpack_pair<f16_t>(r[u][d], lo, hi);
+                        o[d] = ((valid >> u) & 1u) ? pack_pair<bf16_t>(lo, hi) : 0u;
+                    }
+                    char* dst = smem + kWsXBase + rp * 8192 + pw * 2048 + u * 1024 + lane * 16;
+                    *reinterpret_cast<u32x4*>(dst) = o;
+                    if (rp < 2 * LOOK) *reinterpret_cast<u32x4*>(dst + 65536) = o;
+                }
+            };
+            // prologue: X chunks c-LOOK .. c+LOOK+1 through a temporary register set each, dY chunks c and c+1, all awaited and written:
+            // barrier 0 then sees what the DMA form guarantees (every chunk up to c + 1); blocks 2 .. AHEAD-1 follow and stay in flight
+            {
+                u32x4 t[2 * LOOK + 2][2]; unsigned tv[2 * LOOK + 2]; int tp[2 * LOOK + 2];
+#pragma unroll
+                for (int k = 0; k < 2 * LOOK + 1; ++k) load_x(t[k], tv[k], tp[k]);
+                issue_y();
+                load_x(t[2 * LOOK + 1], tv[2 * LOOK + 1], tp[2 * LOOK + 1]); issue_y();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 2 * LOOK + 2; ++k) store_x(t[k], tv[k], tp[k]);
+            }
+#pragma unroll
+            for (int k = 2; k < AHEAD; ++k) { load_x(xr[k % NSET], xvalid[k % NSET], xrp[k % NSET]); issue_y(); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // step s: block s + 1 (set (s + 1) % NSET) has landed -> write it; barrier; block s + AHEAD goes into the set just freed
+            auto step = [&](auto set_tag, int s) {
+                constexpr int SET = decltype(set_tag)::value;
+                if (s > 0) {
+                    if (AHEAD == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    store_x(xr[SET], xvalid[SET], xrp[SET]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                load_x(xr[SET], xvalid[SET], xrp[SET]);
+                issue_y();
+            };
+            for (int s = 0; s < nsteps;) {        // set of step s = (s + 1) % NSET, statically indexed
+                if constexpr (NSET == 3) {
+                    step(std::integral_constant<int, 1>{}, s); ++s;
+                    if (s < nsteps) { step(std::integral_constant<int, 2>{}, s); ++s; }
+                    if (s < nsteps) { step(std::integral_constant<int, 0>{}, s); ++s; }
+                } else {
+                    step(std::integral_constant<int, 1>{}, s); ++s;
+                    if (s < nsteps) { step(std::integral_constant<int, 0>{}, s); ++s; }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
         // prologue: X chunks c-LOOK .. c+LOOK + dY chunk c (step 0's data), one block per further chunk up to c + AHEAD - 1
 #pragma unroll
         for (int k = 0; k < 2 * LOOK + 1; ++k) issue_x();
@@ -416,8 +503,10 @@ int gmk_wgrad_slots_nsplit(int cout, int ktot) {
 
 // Returns the number of splits written (>= 1) if the slot kernel was launched, 0 if the problem is not eligible.
 int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B, int H,
-                             int W, int cout, float* slab, int64_t slab_bytes, int forced, int upsample, hipStream_t stream) {
+                             int W, int cout, float* slab, int64_t slab_bytes, int forced, int upsample, bool x_f16,
+                             hipStream_t stream) {
     if (c0 % 64 || c1 % 64 || cout % 128) return 0;
+    if (x_f16 && forced == 2) return 0;                      // the 8-compute-wave A/B kernel has no fp16-activation form
     const int WE = W + 1, RE = H + 1;
     if (WE + 1 > 128 || W < 4 || H < 2) return 0;
     const bool wide = WE + 1 > 64;
@@ -461,7 +550,10 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
         if ((int64_t)ns3 * 9 * cout * ktot * 4 > slab_bytes) return 0;
         p.chunks_per_split = cps3;
         dim3 grid3(ns3, ktot / 64, cout / 64);
-        if (wide) conv_wgrad_slots_ws_kernel<2><<<grid3, 512, 0, stream>>>(p);
+        if (x_f16) {
+            if (wide) conv_wgrad_slots_ws_kernel<2, true><<<grid3, 512, 0, stream>>>(p);
+            else conv_wgrad_slots_ws_kernel<1, true><<<grid3, 512, 0, stream>>>(p);
+        } else if (wide) conv_wgrad_slots_ws_kernel<2><<<grid3, 512, 0, stream>>>(p);
         else conv_wgrad_slots_ws_kernel<1><<<grid3, 512, 0, stream>>>(p);
         gmk_note_kernel(13);
         return ns3;

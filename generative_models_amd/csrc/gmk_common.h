@@ -9,6 +9,11 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -31,11 +36,11 @@ void gmk_note_kernel(int id);             // 1 conv_igemm_kernel, 2 conv_igemm_d
         }                                      \
     } while (0)
 
-// conv_halo.hip: 3x3 stride-1 bf16 convolution with an LDS-resident halo; returns 1 if launched, 0 if not eligible
+// conv_halo.hip: 3x3 stride-1 convolution of 16-bit operands (dtype GMK_BF16 / GMK_F16) with an LDS-resident halo; returns 1 / 2 if launched, 0 if not eligible
 int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int B, int H, int W, const void* w, int w_rows,
                          int n0, int cout, const float* bias, const float* emb, int emb_stride, const void* residual,
                          void* out, int out_cstride, int min_tiles, int upsample, float* stats, int64_t stats_bytes,
-                         const float* gn_scale, const float* gn_shift, int gn_stride, hipStream_t stream);
+                         const float* gn_scale, const float* gn_shift, int gn_stride, int dtype, hipStream_t stream);
 
 struct HaloGeometry { int R, TP; int64_t rows_total, M, ntiles, nb0, nb1, nbw, nbo; };
 int gmk_halo_geometry(int B, int H, int W, int c0, int c1, int w_rows, int cout, int out_cstride, int min_tiles, int upsample,
@@ -44,11 +49,13 @@ int gmk_halo_geometry(int B, int H, int W, int c0, int c1, int w_rows, int cout,
 // conv_wgrad_slots.hip: 3x3 stride-1 bf16 weight gradient over padded slots; returns the number of slabs written or 0
 int gmk_wgrad_slots_nsplit(int cout, int ktot);
 int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B, int H,
-                             int W, int cout, float* slab, int64_t slab_bytes, int forced, int upsample, hipStream_t stream);
+                             int W, int cout, float* slab, int64_t slab_bytes, int forced, int upsample, bool x_f16,
+                             hipStream_t stream);
 
 
 static inline hipStream_t gmk_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
-static inline int gmk_esize(int dtype) { return dtype == GMK_BF16 ? 2 : 4; }
+static inline int gmk_esize(int dtype) { return dtype == GMK_F32 ? 4 : 2; }
+static inline bool gmk_is16(int dtype) { return dtype == GMK_BF16 || dtype == GMK_F16; }
 
 // ---- device helpers ---------------------------------------------------------------------------
 template <typename T> struct Vec8;   // 8 activation elements as the natural 16/32-byte vector
@@ -64,6 +71,11 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
 }
+__device__ __forceinline__ void load8(const f16_t* p, float (&v)[8]) {
+    const f16x8 a = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
     f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
     *reinterpret_cast<f32x4*>(p) = a;
@@ -75,12 +87,23 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
     *reinterpret_cast<bf16x8*>(p) = a;
 }
+__device__ __forceinline__ void store8(f16_t* p, const float (&v)[8]) {
+    f16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (f16_t)v[i];
+    *reinterpret_cast<f16x8*>(p) = a;
+}
 __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p);
     v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
 }
 __device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
     const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void load4(const f16_t* p, float (&v)[4]) {
+    const f16x4 a = *reinterpret_cast<const f16x4*>(p);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
 }
@@ -94,6 +117,41 @@ __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
     for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
     *reinterpret_cast<bf16x4*>(p) = a;
 }
+
+__device__ __forceinline__ void store4(f16_t* p, const float (&v)[4]) {
+    f16x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (f16_t)v[i];
+    *reinterpret_cast<f16x4*>(p) = a;
+}
+
+// ---- 16-bit storage types.  Forward activations and forward weight packs are fp16 (f16_t: 11 significant bits - the precision of the
+// reference's own fp16 autocast, gms/diffusion/diffusion_model.py:68), gradients are bf16 (fp32's exponent range: no loss scaling).
+// Both are 2 bytes, so every layout is shared; what differs is the pack / unpack arithmetic and the MFMA instruction.
+template <typename T> struct Frag16;                      // 8 elements = one 16-byte MFMA operand fragment
+template <> struct Frag16<bf16_t> { typedef bf16x8 type; typedef bf16x4 half_type; };
+template <> struct Frag16<f16_t> { typedef f16x8 type; typedef f16x4 half_type; };
+template <typename T> __device__ __forceinline__ f32x16 mfma_32x32x16(typename Frag16<T>::type a, typename Frag16<T>::type b, f32x16 c);
+template <> __device__ __forceinline__ f32x16 mfma_32x32x16<bf16_t>(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+template <> __device__ __forceinline__ f32x16 mfma_32x32x16<f16_t>(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+template <typename T> __device__ __forceinline__ f32x4 mfma_16x16x32(typename Frag16<T>::type a, typename Frag16<T>::type b, f32x4 c);
+template <> __device__ __forceinline__ f32x4 mfma_16x16x32<bf16_t>(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+template <> __device__ __forceinline__ f32x4 mfma_16x16x32<f16_t>(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// the two 16-bit values of one dword as a float pair (low half first), and back (round to nearest even)
+template <typename T> __device__ __forceinline__ void unpack_pair(unsigned r, float& lo, float& hi);
+template <> __device__ __forceinline__ void unpack_pair<bf16_t>(unsigned r, float& lo, float& hi) {
+    lo = __builtin_bit_cast(float, r << 16); hi = __builtin_bit_cast(float, r & 0xFFFF0000u);
+}
+template <> __device__ __forceinline__ void unpack_pair<f16_t>(unsigned r, float& lo, float& hi) {
+    const f16x2 h = __builtin_bit_cast(f16x2, r);
+    lo = (float)h[0]; hi = (float)h[1];
+}
+template <typename T> __device__ __forceinline__ unsigned pack_pair(float lo, float hi);
+template <> __device__ __forceinline__ unsigned pack_pair<bf16_t>(float lo, float hi) { const bf16x2 t = {(bf16_t)lo, (bf16_t)hi}; return __builtin_bit_cast(unsigned, t); }
+template <> __device__ __forceinline__ unsigned pack_pair<f16_t>(float lo, float hi) { const f16x2 t = {(f16_t)lo, (f16_t)hi}; return __builtin_bit_cast(unsigned, t); }
+// convolution outputs are unbounded: an fp16 store saturates at the largest finite value instead of producing inf (one v_med3_f32)
+template <typename T> __device__ __forceinline__ float sat16(float v) { return v; }
+template <> __device__ __forceinline__ float sat16<f16_t>(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE `1.0f / d` costs ~12 VALU issue slots more per element (div_scale / fma chain /
 // div_fmas / div_fixup plus hazard nops), which made the GroupNorm kernels VALU-bound instead of HBM-bound

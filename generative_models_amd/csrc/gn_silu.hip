@@ -151,9 +151,9 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
     }
 }
 
-template <typename T>
+template <typename T, typename TX = T>      // T: gradient tensors (dy, addends, dx); TX: the saved forward activation x
 __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
-    const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const T* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd, const T* __restrict__ dadd1,
     const T* __restrict__ dadd2, T* __restrict__ dx, float* __restrict__ dgp, float* __restrict__ dbp,
     float* __restrict__ dxsum, int dxsum_stride, int HW, int C, int G, int CS, int B, float drop_p, uint64_t drop_seed,
@@ -281,20 +281,18 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 
+template <typename T>
 __device__ __forceinline__ void unpack8(const u32x4_t r, float (&v)[8]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        v[2 * k] = __builtin_bit_cast(float, r[k] << 16);
-        v[2 * k + 1] = __builtin_bit_cast(float, r[k] & 0xFFFF0000u);
-    }
+    for (int k = 0; k < 4; ++k) unpack_pair<T>(r[k], v[2 * k], v[2 * k + 1]);
 }
 
 // sum over the lanes of a wave that share (lane & (NVEC-1)); every such lane ends with the total
 template <int NVEC>
 __device__ __forceinline__ float vec_lane_sum(float v) { return lanes_sum_from<NVEC>(v); }
 
-template <int ITER, int NVEC>
-__global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+template <typename T, int ITER, int NVEC>       // T: bf16_t or f16_t (input and output)
+__global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ mean, float* __restrict__ rstd, int HW, int C,
                                                              int G, float eps, int B, int planes, float drop_p,
@@ -325,7 +323,7 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
         float v[8];
-        unpack8(raw[i], v);
+        unpack8<T>(raw[i], v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = ok[i] ? v[k] + ea[k] : 0.f;
         s0 += (v[0] + v[1]) + (v[2] + v[3]);
@@ -375,7 +373,7 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
         if (!ok[i]) continue;
         const int p = pl + i * planes;
         float v[8];
-        unpack8(raw[i], v);
+        unpack8<T>(raw[i], v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = siluf_(fmaf(v[k], sc[k], sh[k]));
         if (drop_p > 0.f) drop8(v, base + (size_t)p * C, drop_p, drop_seed, drop_off);
@@ -388,9 +386,14 @@ __global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const bf16_t* __re
 // 128, and it recomputes the sigmoid in both sweeps.  Removed; the streaming kernel with 32-channel slabs stays.)
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-// the two bf16 of one dword as a float pair (low half first)
+// the two 16-bit values of one dword as a float pair (low half first)
+template <typename T>
 __device__ __forceinline__ f32x2_t unpack2(unsigned r) {
-    return f32x2_t{__builtin_bit_cast(float, r << 16), __builtin_bit_cast(float, r & 0xFFFF0000u)};
+    f32x2_t v;
+    float lo, hi;
+    unpack_pair<T>(r, lo, hi);
+    v[0] = lo; v[1] = hi;
+    return v;
 }
 // d/dg [g * sigmoid(g)] * dy for a channel pair, g = fma(x, s, t): 6 packed ops + 2 x (v_exp_f32, v_rcp_f32)
 __device__ __forceinline__ f32x2_t silu_grad2(f32x2_t x, f32x2_t dy, f32x2_t s, f32x2_t t, float neg_log2e) {
@@ -408,9 +411,9 @@ __device__ __forceinline__ f32x2_t silu_grad2(f32x2_t x, f32x2_t dy, f32x2_t s, 
 // 3 workgroups per CU (LDS), thread = (vec = tid & 3, plane = tid >> 2), pixel p = plane + 64 i.
 // NVEC = 2 (16-channel slabs, 1024 threads, x in 128 KiB of LDS) carries the same scheme to 64 x 64 images, where a 32-channel slab
 // fits neither the registers nor the LDS and the two-sweep streaming kernel used to run (5 passes over HBM instead of 3).
-template <int ITER, int THREADS, int NVEC = 4>
+template <typename TX, int ITER, int THREADS, int NVEC = 4>      // TX: storage type of the saved activation x (bf16_t / f16_t); gradients are bf16
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? 3 : 4, 4))) void gn_silu_bwd_hybrid_kernel(
-    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const bf16_t* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ dadd1,
     const bf16_t* __restrict__ dadd2, bf16_t* __restrict__ dx, float* __restrict__ dgp, float* __restrict__ dbp,
     float* __restrict__ dxsum, int dxsum_stride, int HW, int C, int G, int B, float drop_p, uint64_t drop_seed,
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
             if (p < HW) *reinterpret_cast<u32x4_t*>(xs_lds + ((size_t)p * NVEC + vec) * 16) = xr[u];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const f32x2_t xv = unpack2(xr[u][jj]), dv = unpack2(dr[i][jj]);
+                const f32x2_t xv = unpack2<TX>(xr[u][jj]), dv = unpack2<bf16_t>(dr[i][jj]);
                 const f32x2_t dg = silu_grad2(xv, dv, sv[jj], tv[jj], kNegLog2e);
                 ax[jj] = __builtin_elementwise_fma(dg, xv, ax[jj]);
                 ab[jj] += dg;
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
         float o[8];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const f32x2_t xv = unpack2(xr[jj]), dv = unpack2(dr[i][jj]);
+            const f32x2_t xv = unpack2<TX>(xr[jj]), dv = unpack2<bf16_t>(dr[i][jj]);
             // (recomputing the sigmoid here instead of caching dy * silu'(g) costs 3-4 % of the kernel: a timing-only build without it)
             const f32x2_t dg = silu_grad2(xv, dv, sv[jj], tv[jj], kNegLog2e);
             const f32x2_t ov = __builtin_elementwise_fma(dg, sv[jj], __builtin_elementwise_fma(xv, npv[jj], qv[jj]));
@@ -680,6 +683,19 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ x
     }
 }
 
+// 16-bit storage conversion (fp16 <-> bf16), 8 elements per thread: the attention extension keeps its internals in bf16 and
+// converts the fp16 forward stream at its boundary
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast16_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        load8(src + i * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = sat16<TD>(v[k]);
+        store8(dst + i * 8, v);
+    }
+}
+
 bool gn_shape_ok(int C, int G) {
     if (C <= 0 || C > 256 || (C & 7) || 256 % (C >> 3)) return false;
     if (G <= 0 || G > 64 || C % G) return false;
@@ -715,15 +731,23 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
                 HW, C, groups);
     const int gn_mode = gmk_kernel_choice(2, "GMK_GN_KERNEL");
     // (at 7x7 / 8x8 the whole-sample streaming kernel wins: 19 vs 26 us at 8x8, B = 2048 - the slabs are too small to pay for a workgroup each)
-    if (dtype == GMK_BF16 && !stats_part && (gn_mode == 5 || gn_mode == 6 || (gn_mode == 0 && HW > 64)) && C % 64 == 0 &&
+    GMK_REQUIRE(dtype != GMK_F16 || !stats_part, "gmk_gn_silu_fwd: producer statistics go with bf16 tensors only");
+    if (gmk_is16(dtype) && !stats_part && (gn_mode == 5 || gn_mode == 6 || (gn_mode == 0 && HW > 64)) && C % 64 == 0 &&
                32 % (C / groups) == 0 && gn_reg_iter(HW, 8) > 0) {
         const int nvec = gn_mode == 5 ? 4 : 8;                 // 32- or 64-channel slabs (64 = whole 128-B lines)
         const int it = gn_reg_iter(HW, nvec), planes = (HW + it - 1) / it, threads = (planes * nvec + 63) / 64 * 64;
         const int nblk = B * (C / (nvec * 8));
-#define GMK_GN_FWD_REG(IT, NV)                                                                                                   \
-    gn_silu_fwd_reg_kernel<IT, NV><<<nblk, threads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, \
-                                                                             HW, C, groups, eps, B, planes, drop_p, drop_seed,     \
-                                                                             drop_offset, xadd, xadd_stride)
+#define GMK_GN_FWD_REG(IT, NV)                                                                                                           \
+    do {                                                                                                                                 \
+        if (dtype == GMK_F16)                                                                                                            \
+            gn_silu_fwd_reg_kernel<f16_t, IT, NV><<<nblk, threads, 0, gmk_stream(stream)>>>((const f16_t*)x, (f16_t*)y, gamma, beta, mean, rstd, \
+                                                                                            HW, C, groups, eps, B, planes, drop_p, drop_seed,  \
+                                                                                            drop_offset, xadd, xadd_stride);                   \
+        else                                                                                                                             \
+            gn_silu_fwd_reg_kernel<bf16_t, IT, NV><<<nblk, threads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, mean,  \
+                                                                                             rstd, HW, C, groups, eps, B, planes, drop_p,      \
+                                                                                             drop_seed, drop_offset, xadd, xadd_stride);       \
+    } while (0)
         if (nvec == 4) {
             if (it == 1) GMK_GN_FWD_REG(1, 4);
             else if (it == 2) GMK_GN_FWD_REG(2, 4);
@@ -741,6 +765,11 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
         const int CS = stats_part ? C : gn_slab_channels(gn_mode, C, groups, HW, 2, false);
         gn_silu_fwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, HW, C, groups, eps, stats_part, tile_pixels, ntiles, CS, B, drop_p,
+            drop_seed, drop_offset, xadd, xadd_stride);
+    } else if (dtype == GMK_F16) {
+        const int CS = gn_slab_channels(gn_mode, C, groups, HW, 2, false);
+        gn_silu_fwd_kernel<f16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
+            (const f16_t*)x, (f16_t*)y, gamma, beta, mean, rstd, HW, C, groups, eps, nullptr, 0, 0, CS, B, drop_p,
             drop_seed, drop_offset, xadd, xadd_stride);
     } else if (dtype == GMK_F32) {
         const int CS = stats_part ? C : gn_slab_channels(gn_mode, C, groups, HW, 4, false);
@@ -764,15 +793,22 @@ extern "C" int gmk_gn_stats(const void* x, const float* gamma, const float* beta
     GMK_REQUIRE(!xadd || xadd_stride >= C, "gmk_gn_stats: xadd_stride %d < C %d", xadd_stride, C);
     GMK_REQUIRE(tab_stride >= C, "gmk_gn_stats: tab_stride %d < C %d", tab_stride, C);
     GMK_REQUIRE(B > 0 && HW > 0 && gn_shape_ok(C, groups), "gmk_gn_stats: unsupported shape B=%d HW=%d C=%d G=%d", B, HW, C, groups);
-    GMK_REQUIRE(dtype == GMK_BF16, "gmk_gn_stats: bf16 only (the fused apply lives in the bf16 halo convolution)");
+    GMK_REQUIRE(gmk_is16(dtype), "gmk_gn_stats: 16-bit tensors only (the fused apply lives in the halo convolution)");
     if (C % 64 == 0 && 32 % (C / groups) == 0 && HW > 64 && gn_reg_iter(HW, 8) > 0) {      // same choice as gmk_gn_silu_fwd: same statistics bits
         const int nvec = 8;
         const int it = gn_reg_iter(HW, nvec), planes = (HW + it - 1) / it, threads = (planes * nvec + 63) / 64 * 64;
         const int nblk = B * (C / (nvec * 8));
-#define GMK_GN_STATS_REG(IT)                                                                                                          \
-    gn_silu_fwd_reg_kernel<IT, 8><<<nblk, threads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)nullptr, gamma, beta, mean, rstd, \
-                                                                            HW, C, groups, eps, B, planes, 0.f, 0, 0, xadd, xadd_stride,  \
-                                                                            tab_scale, tab_shift, tab_stride)
+#define GMK_GN_STATS_REG(IT)                                                                                                              \
+    do {                                                                                                                                  \
+        if (dtype == GMK_F16)                                                                                                             \
+            gn_silu_fwd_reg_kernel<f16_t, IT, 8><<<nblk, threads, 0, gmk_stream(stream)>>>((const f16_t*)x, (f16_t*)nullptr, gamma, beta, mean,  \
+                                                                                           rstd, HW, C, groups, eps, B, planes, 0.f, 0, 0, xadd, \
+                                                                                           xadd_stride, tab_scale, tab_shift, tab_stride);        \
+        else                                                                                                                              \
+            gn_silu_fwd_reg_kernel<bf16_t, IT, 8><<<nblk, threads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)nullptr, gamma, beta,     \
+                                                                                            mean, rstd, HW, C, groups, eps, B, planes, 0.f, 0, 0, \
+                                                                                            xadd, xadd_stride, tab_scale, tab_shift, tab_stride); \
+    } while (0)
         if (it == 1) GMK_GN_STATS_REG(1);
         else if (it == 2) GMK_GN_STATS_REG(2);
         else if (it == 4) GMK_GN_STATS_REG(4);
@@ -781,9 +817,14 @@ extern "C" int gmk_gn_stats(const void* x, const float* gamma, const float* beta
 #undef GMK_GN_STATS_REG
     } else {
         const int CS = gn_slab_channels(0, C, groups, HW, 2, false);
-        gn_silu_fwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
-            (const bf16_t*)x, (bf16_t*)nullptr, gamma, beta, mean, rstd, HW, C, groups, eps, nullptr, 0, 0, CS, B, 0.f, 0, 0, xadd,
-            xadd_stride, tab_scale, tab_shift, tab_stride);
+        if (dtype == GMK_F16)
+            gn_silu_fwd_kernel<f16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
+                (const f16_t*)x, (f16_t*)nullptr, gamma, beta, mean, rstd, HW, C, groups, eps, nullptr, 0, 0, CS, B, 0.f, 0, 0, xadd,
+                xadd_stride, tab_scale, tab_shift, tab_stride);
+        else
+            gn_silu_fwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
+                (const bf16_t*)x, (bf16_t*)nullptr, gamma, beta, mean, rstd, HW, C, groups, eps, nullptr, 0, 0, CS, B, 0.f, 0, 0, xadd,
+                xadd_stride, tab_scale, tab_shift, tab_stride);
     }
     return gmk_check_launch("gmk_gn_stats");
 }
@@ -792,8 +833,11 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
                                const float* rstd, const void* dadd1, const void* dadd2, void* dx, float* dgamma_part,
                                float* dbeta_part, float* dxsum, int dxsum_stride, int B, int HW, int C, int groups,
                                float drop_p, uint64_t drop_seed, uint64_t drop_offset, const float* xadd, int xadd_stride,
-                               int dtype, void* stream) {
+                               int dtype, int x_dtype, void* stream) {
     GMK_REQUIRE(!xadd || xadd_stride >= C, "gmk_gn_silu_bwd: xadd_stride %d < C %d", xadd_stride, C);
+    GMK_REQUIRE(x_dtype == dtype || (dtype == GMK_BF16 && x_dtype == GMK_F16),
+                "gmk_gn_silu_bwd: x of type %d with gradients of type %d (same type, or fp16 activations with bf16 gradients)", x_dtype, dtype);
+    const bool xf16 = x_dtype == GMK_F16;
     GMK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gmk_gn_silu_bwd: dropout probability %g outside [0, 1)", (double)drop_p);
     GMK_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma_part && dbeta_part,
                 "gmk_gn_silu_bwd: null pointer");
@@ -804,10 +848,17 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
     if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 32 == 0 && 32 % (C / groups) == 0 && HW > (gn_mode == 7 ? 511 : 64) &&
                HW <= 1024 && drop_p == 0.f) {
         const size_t lds = (size_t)HW * 64;
-#define GMK_GN_BWD_HYB(IT, TH)                                                                                                      \
-    gn_silu_bwd_hybrid_kernel<IT, TH><<<B * (C / 32), TH, lds, gmk_stream(stream)>>>(                                                \
-        (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,       \
-        dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride)
+#define GMK_GN_BWD_HYB(IT, TH)                                                                                                          \
+    do {                                                                                                                                \
+        if (xf16)                                                                                                                       \
+            gn_silu_bwd_hybrid_kernel<f16_t, IT, TH><<<B * (C / 32), TH, lds, gmk_stream(stream)>>>(                                     \
+                (const bf16_t*)dy, (const f16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,     \
+                dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);       \
+        else                                                                                                                            \
+            gn_silu_bwd_hybrid_kernel<bf16_t, IT, TH><<<B * (C / 32), TH, lds, gmk_stream(stream)>>>(                                    \
+                (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,    \
+                dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);       \
+    } while (0)
         if (HW <= 256) GMK_GN_BWD_HYB(4, 256);       // 14x14 (-16 % against the streaming kernel), 16x16 (-10 %); at 7x7 / 8x8 the whole-sample
                                                      // streaming kernel is as fast or faster (42 vs 46 us at 8x8, B = 2048)
         else if (HW <= 832) GMK_GN_BWD_HYB(13, 256); // 28x28: 3 workgroups of 4 waves per CU
@@ -816,12 +867,25 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
     } else if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 16 == 0 && 16 % (C / groups) == 0 && HW > 1024 &&
                HW <= 4096 && drop_p == 0.f) {
         // 64 x 64: 16-channel slabs, one workgroup of 16 waves per CU
-        static const hipError_t attr = hipFuncSetAttribute((const void*)gn_silu_bwd_hybrid_kernel<8, 1024, 2>,
+        static const hipError_t attr = hipFuncSetAttribute((const void*)gn_silu_bwd_hybrid_kernel<bf16_t, 8, 1024, 2>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32);
-        (void)attr;
-        gn_silu_bwd_hybrid_kernel<8, 1024, 2><<<B * (C / 16), 1024, (size_t)HW * 32, gmk_stream(stream)>>>(
-            (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,
-            dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);
+        static const hipError_t attr16 = hipFuncSetAttribute((const void*)gn_silu_bwd_hybrid_kernel<f16_t, 8, 1024, 2>,
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32);
+        (void)attr; (void)attr16;
+        if (xf16)
+            gn_silu_bwd_hybrid_kernel<f16_t, 8, 1024, 2><<<B * (C / 16), 1024, (size_t)HW * 32, gmk_stream(stream)>>>(
+                (const bf16_t*)dy, (const f16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,
+                dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);
+        else
+            gn_silu_bwd_hybrid_kernel<bf16_t, 8, 1024, 2><<<B * (C / 16), 1024, (size_t)HW * 32, gmk_stream(stream)>>>(
+                (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,
+                dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);
+    } else if (dtype == GMK_BF16 && xf16) {
+        const int CS = gn_slab_channels(gn_mode, C, groups, HW, 2, true);
+        gn_silu_bwd_kernel<bf16_t, f16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
+            (const bf16_t*)dy, (const f16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2,
+            (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, CS, B, drop_p, drop_seed, drop_offset, xadd,
+            xadd_stride);
     } else if (dtype == GMK_BF16) {
         const int CS = gn_slab_channels(gn_mode, C, groups, HW, 2, true);
         gn_silu_bwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
@@ -838,6 +902,19 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
     else
         GMK_REQUIRE(false, "gmk_gn_silu_bwd: bad dtype %d", dtype);
     return gmk_check_launch("gmk_gn_silu_bwd");
+}
+
+extern "C" int gmk_cast16(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream) {
+    GMK_REQUIRE(src && dst && n > 0 && n % 8 == 0, "gmk_cast16: null pointer or n %lld not a multiple of 8", (long long)n);
+    const int64_t nvec = n / 8;
+    const int blocks = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+    if (src_dtype == GMK_F16 && dst_dtype == GMK_BF16)
+        cast16_kernel<f16_t, bf16_t><<<blocks, 256, 0, gmk_stream(stream)>>>((const f16_t*)src, (bf16_t*)dst, nvec);
+    else if (src_dtype == GMK_BF16 && dst_dtype == GMK_F16)
+        cast16_kernel<bf16_t, f16_t><<<blocks, 256, 0, gmk_stream(stream)>>>((const bf16_t*)src, (f16_t*)dst, nvec);
+    else
+        GMK_REQUIRE(false, "gmk_cast16: %d -> %d (fp16 <-> bf16 only)", src_dtype, dst_dtype);
+    return gmk_check_launch("gmk_cast16");
 }
 
 extern "C" int gmk_chansum(const void* x, float* out, int out_stride, int B, int HW, int C, int dtype, void* stream) {

@@ -173,7 +173,6 @@ __global__ __launch_bounds__(256) void expand3x3_mfma_kernel(const float* __rest
         }
         // lane (pixel r, half h) holds channels 32 cb + 8 q4 + 4 h + (0..3), q4 = 0..3
         const unsigned row_b = g * (unsigned)C * (unsigned)sizeof(T);
-        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2s;
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
         if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -190,9 +189,8 @@ __global__ __launch_bounds__(256) void expand3x3_mfma_kernel(const float* __rest
                 unsigned pk[4][2];
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    const bf16x4 t = {(bf16_t)acc[cb][4 * q4], (bf16_t)acc[cb][4 * q4 + 1], (bf16_t)acc[cb][4 * q4 + 2], (bf16_t)acc[cb][4 * q4 + 3]};
-                    const auto u = __builtin_bit_cast(u32x2s, t);
-                    pk[q4][0] = u[0]; pk[q4][1] = u[1];
+                    pk[q4][0] = pack_pair<T>(sat16<T>(acc[cb][4 * q4]), sat16<T>(acc[cb][4 * q4 + 1]));
+                    pk[q4][1] = pack_pair<T>(sat16<T>(acc[cb][4 * q4 + 2]), sat16<T>(acc[cb][4 * q4 + 3]));
                 }
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4 += 2) {       // after the swap: lanes < 32 hold channels 8 q4 .. 8 q4 + 7, lanes >= 32 the next 8
@@ -337,7 +335,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(const float* __restr
         const unsigned ao = live ? (g * (unsigned)C + (unsigned)r) * (unsigned)sizeof(T) : kBadOff;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
-            if constexpr (sizeof(T) == 2)
+            if constexpr (__is_same(T, f16_t))
+                av[cb] = (float)__builtin_bit_cast(f16_t, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsb, ao, cb * 64, 0));
+            else if constexpr (sizeof(T) == 2)
                 av[cb] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsb, ao, cb * 64, 0) << 16);
             else
                 av[cb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsb, ao, cb * 128, 0));
@@ -459,14 +459,15 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a, 
 }
 
 
-// ---- head forward on the bf16 matrix cores (bf16 activations) ----------------------------------------------------------------
+// ---- head forward on the 16-bit matrix cores (bf16 or fp16 activations) ------------------------------------------------------
 // Pass 1 of the kernel above is a GEMM: Tap[j][q] = sum_c w[j][c] a[q][c], j = (image channel, tap) <= 27 rows, 128-deep.  Here it IS
 // one: v_mfma_f32_32x32x16_bf16 with the fp32 weights split into bf16 hi + lo parts (two MFMAs per k-step, the weight error drops to
 // 2^-17; the activations are bf16 already), the weights resident in registers as A operands, a lane's B operand = the 16 bytes of
 // its pixel's k-slice straight from HBM.  All image channels come out of ONE read of the activations (the VALU kernel re-read the band
 // once per image channel), D[j][q] lands a lane's 16 tap sums for its own pixel, which go to the LDS planes; pass 2 is unchanged.
 // One workgroup of 8 waves = one band of rows (+1 row above / below) of one image.
-__global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const bf16_t* __restrict__ a, const float* __restrict__ w,
+template <typename T>
+__global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const T* __restrict__ a, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out, int cs, int H,
                                                            int W, int band, int nbands, unsigned a_bytes) {
     constexpr int C = 128;
@@ -479,9 +480,10 @@ __global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const bf16_t* __rest
     const int e0 = max(r0 - 1, 0), e1 = min(r0 + rows + 1, H);       // rows whose activations feed this band
     const int next = (e1 - e0) * W, plane = (band + 2) * W;
     const int K = 9 * cs;
-    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a), 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a), 0, (int)a_bytes, 0x00020000);
     // A operands: row j = r, k = 16 ks + 8 h + e
-    bf16x8 whi[8], wlo[8];
+    typedef typename Frag16<T>::type frag_t;
+    frag_t whi[8], wlo[8];
     {
         const int sj = r / 9, tj = r - sj * 9;
 #pragma unroll
@@ -489,9 +491,9 @@ __global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const bf16_t* __rest
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float wv = r < K ? w[((size_t)sj * C + 16 * ks + 8 * h + e) * 9 + tj] : 0.f;
-                const bf16_t hi = (bf16_t)wv;
+                const T hi = (T)wv;
                 whi[ks][e] = hi;
-                wlo[ks][e] = (bf16_t)(wv - (float)hi);
+                wlo[ks][e] = (T)(wv - (float)hi);
             }
     }
     const unsigned pix0 = ((unsigned)b * H + e0) * W;               // first pixel of the region
@@ -515,9 +517,9 @@ __global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const bf16_t* __rest
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 bv = __builtin_bit_cast(bf16x8, bc[ks]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[ks], bv, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[ks], bv, acc, 0, 0, 0);
+            const frag_t bv = __builtin_bit_cast(frag_t, bc[ks]);
+            acc = mfma_32x32x16<T>(whi[ks], bv, acc);
+            acc = mfma_32x32x16<T>(wlo[ks], bv, acc);
         }
         const int q = blk * 32 + r;
         if (q < next) {
@@ -608,6 +610,7 @@ extern "C" int gmk_stem_fwd(const float* x, const float* w, const float* bias, v
     GMK_REQUIRE(x && w && bias && y, "gmk_stem_fwd: null pointer");
     GMK_REQUIRE(small_shape_ok(B, cin, H, W, C), "gmk_stem_fwd: unsupported shape B=%d cin=%d %dx%d C=%d", B, cin, H, W, C);
     if (dtype == GMK_BF16) launch_expand<bf16_t, false>(x, w, bias, (bf16_t*)y, B, cin, H, W, C, gmk_stream(stream));
+    else if (dtype == GMK_F16) launch_expand<f16_t, false>(x, w, bias, (f16_t*)y, B, cin, H, W, C, gmk_stream(stream));
     else if (dtype == GMK_F32) launch_expand<float, false>(x, w, bias, (float*)y, B, cin, H, W, C, gmk_stream(stream));
     else GMK_REQUIRE(false, "gmk_stem_fwd: bad dtype %d", dtype);
     return gmk_check_launch("gmk_stem_fwd");
@@ -663,6 +666,7 @@ extern "C" int gmk_head_wgrad(const float* dout, const void* a, float* dw_part, 
     GMK_REQUIRE(dout && a && dw_part, "gmk_head_wgrad: null pointer");
     GMK_REQUIRE(small_shape_ok(B, cout, H, W, C), "gmk_head_wgrad: unsupported shape");
     if (dtype == GMK_BF16) launch_wgrad<bf16_t, true>(dout, (const bf16_t*)a, dw_part, B, cout, H, W, C, gmk_stream(stream));
+    else if (dtype == GMK_F16) launch_wgrad<f16_t, true>(dout, (const f16_t*)a, dw_part, B, cout, H, W, C, gmk_stream(stream));
     else if (dtype == GMK_F32) launch_wgrad<float, true>(dout, (const float*)a, dw_part, B, cout, H, W, C, gmk_stream(stream));
     else GMK_REQUIRE(false, "gmk_head_wgrad: bad dtype %d", dtype);
     return gmk_check_launch("gmk_head_wgrad");
@@ -673,7 +677,7 @@ extern "C" int gmk_head_fwd(const void* a, const float* w, const float* bias, fl
     GMK_REQUIRE(a && w && bias && out, "gmk_head_fwd: null pointer");
     GMK_REQUIRE(small_shape_ok(B, cout, H, W, C), "gmk_head_fwd: unsupported shape");
     const size_t a_bytes = (size_t)B * H * W * C * 2;
-    if (dtype == GMK_BF16 && C == 128 && cout <= 3 && a_bytes < 0xFFFFFF00ull && gmk_kernel_choice(3, "GMK_DEV_VARIANT") != 41) {
+    if (gmk_is16(dtype) && C == 128 && cout <= 3 && a_bytes < 0xFFFFFF00ull && gmk_kernel_choice(3, "GMK_DEV_VARIANT") != 41) {
         // matrix-core kernel: all image channels from one read; 9 * cout fp32 planes of (band + 2) rows in <= 124 KiB of LDS
         int mb = (int)(126976 / ((size_t)36 * cout * W)) - 2;
         if (mb >= 1) {
@@ -684,11 +688,17 @@ extern "C" int gmk_head_fwd(const void* a, const float* w, const float* bias, fl
             }
             const int nb2 = (H + mb - 1) / mb;
             const size_t lds2 = (size_t)9 * cout * (mb + 2) * W * 4;
-            static const hipError_t attr = hipFuncSetAttribute((const void*)head_fwd_mfma_kernel,
+            static const hipError_t attr = hipFuncSetAttribute((const void*)head_fwd_mfma_kernel<bf16_t>,
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            (void)attr;
-            head_fwd_mfma_kernel<<<B * nb2, 512, lds2, gmk_stream(stream)>>>((const bf16_t*)a, w, bias, out, cout, H, W, mb, nb2,
-                                                                            (unsigned)a_bytes);
+            static const hipError_t attr16 = hipFuncSetAttribute((const void*)head_fwd_mfma_kernel<f16_t>,
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            (void)attr; (void)attr16;
+            if (dtype == GMK_F16)
+                head_fwd_mfma_kernel<f16_t><<<B * nb2, 512, lds2, gmk_stream(stream)>>>((const f16_t*)a, w, bias, out, cout, H, W, mb, nb2,
+                                                                                       (unsigned)a_bytes);
+            else
+                head_fwd_mfma_kernel<bf16_t><<<B * nb2, 512, lds2, gmk_stream(stream)>>>((const bf16_t*)a, w, bias, out, cout, H, W, mb, nb2,
+                                                                                        (unsigned)a_bytes);
             return gmk_check_launch("gmk_head_fwd");
         }
     }
@@ -702,6 +712,9 @@ extern "C" int gmk_head_fwd(const void* a, const float* w, const float* bias, fl
     if (dtype == GMK_BF16)
         head_fwd_kernel<bf16_t><<<B * nbands, 256, lds, gmk_stream(stream)>>>((const bf16_t*)a, w, bias, out, cout, H, W, C, inv_w,
                                                                               band, nbands);
+    else if (dtype == GMK_F16)
+        head_fwd_kernel<f16_t><<<B * nbands, 256, lds, gmk_stream(stream)>>>((const f16_t*)a, w, bias, out, cout, H, W, C, inv_w,
+                                                                             band, nbands);
     else if (dtype == GMK_F32)
         head_fwd_kernel<float><<<B * nbands, 256, lds, gmk_stream(stream)>>>((const float*)a, w, bias, out, cout, H, W, C, inv_w,
                                                                              band, nbands);

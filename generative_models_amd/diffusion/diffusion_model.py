@@ -43,7 +43,9 @@ def make_plugin(GMBase, AttrDict):
         DG.teacher_mode = "step1"
         DG.lr_scheduler = "none"
         # additions of the HIP path
-        DG.compute_dtype = "bf16"      # 'bf16' (MFMA) or 'fp32' (exact-fp32 MFMA, 1e-3 parity mode)
+        DG.compute_dtype = "bf16"      # 'bf16' (16-bit MFMA mode: bf16 gradients) or 'fp32' (exact-fp32 MFMA, 1e-3 parity mode)
+        DG.act_dtype = "fp16"          # 16-bit mode only: storage of forward activations / forward weight packs, 'fp16' (the precision of the
+                                       # reference's fp16 autocast forward, diffusion_model.py:68) or 'bf16' (the all-bf16 path, A/B)
         DG.in_channels = 1             # reference: 1 (simple_unet.py:93,41)
         DG.attention = 0               # 1: self-attention block behind `turn` (north_star / BASELINE config 5; not in the reference); 2: the same
                                        # with QK^T / PV on the fp8 matrix cores
@@ -52,14 +54,16 @@ def make_plugin(GMBase, AttrDict):
         def __init__(self, G):
             super().__init__(G)
             get = lambda k: G[k] if k in G else self.DG[k]
+            cdt = _DTYPES[get("compute_dtype")]
+            adt = cdt if cdt == torch.float32 else {"fp16": torch.float16, "bf16": torch.bfloat16}[get("act_dtype")]
             self.net = SimpleUnet(get("hidden_size"), get("dropout"), in_channels=get("in_channels"),
-                                  compute_dtype=_DTYPES[get("compute_dtype")], attention=int(get("attention")))
+                                  compute_dtype=cdt, attention=int(get("attention")), act_dtype=adt)
             weights_from = Path(G["weights_from"]) if "weights_from" in G else Path(".")
             if Path(get("teacher_path")) != Path(".") and weights_from == Path("."):      # diffusion_model.py:34-43
                 print("Loading teacher model")
                 self.load_state_dict(torch.load(get("teacher_path"), map_location="cpu"), strict=False)
                 self.teacher_net = SimpleUnet(get("hidden_size"), get("dropout"), in_channels=get("in_channels"),
-                                              compute_dtype=_DTYPES[get("compute_dtype")], attention=int(get("attention")))
+                                              compute_dtype=cdt, attention=int(get("attention")), act_dtype=adt)
                 self.teacher_net.load_state_dict(self.net.state_dict())
                 self.teacher_net.eval()
                 for param in self.teacher_net.parameters():

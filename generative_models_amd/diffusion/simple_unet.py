@@ -17,6 +17,7 @@ Extension over the reference: `in_channels` (the reference hard-codes 1, simple_
 Restriction: `channels` must be a multiple of 128 (the MFMA tile width); other widths raise.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -85,7 +86,7 @@ def _attach(root, dotted, param):
 
 
 class SimpleUnet(nn.Module):
-    def __init__(self, channels, dropout=0.0, in_channels=1, compute_dtype=torch.bfloat16, attention=False):
+    def __init__(self, channels, dropout=0.0, in_channels=1, compute_dtype=torch.bfloat16, attention=False, act_dtype=None):
         super().__init__()
         if channels != 128:
             raise ValueError(f"the HIP path is built for hidden_size 128 (the reference default, every BASELINE config; the MFMA "
@@ -96,7 +97,14 @@ class SimpleUnet(nn.Module):
             raise ValueError("in_channels must be 1..4")
         if compute_dtype not in (torch.bfloat16, torch.float32):
             raise ValueError("compute_dtype must be torch.bfloat16 or torch.float32")
-        self.channels, self.in_channels, self.compute_dtype = channels, in_channels, compute_dtype
+        # 16-bit mode: forward activations and forward weight packs are fp16 (11 significant bits: the precision of the reference's own fp16
+        # autocast forward, diffusion_model.py:68), gradients stay bf16 (fp32's range, so no GradScaler).  act_dtype=torch.bfloat16 (or
+        # GMK_ACT_DTYPE=bf16) is the all-bf16 path of rounds 1-2, kept for A/B runs.
+        if act_dtype is None:
+            act_dtype = torch.float16 if compute_dtype == torch.bfloat16 and os.environ.get("GMK_ACT_DTYPE", "fp16") != "bf16" else compute_dtype
+        if act_dtype != compute_dtype and not (compute_dtype == torch.bfloat16 and act_dtype == torch.float16):
+            raise ValueError("act_dtype must equal compute_dtype, or be torch.float16 next to compute_dtype=torch.bfloat16")
+        self.channels, self.in_channels, self.compute_dtype, self.act_dtype = channels, in_channels, compute_dtype, act_dtype
         self.dropout = float(dropout)      # nn.Dropout(p) of every ResBlock's out_layers (simple_unet.py:171); training mode only
         self.drop_seed, self._drop_counter = 0x5EEDD0, 0
         self.attention = bool(attention)
@@ -215,15 +223,20 @@ class SimpleUnet(nn.Module):
             self._packs = {}
             off = 0
             table = ([], [], [], [], [])
-            for n in names:
+            # forward packs in the activation type (fp16 in the 16-bit mode), data-gradient packs in the gradient type; the attention
+            # extension keeps bf16 internals (its input is converted at the block boundary)
+            f16 = self.act_dtype == torch.float16
+            self._pack_f16 = [int(f16 and not n.startswith("attn.")) for n in names]
+            for n, half in zip(names, self._pack_f16):
                 shp = self._shapes[n + ".weight"]
                 k = math.prod(shp)
-                self._packs[n] = (self._pack_buf[off:off + k], self._pack_buf[off + k:off + 2 * k])
+                wf = self._pack_buf[off:off + k]
+                self._packs[n] = (wf.view(torch.float16) if half else wf, self._pack_buf[off + k:off + 2 * k])
                 for col, v in zip(table, (self._offsets[n + ".weight"], off, shp[0], shp[1], shp[2])):
                     col.append(v)
                 off += 2 * k
             self._pack_table = table
-        ops.pack_conv_weights_multi(self.flat_params, self._pack_buf, self._pack_table)      # all convolutions, one launch
+        ops.pack_conv_weights_multi(self.flat_params, self._pack_buf, self._pack_table, self._pack_f16)      # all convolutions, one launch
         self._packs_stale = False
         self._packed_version = self._version_sum()
 
@@ -375,6 +388,7 @@ class SimpleUnet(nn.Module):
         P, C, T = self._pv, self.channels, self.compute_dtype
         B, H, W, _ = x.shape
         N = H * W
+        x = ops.cast16(x, T) if x.dtype != T else x        # fp16 stream -> the block's bf16 internals (16-bit mode)
         if N % 8 or N > 1024:
             raise ValueError(f"the attention level has {N} tokens: the HIP path needs a multiple of 8, at most 1024 "
                              f"(input sizes 32 / 64: 64 / 256 tokens)")
@@ -392,7 +406,7 @@ class SimpleUnet(nn.Module):
         out = ops.conv_igemm([o], self._packs["attn.proj"][0], C, 1, ops.NORMAL, (H, W), bias=P["attn.proj.bias"], residual=x)
         if ctx is not None:
             ctx["attn"] = (x, a, mean, rstd, qkv, Pm, o)
-        return out
+        return ops.cast16(out, self.act_dtype) if self.act_dtype != T else out
 
     def _attn_bwd(self, ctx, dout):
         """-> (dx, per-sample channel sums of dx)."""
@@ -492,7 +506,7 @@ class SimpleUnet(nn.Module):
         """x: NCHW fp32 [B, in_channels, H, W]; returns NCHW fp32.  ctx: dict receiving what backward needs."""
         if self._packs_stale or self._packed_version != self._version_sum():
             self._repack()
-        P, C, T = self._pv, self.channels, self.compute_dtype
+        P, C, T = self._pv, self.channels, self.act_dtype
         B, cin, H, W = x.shape
         if cin != self.in_channels or H % 4 or W % 4:
             raise ValueError(f"input {tuple(x.shape)}: need {self.in_channels} channels and H, W divisible by 4")

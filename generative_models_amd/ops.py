@@ -11,8 +11,10 @@ import torch
 
 from ._lib import check, lib
 
-F32, BF16 = 0, 1
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+F32, BF16, F16 = 0, 1, 2
+# fp16 = forward activations / forward weight packs of the 16-bit mode; bf16 = gradients (and the all-bf16 A/B mode)
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+_HALF = (torch.bfloat16, torch.float16)
 NORMAL, STRIDE2, UPSAMPLE2, TRANSPOSED2 = 0, 1, 2, 3
 
 # bench.py sets this to a list to collect (kernel name, start event, end event, algorithmic FLOPs) per launch of the
@@ -106,19 +108,25 @@ def pack_conv_weight(w, w_fwd, w_dgrad):
     ref = w_fwd if w_fwd is not None else w_dgrad
     for t in (w_fwd, w_dgrad):
         if t is not None:
-            _chk(t, ref.dtype, "pack")
+            _chk(t, name="pack")
             assert t.numel() == w.numel()
+    if w_fwd is not None and w_dgrad is not None and w_fwd.dtype != w_dgrad.dtype:      # fp16 forward pack + bf16 data-gradient pack
+        pack_conv_weight(w, w_fwd, None)
+        pack_conv_weight(w, None, w_dgrad)
+        return
     check(lib.gmk_pack_conv_weight(_p(w), _p(w_fwd), _p(w_dgrad), cout, cin, k, _DT[ref.dtype], _s()), "pack_conv_weight")
 
 
-def pack_conv_weights_multi(arena, packs, table):
+def pack_conv_weights_multi(arena, packs, table, fwd_f16=None):
     """One launch for every convolution of the net.  table = (w_off, pack_off, cout, cin, ksize) host int lists: tensor e is
-    arena[w_off[e]:...] (fp32 [cout][cin][k][k]) -> packs[pack_off[e]:...] = [w_fwd | w_dgrad]."""
+    arena[w_off[e]:...] (fp32 [cout][cin][k][k]) -> packs[pack_off[e]:...] = [w_fwd | w_dgrad]; fwd_f16[e] != 0: that entry's
+    w_fwd half is written as fp16 (bf16 packs only)."""
     import ctypes
     _f32(arena, "arena"); _chk(packs, name="packs")
     n = len(table[0])
     arrs = [(ctypes.c_int * n)(*[int(v) for v in col]) for col in table]
-    check(lib.gmk_pack_conv_weights_multi(_p(arena), _p(packs), n, *arrs, _DT[packs.dtype], _s()), "pack_conv_weights_multi")
+    flags = (ctypes.c_int * n)(*[int(v) for v in fwd_f16]) if fwd_f16 is not None else None
+    check(lib.gmk_pack_conv_weights_multi(_p(arena), _p(packs), n, *arrs, flags, _DT[packs.dtype], _s()), "pack_conv_weights_multi")
 
 
 # ---- GroupNorm + SiLU ------------------------------------------------------------------------------------
@@ -167,7 +175,8 @@ def gn_stats(x, gamma, beta, groups, tab_scale, tab_shift, eps=1e-5, xadd=None):
     """Statistics-only GroupNorm of x NHWC [B,H,W,C]: fills columns [0, C) of the fp32 table views tab_scale / tab_shift
     ([B, C] slices of a [B, Ctot] table: unit column stride, row stride Ctot) with the affine form of the normalisation,
     y = silu(x * scale + shift), for a convolution that applies it itself (conv_igemm gn=).  -> (mean, rstd)"""
-    _chk(x, torch.bfloat16, "x"); _f32(gamma, "gamma"); _f32(beta, "beta")
+    _chk(x, name="x"); _f32(gamma, "gamma"); _f32(beta, "beta")
+    assert x.dtype in _HALF
     B, H, W, C = x.shape
     for t in (tab_scale, tab_shift):
         assert t.dtype == torch.float32 and t.shape == (B, C) and t.stride(1) == 1 and t.is_cuda and t.data_ptr() % 16 == 0
@@ -181,23 +190,24 @@ def gn_stats(x, gamma, beta, groups, tab_scale, tab_shift, eps=1e-5, xadd=None):
 
 
 def conv_gn_fusable(srcs, cout=128):
-    """Can conv_igemm(srcs, ..., 3, NORMAL, gn=...) apply the GroupNorm of its (bf16) sources itself?"""
+    """Can conv_igemm(srcs, ..., 3, NORMAL, gn=...) apply the GroupNorm of its (16-bit) sources itself?"""
     s0 = srcs[0]
     c1 = srcs[1].shape[3] if len(srcs) > 1 else 0
     B, H, W, c0 = s0.shape
-    return s0.dtype == torch.bfloat16 and H * W >= GN_FUSE_MIN_HW and bool(lib.gmk_conv_gn_fusable(B, H, W, c0, c1, cout))
+    return s0.dtype in _HALF and H * W >= GN_FUSE_MIN_HW and bool(lib.gmk_conv_gn_fusable(B, H, W, c0, c1, cout))
 
 
 def gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=None, dadd2=None, dxsum=None, dropout=None, xadd=None):
-    """-> (dx, dgamma_part[B,C], dbeta_part[B,C]); dxsum (optional fp32 [B, >=C] view with row stride) is filled."""
-    _chk(x, name="x"); _chk(dy, x.dtype, "dy")
-    assert dy.shape == x.shape
+    """-> (dx, dgamma_part[B,C], dbeta_part[B,C]); dxsum (optional fp32 [B, >=C] view with row stride) is filled.
+    x (the saved forward input) may be fp16 next to bf16 gradients (dy, addends, dx)."""
+    _chk(x, name="x"); _chk(dy, name="dy")
+    assert dy.shape == x.shape and (x.dtype == dy.dtype or (x.dtype == torch.float16 and dy.dtype == torch.bfloat16)), (x.dtype, dy.dtype)
     for t in (dadd1, dadd2):
         if t is not None:
-            _chk(t, x.dtype, "dadd"); assert t.shape == x.shape
+            _chk(t, dy.dtype, "dadd"); assert t.shape == x.shape
     B, H, W, C = x.shape
     G = mean.shape[1]
-    dx = torch.empty_like(x)
+    dx = torch.empty_like(dy)
     dgp = torch.empty((B, C), device=x.device, dtype=torch.float32)
     dbp = torch.empty_like(dgp)
     stride = 0
@@ -208,8 +218,19 @@ def gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=None, dadd2=None, dxsum=No
     xs = _xadd_stride(xadd, B, C)
     check(lib.gmk_gn_silu_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dadd1), _p(dadd2), _p(dx),
                               _p(dgp), _p(dbp), _p(dxsum), stride, B, H * W, C, G, float(dp), int(dseed), int(doff),
-                              _p(xadd), xs, _DT[x.dtype], _s()), "gn_silu_bwd")
+                              _p(xadd), xs, _DT[dy.dtype], _DT[x.dtype], _s()), "gn_silu_bwd")
     return dx, dgp, dbp
+
+
+def cast16(x, dtype):
+    """fp16 <-> bf16 copy of a contiguous tensor (numel a multiple of 8)."""
+    _chk(x, name="x")
+    assert x.dtype in _HALF and dtype in _HALF
+    if x.dtype == dtype:
+        return x
+    out = torch.empty_like(x, dtype=dtype)
+    check(lib.gmk_cast16(_p(x), _p(out), x.numel(), _DT[x.dtype], _DT[dtype], _s()), "cast16")
+    return out
 
 
 def chansum(x, out=None):
@@ -306,7 +327,7 @@ def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, 
         gstride = c0 + c1
     mpix = B * hs * ws if mode == TRANSPOSED2 else B * ho * wo     # algorithmic work: that of the stride-2 conv
     part, tp, nt = None, 0, 0
-    if gn_stats and GN_STATS and ksize == 3 and mode in (NORMAL, UPSAMPLE2) and s0.dtype == torch.bfloat16 and 4 <= wo <= 254:
+    if gn_stats and GN_STATS and ksize == 3 and mode in (NORMAL, UPSAMPLE2) and s0.dtype == torch.bfloat16 and 4 <= wo <= 254:      # (bf16 only)
         r = 256 // wo
         tp, nt = r * wo, (B * ho + r - 1) // r
         part = torch.empty(nt * 8 * 2 * (cout // 4) * 2, device=s0.device, dtype=torch.float32)
@@ -349,8 +370,9 @@ def _workspace(nbytes, device, tag="conv"):
 def conv_wgrad(dy, srcs, ksize, mode, dw):
     """dw (fp32 [cout][sum C][k][k], a contiguous view into the gradient arena) = weight gradient."""
     _chk(dy, name="dy")
-    s0 = _chk(srcs[0], dy.dtype, "src0")
-    s1 = _chk(srcs[1], dy.dtype, "src1") if len(srcs) > 1 else None
+    s0 = _chk(srcs[0], name="src0")
+    s1 = _chk(srcs[1], s0.dtype, "src1") if len(srcs) > 1 else None
+    assert s0.dtype == dy.dtype or (s0.dtype == torch.float16 and dy.dtype == torch.bfloat16), (s0.dtype, dy.dtype)
     B, hs, ws_, c0 = s0.shape
     c1 = s1.shape[3] if s1 is not None else 0
     _, ho, wo, cout = dy.shape
@@ -361,7 +383,7 @@ def conv_wgrad(dy, srcs, ksize, mode, dw):
     wsbuf = _workspace(need, dy.device)
     with _Timed("conv_wgrad", 2.0 * B * ho * wo * cout * (c0 + c1) * ksize * ksize):
         check(lib.gmk_conv_wgrad(_p(dy), cout, _p(s0), _p(s1), c0, c1, B, hs, ws_, ho, wo, ksize, mode, _p(dw), cout,
-                                 _p(wsbuf), wsbuf.numel(), _DT[dy.dtype], _s()), "conv_wgrad")
+                                 _p(wsbuf), wsbuf.numel(), _DT[dy.dtype], _DT[s0.dtype], _s()), "conv_wgrad")
     return dw
 
 

@@ -8,8 +8,8 @@
  *   - every pointer is a BORROWED device pointer (e.g. torch `tensor.data_ptr()`), contiguous, 16-byte aligned;
  *     workspaces are passed in by the caller; all work is enqueued on `stream` (a hipStream_t).
  *   - re-entrant: callable from any host thread (autograd's backward thread, one process per GPU).
- *   - activations inside the network are NHWC `[B][H][W][C]` in `dtype` (GMK_F32 or GMK_BF16), C a
- *     multiple of 128; parameters, statistics, embeddings and everything in the diffusion algebra are fp32;
+ *   - activations inside the network are NHWC `[B][H][W][C]` in `dtype` (GMK_F32, GMK_BF16 or GMK_F16), C a
+ *     multiple of 128; a kernel that reads forward activations next to gradients takes the two types separately (`x_dtype`); parameters, statistics, embeddings and everything in the diffusion algebra are fp32;
  *     images at the model boundary are NCHW fp32 exactly as the reference passes them.
  */
 #ifndef GMK_H
@@ -22,6 +22,8 @@ extern "C" {
 
 #define GMK_F32 0
 #define GMK_BF16 1
+#define GMK_F16 2   /* fp16 storage: forward activations and forward weight packs of the 16-bit mode (gradients stay GMK_BF16); the
+                     * reference's GPU path computes its forward under fp16 autocast (diffusion_model.py:68) */
 #define GMK_ERR_ARG (-1)
 
 /* gather modes of the implicit-GEMM convolution (how an output pixel + filter tap maps to a source pixel) */
@@ -58,9 +60,10 @@ int gmk_pack_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int cout, i
                          void* stream);
 /* the same for up to 40 convolutions in ONE launch (the re-pack after every optimiser step): tensor e is the fp32
  * weight at arena + w_off[e] (elements) and is written as [w_fwd | w_dgrad], n = cout*cin*ksize^2 elements each, at
- * packs + pack_off[e] (elements of `dtype`).  The five tables are HOST arrays of `count` ints. */
+ * packs + pack_off[e] (elements of `dtype`).  fwd_f16 (optional; with dtype GMK_BF16 only): entries with a non-zero flag get their
+ * w_fwd half in fp16 (same 2-byte slots), the operand type of the 16-bit mode's forward.  The six tables are HOST arrays of `count` ints. */
 int gmk_pack_conv_weights_multi(const float* arena, void* packs, int count, const int* w_off, const int* pack_off,
-                                const int* cout, const int* cin, const int* ksize, int dtype, void* stream);
+                                const int* cout, const int* cin, const int* ksize, const int* fwd_f16, int dtype, void* stream);
 
 /* ---- GroupNorm + SiLU (simple_unet.py:39-40,161-162,169-170; always adjacent in the reference) ---------
  * x,y: NHWC [B][HW][C]; `groups` groups over these C channels (a 2C-channel concatenated input is handled as
@@ -79,12 +82,17 @@ int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const float* bet
  * triple to gmk_gn_silu_bwd. */
 /* backward of the above.  dx = d/dx + dadd1 + dadd2 (optional NHWC addends, e.g. the identity-skip gradient).
  * dgamma_part/dbeta_part: fp32 [B][C] per-sample partials (reduce with gmk_colsum); dxsum: optional fp32
- * [B][dxsum_stride] per-sample channel sums of the final dx (bias / embedding gradients). */
+ * [B][dxsum_stride] per-sample channel sums of the final dx (bias / embedding gradients).
+ * dtype: type of dy / dadd1 / dadd2 / dx; x_dtype: type of the saved input x (the same, or GMK_F16 next to GMK_BF16 gradients). */
 int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                     const float* rstd, const void* dadd1, const void* dadd2, void* dx, float* dgamma_part,
                     float* dbeta_part, float* dxsum, int dxsum_stride, int B, int HW, int C, int groups,
                     float drop_p, uint64_t drop_seed, uint64_t drop_offset, const float* xadd, int xadd_stride, int dtype,
-                    void* stream);
+                    int x_dtype, void* stream);
+/* dst[i] = (dst type) src[i], n a multiple of 8: fp16 <-> bf16 storage conversion (fp16 results saturate at the largest finite value).
+ * No reference call site: the self-attention extension (north_star, BASELINE configs[4]) keeps bf16 internals and converts the fp16
+ * forward stream at its boundary. */
+int gmk_cast16(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 /* out[b][c] = sum over pixels of x[b][:, c]  (NHWC, fp32 result [B][out_stride]) */
 int gmk_chansum(const void* x, float* out, int out_stride, int B, int HW, int C, int dtype, void* stream);
 /* out[c] (+)= sum_r part[r*stride + c], r < R, c < C  (fp32) */
@@ -132,10 +140,12 @@ int gmk_gn_stats(const void* x, const float* gamma, const float* beta, float* me
                  int xadd_stride, int dtype, void* stream);
 /* weight gradient: dw[n][k][tap] (reference layout `[Cout][Cin][k][k]`, fp32, overwritten or accumulated) =
  *   sum_pixels dy[b][oy][ox][n0_dy + n] * srcK[b][sy][sx][k],  same gather as the forward of `mode`.
- * workspace: gmk_conv_wgrad_workspace_bytes(B*ho*wo, ksize*ksize, cout, c0+c1) bytes. */
+ * workspace: gmk_conv_wgrad_workspace_bytes(B*ho*wo, ksize*ksize, cout, c0+c1) bytes.
+ * dtype: type of dy; x_dtype: type of the saved activations src0 / src1 - the same, or GMK_F16 next to GMK_BF16 gradients (the
+ * activations are re-rounded to bf16 on their way into LDS: bf16 x bf16 products, fp32 accumulation). */
 int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B,
                    int hs, int ws, int ho, int wo, int ksize, int mode, float* dw, int cout, void* workspace,
-                   int64_t workspace_bytes, int dtype, void* stream);
+                   int64_t workspace_bytes, int dtype, int x_dtype, void* stream);
 
 /* ---- stem / head convolutions (degenerate channel counts; simple_unet.py:92-94 and :41) ----------------
  * stem: x NCHW fp32 [B][cin][H][W] (cin <= 4) -> y NHWC [B][H][W][C]; w [C][cin][3][3], bias [C] */

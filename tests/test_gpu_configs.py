@@ -67,13 +67,15 @@ def test_whole_net_at_config_shapes(dtype, S, B, attention):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("B,S,attention", [(2048, 32, False), (1024, 64, False), (512, 64, True)],
-                         ids=["cfg2-B2048-3x32x32", "cfg3-shard-B1024-3x64x64", "cfg4-shard-B512-3x64x64-attn"])
+@pytest.mark.parametrize("B,S,attention", [(2048, 32, False), (1024, 64, False), (512, 64, 1), (512, 64, 2)],
+                         ids=["cfg2-B2048-3x32x32", "cfg3-shard-B1024-3x64x64", "cfg4-shard-B512-3x64x64-attn-bf16",
+                              "cfg4-shard-B512-3x64x64-attn-fp8"])
 def test_full_size_train_step_properties(B, S, attention):
     """The bench's own sizes (bf16): a train step is bit-for-bit reproducible, per-sample losses do not depend on the batch
     they ride in, and the gradient of the batch equals the sum of its halves' gradients (what data parallelism relies on)."""
     from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
     net, _ = live_net(torch.bfloat16, in_channels=3, attention=attention, seed=3)
+    assert net.attention_fp8 == (attention == 2)            # configs[4] as written: QK^T / PV on the fp8 matrix cores
     d = GaussianDiffusion(mean_type="v", num_steps=1000)
     g = torch.Generator().manual_seed(B + S)
     x = (torch.rand((B, 3, S, S), generator=g) * 2 - 1).cuda()
@@ -115,6 +117,26 @@ def test_distillation_integer_times_bit_exact(golden, name):
         _, uu = ops.logsnr_schedule(steps, ii.device, i_times=ii, num_steps=steps, want_u=True)
         ref = (torch.arange(steps, dtype=torch.int64) + 1).to(torch.float32) / steps       # the reference's expression (:90-91)
         assert uu.cpu().numpy().tobytes() == ref.numpy().tobytes()
+
+
+def test_fp8_attention_net_vs_oracle():
+    """configs[4] as written (`--attention 2`: fp8 e4m3 QK^T / PV) against the ORACLE (fp32 attention_block; parity unpinned: the block has
+    no reference counterpart) at the config's shape, 3x64x64 -> 256 tokens.  The block moves this net's output by 1.8e-2 (max-norm;
+    1.5e-2 in L2), its fp8 error is 5 - 8 % of the block's own output, so the whole net is held to the 16-bit bar of the north_star,
+    1e-2 max-norm - a bar the net without the block misses."""
+    from oracle import unet_ref as U
+    net, params = live_net(torch.bfloat16, in_channels=3, attention=2)
+    g = torch.Generator().manual_seed(8)
+    B = 2
+    z = torch.randn((B, 3, 64, 64), generator=g); l = torch.tensor([0.5, -3.0]); y = torch.tensor([1, 6])
+    with torch.no_grad():
+        ref = U.unet_forward(params, z, l, guide=y)
+        plain = U.unet_forward({k: v for k, v in params.items() if not k.startswith("attn.")}, z, l, guide=y)
+    out = net.forward_hip(z.cuda(), l.cuda(), y.cuda(), None)
+    e_max = rel_err(out, ref)
+    e_l2 = float((out.cpu().double() - ref.double()).norm() / ref.double().norm())
+    assert rel_err(plain, ref) > 1.5e-2                                 # the block is live: dropping it fails the bar below
+    assert e_max < 1e-2 and e_l2 < 5e-3, (e_max, e_l2)
 
 
 def test_fp8_attention_net_vs_bf16_attention_net():
