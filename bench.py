@@ -37,8 +37,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 / fp16 (guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3
+VECTOR_F32_PEAK_TFLOPS = 157.3     # the vector ALUs' fp32 peak: the ceiling the north_star's wording ("MFMA only for attention") would put on the convolutions
+HBM_PEAK_GBS = 8000.0              # HBM3E spec peak (a device copy measures 5.3 - 5.5 TB/s on this part: tools/hbm_probe.py)
 FWD_GFLOP = {(1, 28): 4.3913, (3, 32): 5.7447, (3, 64): 22.9754}      # U-Net forward per image
 
 CONFIGS = {      # name -> (in_channels, size, per-GPU batch, attention, BASELINE.json entry)
@@ -55,7 +57,25 @@ KERNEL_DESC = {
     "conv_igemm_kernel": "im2col register-staged convolution (small problems)",
     "conv_wgrad_slots_kernel": "3x3 weight gradient over padded slots, 8 compute waves (+ slab reduce)",
     "conv_wgrad_slots_ws_kernel": "3x3 weight gradient over padded slots, wave-specialised (+ slab reduce)",
-    "conv_wgrad_kernel": "im2col split-K weight gradient (+ slab reduce)"}
+    "conv_wgrad_kernel": "im2col split-K weight gradient (+ slab reduce)",
+    "gn_silu_fwd_reg_kernel": "GroupNorm+SiLU forward, register-resident (one read + one write of the tensor)",
+    "gn_silu_fwd_kernel": "GroupNorm+SiLU forward, two-sweep streaming (8x8 / 7x7 levels, 64-pixel rows)",
+    "gn_silu_bwd_hybrid_kernel": "GroupNorm+SiLU backward, dy in registers + x parked in LDS (x, dy, addends read once, dx written once)",
+    "gn_silu_bwd_kernel": "GroupNorm+SiLU backward, two-sweep streaming",
+    "expand3x3_mfma_kernel": "stem forward / head data gradient (<= 4 image channels <-> 128), fp32 MFMA",
+    "wgrad3x3_mfma_kernel": "stem / head weight gradients, fp32 MFMA", "head_fwd_mfma_kernel": "head forward (128 -> <= 3 image channels)",
+    "sumpool2x2_kernel": "backward of the nearest x2 upsample", "chansum_kernel": "per-sample channel sums (bias / embedding gradients)"}
+
+
+def kernel_hash():
+    """sha1 over the kernel sources: stamps the PMC traffic file so that a bench line never quotes counters of other kernels."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "generative_models_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "generative_models_amd", "csrc", "*.h")) + [os.path.join(ROOT, "include", "gmk.h")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -187,38 +207,64 @@ class Bench:
         return elapsed, nprof
 
     def roofline(self, prof, nprof, elapsed, steps, key):
+        """Dominant kernel against the MFMA roofline (FLOP/s), every HBM-bound kernel and every kernel above 2 % of the step against
+        the HBM roofline (algorithmic bytes / HIP-event time / 8 TB/s), all from this run's events; PMC traffic from the committed
+        counter passes only if they were taken on these very kernel sources."""
         if not prof:
             return None
         torch.cuda.synchronize()
         peak = MFMA_BF16_PEAK_TFLOPS if self.a.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
         by = {}
-        for name, s, e, f in prof:
-            d = by.setdefault(name, [0.0, 0.0, 0])
-            d[0] += s.elapsed_time(e); d[1] += f; d[2] += 1
-        dom = max(by, key=lambda k: by[k][0])          # dominant kernel = largest total HIP-event time
-        ms, fl, n = by[dom]
+        for name, s, e, f, nb in prof:
+            d = by.setdefault(name, [0.0, 0.0, 0, 0.0])
+            d[0] += s.elapsed_time(e); d[1] += f; d[2] += 1; d[3] += nb
+        mfma = {k: v for k, v in by.items() if k.startswith("conv")}
+        dom = max(mfma, key=lambda k: mfma[k][0])          # dominant kernel = largest total HIP-event time
+        ms, fl, n, _ = by[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        traffic, source, pmc = None, None, None
-        tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")     # HBM bytes per launch from separate rocprofv3 --pmc passes
+        traffic, source, pmc, stale = None, None, None, None
+        tfile = os.path.join(ROOT, "profiles", "r03_traffic.json")     # HBM bytes per launch from separate rocprofv3 --pmc passes
+        kern = {}
         if os.path.exists(tfile):
             rec = json.load(open(tfile)).get(key, {})
-            kern = rec.get("kernels", {})
-            traffic = kern.get(dom, {}).get("hbm_bytes_per_launch")
-            source = rec.get("provenance")
-            # MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE) of the two MFMA kernels from the same passes:
-            # achieved = peak x busy x (shader clock / 2.4 GHz), and the board's power cap trades one against the other
-            pmc = {k: {"mfma_busy_frac": kern[k]["mfma_busy_frac"], "sclk_ghz": kern[k].get("sclk_ghz_est")}
-                   for k in (dom, "conv_wgrad_slots_ws_kernel") if k in kern and "mfma_busy_frac" in kern[k]}
+            if rec.get("kernel_hash") == kernel_hash():
+                kern = rec.get("kernels", {})
+                traffic = kern.get(dom, {}).get("hbm_bytes_per_launch")
+                source = rec.get("provenance")
+                # MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE) of the two MFMA kernels from the same passes:
+                # achieved = peak x busy x (shader clock / 2.4 GHz), and the board's power cap trades one against the other
+                pmc = {k: {"mfma_busy_frac": kern[k]["mfma_busy_frac"], "sclk_ghz": kern[k].get("sclk_ghz_est")}
+                       for k in (dom, "conv_wgrad_slots_ws_kernel") if k in kern and "mfma_busy_frac" in kern[k]}
+            elif rec:
+                stale = f"profiles/r03_traffic.json was taken on kernel sources {rec.get('kernel_hash')}, this run is {kernel_hash()}: counters withheld"
         step_s = elapsed * nprof / steps
         share = lambda v: round(v[0] * 1e-3 / step_s, 3)
+        gbs = lambda v: v[3] / (v[0] * 1e-3) / 1e9
+        hbm = {}
+        for k, v in sorted(by.items(), key=lambda kv: -kv[1][0]):
+            if v[3] <= 0 or (share(v) < 0.02 and not k.startswith("gn_silu_bwd")):
+                continue
+            ent = {"achieved": round(gbs(v), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs(v) / HBM_PEAK_GBS, 4),
+                   "algorithmic_bytes_per_launch": round(v[3] / v[2]), "avg_launch_us": round(v[0] * 1e3 / v[2], 2),
+                   "launches_per_step": v[2] // nprof, "share_of_step_time": share(v), "what": KERNEL_DESC.get(k, "")}
+            if k in kern and "hbm_bytes_per_launch" in kern[k]:
+                ent["traffic"] = kern[k]["hbm_bytes_per_launch"]
+            hbm[k] = ent
+        hbm_bound = [k for k in hbm if not k.startswith("conv3x3") and not k.startswith("conv_wgrad_slots")]
+        top_hbm = max(hbm_bound, key=lambda k: by[k][0]) if hbm_bound else None
         return {"kernel": dom, "what": KERNEL_DESC.get(dom, ""), "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_provenance": source,
-                "pmc": pmc,
+                "traffic_withheld": stale, "pmc": pmc,
+                "vector_peak": VECTOR_F32_PEAK_TFLOPS, "achieved_vs_vector_peak": round(ach / VECTOR_F32_PEAK_TFLOPS, 2),
                 "launches_per_step": n // nprof, "avg_launch_us": round(ms * 1e3 / n, 2), "share_of_step_time": share(by[dom]),
                 "profiled_steps": nprof,
-                "other_kernels": {k: {"achieved": round(v[1] / (v[0] * 1e-3) / 1e12, 2), "avg_launch_us": round(v[0] * 1e3 / v[2], 2),
+                "other_kernels": {k: {"achieved": round(v[1] / (v[0] * 1e-3) / 1e12, 2), "achieved_vs_vector_peak": round(v[1] / (v[0] * 1e-3) / 1e12 / VECTOR_F32_PEAK_TFLOPS, 2),
+                                      "avg_launch_us": round(v[0] * 1e3 / v[2], 2),
                                       "launches_per_step": v[2] // nprof, "share_of_step_time": share(v)}
-                                  for k, v in by.items() if k != dom}}
+                                  for k, v in mfma.items() if k != dom},
+                "hbm": {"top_hbm_bound_kernel": top_hbm, "note": "achieved = ALGORITHMIC bytes (every operand tensor read once, every result written "
+                        "once; DESIGN.md section 4) / HIP-event time of this run; kernels above 2 % of the step and both GroupNorm backward forms",
+                        "kernels": hbm}}
 
     def time_sampler(self, model, y, init, kind, cond_w, steps):
         """One warm-up pass of 2 steps, then ONE timed pass of `steps` sampler iterations."""
@@ -311,11 +357,17 @@ class Bench:
         if self.rank == 0 and self.world == 1 and not a.no_cpu:
             cpu = cpu_baseline(a.cpu_seconds, plan[0][1][1], plan[0][1][0])
         if self.rank == 0:
+            act = os.environ.get("GMK_ACT_DTYPE", "fp16")
+            dtype_label = "fp32" if a.dtype == "fp32" else ("bf16" if act == "bf16" else "fp16_fwd+bf16_bwd")
+            precision = {"fp32": "fp32 storage, exact-fp32 MFMA", "bf16": "bf16 storage of activations, weight packs and gradients; fp32 accumulation, fp32 master weights",
+                         "fp16_fwd+bf16_bwd": "16-bit storage throughout: forward activations and forward weight packs fp16 (v_mfma_*_f16; the "
+                         "reference's forward runs under fp16 autocast), gradients and data-gradient packs bf16 (v_mfma_*_bf16, no loss scaling); "
+                         "fp32 accumulation, fp32 master weights, fp32 Adam"}[dtype_label]
             line = {"metric": "ddpm_train_images_per_sec", "value": head["value"], "unit": "images/s", "n_gpus": self.world,
                     "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
-                    "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-                    "config": {"workload": head["workload"], "global_batch": head["global_batch"], "parallelism": f"dp{self.world}",
-                               "optimizer": "fused Adam lr=3e-4", "mean_type": "v", "resident_batches": 4}}
+                    "scaling": "weak", "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
+                    "config": {"workload": head["workload"], "key": plan[0][0], "global_batch": head["global_batch"], "parallelism": f"dp{self.world}",
+                               "optimizer": "fused Adam lr=3e-4", "mean_type": "v", "resident_batches": 4, "precision": precision}}
             for k in ("steady_state", "sampler", "model_tflops", "roofline", "exchange"):
                 if head.get(k) is not None:
                     line[k] = head[k]

@@ -737,6 +737,7 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
         const int nvec = gn_mode == 5 ? 4 : 8;                 // 32- or 64-channel slabs (64 = whole 128-B lines)
         const int it = gn_reg_iter(HW, nvec), planes = (HW + it - 1) / it, threads = (planes * nvec + 63) / 64 * 64;
         const int nblk = B * (C / (nvec * 8));
+        gmk_note_kernel(21);
 #define GMK_GN_FWD_REG(IT, NV)                                                                                                           \
     do {                                                                                                                                 \
         if (dtype == GMK_F16)                                                                                                            \
@@ -762,16 +763,19 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
         }
 #undef GMK_GN_FWD_REG
     } else if (dtype == GMK_BF16) {
+        gmk_note_kernel(22);
         const int CS = stats_part ? C : gn_slab_channels(gn_mode, C, groups, HW, 2, false);
         gn_silu_fwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, HW, C, groups, eps, stats_part, tile_pixels, ntiles, CS, B, drop_p,
             drop_seed, drop_offset, xadd, xadd_stride);
     } else if (dtype == GMK_F16) {
+        gmk_note_kernel(22);
         const int CS = gn_slab_channels(gn_mode, C, groups, HW, 2, false);
         gn_silu_fwd_kernel<f16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const f16_t*)x, (f16_t*)y, gamma, beta, mean, rstd, HW, C, groups, eps, nullptr, 0, 0, CS, B, drop_p,
             drop_seed, drop_offset, xadd, xadd_stride);
     } else if (dtype == GMK_F32) {
+        gmk_note_kernel(22);
         const int CS = stats_part ? C : gn_slab_channels(gn_mode, C, groups, HW, 4, false);
         gn_silu_fwd_kernel<float><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const float*)x, (float*)y, gamma, beta, mean, rstd, HW, C, groups, eps, stats_part, tile_pixels, ntiles, CS, B, drop_p,
@@ -798,6 +802,7 @@ extern "C" int gmk_gn_stats(const void* x, const float* gamma, const float* beta
         const int nvec = 8;
         const int it = gn_reg_iter(HW, nvec), planes = (HW + it - 1) / it, threads = (planes * nvec + 63) / 64 * 64;
         const int nblk = B * (C / (nvec * 8));
+        gmk_note_kernel(21);
 #define GMK_GN_STATS_REG(IT)                                                                                                              \
     do {                                                                                                                                  \
         if (dtype == GMK_F16)                                                                                                             \
@@ -817,6 +822,7 @@ extern "C" int gmk_gn_stats(const void* x, const float* gamma, const float* beta
 #undef GMK_GN_STATS_REG
     } else {
         const int CS = gn_slab_channels(0, C, groups, HW, 2, false);
+        gmk_note_kernel(22);
         if (dtype == GMK_F16)
             gn_silu_fwd_kernel<f16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
                 (const f16_t*)x, (f16_t*)nullptr, gamma, beta, mean, rstd, HW, C, groups, eps, nullptr, 0, 0, CS, B, 0.f, 0, 0, xadd,
@@ -848,6 +854,7 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
     if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 32 == 0 && 32 % (C / groups) == 0 && HW > (gn_mode == 7 ? 511 : 64) &&
                HW <= 1024 && drop_p == 0.f) {
         const size_t lds = (size_t)HW * 64;
+        gmk_note_kernel(23);
 #define GMK_GN_BWD_HYB(IT, TH)                                                                                                          \
     do {                                                                                                                                \
         if (xf16)                                                                                                                       \
@@ -867,6 +874,7 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
     } else if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 16 == 0 && 16 % (C / groups) == 0 && HW > 1024 &&
                HW <= 4096 && drop_p == 0.f) {
         // 64 x 64: 16-channel slabs, one workgroup of 16 waves per CU
+        gmk_note_kernel(23);
         static const hipError_t attr = hipFuncSetAttribute((const void*)gn_silu_bwd_hybrid_kernel<bf16_t, 8, 1024, 2>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32);
         static const hipError_t attr16 = hipFuncSetAttribute((const void*)gn_silu_bwd_hybrid_kernel<f16_t, 8, 1024, 2>,
@@ -881,18 +889,21 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
                 (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,
                 dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);
     } else if (dtype == GMK_BF16 && xf16) {
+        gmk_note_kernel(24);
         const int CS = gn_slab_channels(gn_mode, C, groups, HW, 2, true);
         gn_silu_bwd_kernel<bf16_t, f16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const bf16_t*)dy, (const f16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2,
             (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, CS, B, drop_p, drop_seed, drop_offset, xadd,
             xadd_stride);
     } else if (dtype == GMK_BF16) {
+        gmk_note_kernel(24);
         const int CS = gn_slab_channels(gn_mode, C, groups, HW, 2, true);
         gn_silu_bwd_kernel<bf16_t><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2,
             (bf16_t*)dx, dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, CS, B, drop_p, drop_seed, drop_offset, xadd,
             xadd_stride);
     } else if (dtype == GMK_F32) {
+        gmk_note_kernel(24);
         const int CS = gn_slab_channels(gn_mode, C, groups, HW, 4, true);
         gn_silu_bwd_kernel<float><<<B * (C / CS), kThreads, 0, gmk_stream(stream)>>>(
             (const float*)dy, (const float*)x, gamma, beta, mean, rstd, (const float*)dadd1, (const float*)dadd2,

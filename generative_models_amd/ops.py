@@ -17,8 +17,8 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 _HALF = (torch.bfloat16, torch.float16)
 NORMAL, STRIDE2, UPSAMPLE2, TRANSPOSED2 = 0, 1, 2, 3
 
-# bench.py sets this to a list to collect (kernel name, start event, end event, algorithmic FLOPs) per launch of the
-# MFMA convolution kernels; events are recorded on the stream the kernel is launched on.
+# bench.py sets this to a list to collect (kernel name, start event, end event, algorithmic FLOPs, algorithmic HBM bytes) per launch
+# of the convolution, weight-gradient, GroupNorm and stem / head kernels; events are recorded on the stream the kernel is launched on.
 PROFILE = None
 
 
@@ -26,14 +26,22 @@ KERNEL_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_dma_kernel", 3: "conv3x3_
                 12: "conv_wgrad_slots_kernel", 13: "conv_wgrad_slots_ws_kernel",
                 # same binary as 4, launched on the zero-stuffed gradient of a stride-2 conv: 4x the algorithmic MFMA work by
                 # construction, so the profile keeps it apart from the plain 3x3 convolutions
-                5: "conv3x3_halo_ws_kernel[zero-stuffed transposed conv]"}
+                5: "conv3x3_halo_ws_kernel[zero-stuffed transposed conv]",
+                21: "gn_silu_fwd_reg_kernel", 22: "gn_silu_fwd_kernel", 23: "gn_silu_bwd_hybrid_kernel", 24: "gn_silu_bwd_kernel"}
+
+
+def _nbytes(*tensors):
+    return float(sum(t.numel() * t.element_size() for t in tensors if t is not None))
 
 
 class _Timed:
-    def __init__(self, name, flops):
+    """flops / nbytes: ALGORITHMIC work of the launch (DESIGN.md section 4: each operand tensor read once, each result written once);
+    fixed=True: `name` is the kernel's own name (no gmk_last_kernel lookup)."""
+
+    def __init__(self, name, flops, nbytes=0.0, fixed=False):
         self.on = PROFILE is not None
         if self.on:
-            self.name, self.flops = name, flops
+            self.name, self.flops, self.nbytes, self.fixed = name, flops, nbytes, fixed
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
 
@@ -44,7 +52,8 @@ class _Timed:
     def __exit__(self, *exc):
         if self.on:
             self.e.record()
-            PROFILE.append((KERNEL_NAMES.get(lib.gmk_last_kernel(), self.name), self.s, self.e, self.flops))
+            name = self.name if self.fixed else KERNEL_NAMES.get(lib.gmk_last_kernel(), self.name)
+            PROFILE.append((name, self.s, self.e, self.flops, self.nbytes))
 
 
 _IN_FLIGHT = {}
@@ -166,8 +175,9 @@ def gn_silu_fwd(x, gamma, beta, groups, eps=1e-5, dropout=None, xadd=None):
     part, tp, nt = st if st is not None else (None, 0, 0)
     dp, dseed, doff = dropout if dropout is not None else (0.0, 0, 0)
     xs = _xadd_stride(xadd, B, C)
-    check(lib.gmk_gn_silu_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), B, H * W, C, groups, eps, _p(part), tp, nt,
-                              float(dp), int(dseed), int(doff), _p(xadd), xs, _DT[x.dtype], _s()), "gn_silu_fwd")
+    with _Timed("gn_silu_fwd", 0.0, _nbytes(x, y)):
+        check(lib.gmk_gn_silu_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), B, H * W, C, groups, eps, _p(part), tp, nt,
+                                  float(dp), int(dseed), int(doff), _p(xadd), xs, _DT[x.dtype], _s()), "gn_silu_fwd")
     return y, mean, rstd
 
 
@@ -184,8 +194,9 @@ def gn_stats(x, gamma, beta, groups, tab_scale, tab_shift, eps=1e-5, xadd=None):
     mean = torch.empty((B, groups), device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     xs = _xadd_stride(xadd, B, C)
-    check(lib.gmk_gn_stats(_p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(tab_scale), _p(tab_shift), tab_scale.stride(0), B, H * W, C,
-                           groups, eps, _p(xadd), xs, _DT[x.dtype], _s()), "gn_stats")
+    with _Timed("gn_stats", 0.0, _nbytes(x)):
+        check(lib.gmk_gn_stats(_p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(tab_scale), _p(tab_shift), tab_scale.stride(0), B, H * W, C,
+                               groups, eps, _p(xadd), xs, _DT[x.dtype], _s()), "gn_stats")
     return mean, rstd
 
 
@@ -216,9 +227,10 @@ def gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=None, dadd2=None, dxsum=No
         stride = dxsum.stride(0)
     dp, dseed, doff = dropout if dropout is not None else (0.0, 0, 0)
     xs = _xadd_stride(xadd, B, C)
-    check(lib.gmk_gn_silu_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dadd1), _p(dadd2), _p(dx),
-                              _p(dgp), _p(dbp), _p(dxsum), stride, B, H * W, C, G, float(dp), int(dseed), int(doff),
-                              _p(xadd), xs, _DT[dy.dtype], _DT[x.dtype], _s()), "gn_silu_bwd")
+    with _Timed("gn_silu_bwd", 0.0, _nbytes(dy, x, dadd1, dadd2, dx)):
+        check(lib.gmk_gn_silu_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dadd1), _p(dadd2), _p(dx),
+                                  _p(dgp), _p(dbp), _p(dxsum), stride, B, H * W, C, G, float(dp), int(dseed), int(doff),
+                                  _p(xadd), xs, _DT[dy.dtype], _DT[x.dtype], _s()), "gn_silu_bwd")
     return dx, dgp, dbp
 
 
@@ -239,7 +251,8 @@ def chansum(x, out=None):
     if out is None:
         out = torch.empty((B, C), device=x.device, dtype=torch.float32)
     assert out.dtype == torch.float32 and out.shape == (B, C) and out.stride(1) == 1
-    check(lib.gmk_chansum(_p(x), _p(out), out.stride(0), B, H * W, C, _DT[x.dtype], _s()), "chansum")
+    with _Timed("chansum_kernel", 0.0, _nbytes(x), fixed=True):
+        check(lib.gmk_chansum(_p(x), _p(out), out.stride(0), B, H * W, C, _DT[x.dtype], _s()), "chansum")
     return out
 
 
@@ -281,7 +294,8 @@ def sumpool2x2(x):
     B, H2, W2, C = x.shape
     assert H2 % 2 == 0 and W2 % 2 == 0
     y = torch.empty((B, H2 // 2, W2 // 2, C), device=x.device, dtype=x.dtype)
-    check(lib.gmk_sumpool2x2(_p(x), _p(y), B, H2 // 2, W2 // 2, C, _DT[x.dtype], _s()), "sumpool2x2")
+    with _Timed("sumpool2x2_kernel", 0.0, _nbytes(x, y), fixed=True):
+        check(lib.gmk_sumpool2x2(_p(x), _p(y), B, H2 // 2, W2 // 2, C, _DT[x.dtype], _s()), "sumpool2x2")
     return y
 
 
@@ -331,7 +345,7 @@ def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, 
         r = 256 // wo
         tp, nt = r * wo, (B * ho + r - 1) // r
         part = torch.empty(nt * 8 * 2 * (cout // 4) * 2, device=s0.device, dtype=torch.float32)
-    with _Timed("conv_igemm", 2.0 * mpix * cout * (c0 + c1) * ksize * ksize):
+    with _Timed("conv_igemm", 2.0 * mpix * cout * (c0 + c1) * ksize * ksize, _nbytes(s0, s1, residual, out)):
         check(lib.gmk_conv_igemm(_p(s0), _p(s1), c0, c1, B, hs, ws, ho, wo, ksize, mode, _p(w), w_rows, n0, cout,
                                  _p(bias), _p(emb), emb_stride, _p(residual), _p(out), cout, _p(part),
                                  part.numel() * 4 if part is not None else 0, _p(gsc), _p(gsh), gstride, _DT[s0.dtype], _s()),
@@ -350,7 +364,7 @@ def conv1x1_pair(src, w, w_rows, n0=0):
     assert w.numel() == w_rows * c and n0 + 256 <= w_rows
     oa = torch.empty((B, H, W, 128), device=s0.device, dtype=s0.dtype)
     ob = torch.empty_like(oa)
-    with _Timed("conv_igemm", 2.0 * B * H * W * 256 * c):
+    with _Timed("conv_igemm", 2.0 * B * H * W * 256 * c, _nbytes(s0, oa, ob)):
         check(lib.gmk_conv1x1_pair(_p(s0), c, B, H, W, _p(w), w_rows, n0, _p(oa), _p(ob), _DT[s0.dtype], _s()), "conv1x1_pair")
     return oa, ob
 
@@ -381,7 +395,7 @@ def conv_wgrad(dy, srcs, ksize, mode, dw):
     need = lib.gmk_conv_wgrad_workspace_bytes(B * ho * wo, ksize * ksize, cout, c0 + c1)
     assert need > 0
     wsbuf = _workspace(need, dy.device)
-    with _Timed("conv_wgrad", 2.0 * B * ho * wo * cout * (c0 + c1) * ksize * ksize):
+    with _Timed("conv_wgrad", 2.0 * B * ho * wo * cout * (c0 + c1) * ksize * ksize, _nbytes(dy, s0, s1)):
         check(lib.gmk_conv_wgrad(_p(dy), cout, _p(s0), _p(s1), c0, c1, B, hs, ws_, ho, wo, ksize, mode, _p(dw), cout,
                                  _p(wsbuf), wsbuf.numel(), _DT[dy.dtype], _DT[s0.dtype], _s()), "conv_wgrad")
     return dw
@@ -392,7 +406,8 @@ def stem_fwd(x, w, bias, C, dtype):
     B, cin, H, W = x.shape
     assert w.shape == (C, cin, 3, 3)
     y = torch.empty((B, H, W, C), device=x.device, dtype=dtype)
-    check(lib.gmk_stem_fwd(_p(x), _p(w), _p(bias), _p(y), B, cin, H, W, C, _DT[dtype], _s()), "stem_fwd")
+    with _Timed("expand3x3_mfma_kernel", 2.0 * B * H * W * C * cin * 9, _nbytes(x, y), fixed=True):
+        check(lib.gmk_stem_fwd(_p(x), _p(w), _p(bias), _p(y), B, cin, H, W, C, _DT[dtype], _s()), "stem_fwd")
     return y
 
 
@@ -402,7 +417,8 @@ def stem_wgrad(x, dy, dw):
     C = dy.shape[3]
     nb = lib.gmk_stem_wgrad_blocks(B * H * W)
     part = torch.empty((nb, C * cin * 9), device=x.device, dtype=torch.float32)
-    check(lib.gmk_stem_wgrad(_p(x), _p(dy), _p(part), B, cin, H, W, C, _DT[dy.dtype], _s()), "stem_wgrad")
+    with _Timed("wgrad3x3_mfma_kernel", 2.0 * B * H * W * C * cin * 9, _nbytes(x, dy), fixed=True):
+        check(lib.gmk_stem_wgrad(_p(x), _p(dy), _p(part), B, cin, H, W, C, _DT[dy.dtype], _s()), "stem_wgrad")
     return colsum(part, dw)
 
 
@@ -412,7 +428,8 @@ def head_fwd(a, w, bias):
     cout = w.shape[0]
     assert w.shape == (cout, C, 3, 3)
     out = torch.empty((B, cout, H, W), device=a.device, dtype=torch.float32)
-    check(lib.gmk_head_fwd(_p(a), _p(w), _p(bias), _p(out), B, cout, H, W, C, _DT[a.dtype], _s()), "head_fwd")
+    with _Timed("head_fwd_mfma_kernel", 2.0 * B * H * W * C * cout * 9, _nbytes(a, out), fixed=True):
+        check(lib.gmk_head_fwd(_p(a), _p(w), _p(bias), _p(out), B, cout, H, W, C, _DT[a.dtype], _s()), "head_fwd")
     return out
 
 
@@ -421,7 +438,8 @@ def head_dgrad(dout, w, dtype):
     B, cout, H, W = dout.shape
     C = w.shape[1]
     da = torch.empty((B, H, W, C), device=dout.device, dtype=dtype)
-    check(lib.gmk_head_dgrad(_p(dout), _p(w), _p(da), B, cout, H, W, C, _DT[dtype], _s()), "head_dgrad")
+    with _Timed("expand3x3_mfma_kernel", 2.0 * B * H * W * C * cout * 9, _nbytes(dout, da), fixed=True):
+        check(lib.gmk_head_dgrad(_p(dout), _p(w), _p(da), B, cout, H, W, C, _DT[dtype], _s()), "head_dgrad")
     return da
 
 
@@ -434,7 +452,8 @@ def head_wgrad(dout, a, dwb):
     assert dwb.numel() == n
     nb = lib.gmk_head_wgrad_blocks(B * H * W)
     part = torch.empty((nb, n), device=a.device, dtype=torch.float32)
-    check(lib.gmk_head_wgrad(_p(dout), _p(a), _p(part), B, cout, H, W, C, _DT[a.dtype], _s()), "head_wgrad")
+    with _Timed("wgrad3x3_mfma_kernel", 2.0 * B * H * W * C * cout * 9, _nbytes(dout, a), fixed=True):
+        check(lib.gmk_head_wgrad(_p(dout), _p(a), _p(part), B, cout, H, W, C, _DT[a.dtype], _s()), "head_wgrad")
     return colsum(part, dwb)
 
 

@@ -35,6 +35,12 @@ def rnd(*shape, seed=0):
     return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
 
 
+def both16(x):
+    """x rounded so that it is exactly representable in bf16 AND fp16 (bf16 values below 2^-17 are not: fp16 subnormals stop at 2^-24)."""
+    x = x.to(BF).float()
+    return torch.where(x.abs() < 2.0 ** -10, torch.zeros_like(x), x)
+
+
 def nhwc(x, dtype):
     return x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
 
@@ -134,9 +140,9 @@ def test_groupnorm_fp16_forward_and_mixed_backward(ops, C, G, S):
     assert rel_err(nchw(dx), x.grad + add1) < 1e-2
     assert rel_err(dgp.sum(0), gamma.grad) < 5e-3 and rel_err(dbp.sum(0), beta.grad) < 5e-3
     # the same kernels on a bf16-representable x give the bits of the all-bf16 call (only the unpack differs)
-    xb = x.detach().bfloat16()
-    dx1, g1, b1 = ops.gn_silu_bwd(nhwc(dy, BF), nhwc(xb.float(), H), gamma.detach().cuda(), beta.detach().cuda(), mean, rstd)
-    dx2, g2, b2 = ops.gn_silu_bwd(nhwc(dy, BF), nhwc(xb.float(), BF), gamma.detach().cuda(), beta.detach().cuda(), mean, rstd)
+    xb = both16(x.detach())
+    dx1, g1, b1 = ops.gn_silu_bwd(nhwc(dy, BF), nhwc(xb, H), gamma.detach().cuda(), beta.detach().cuda(), mean, rstd)
+    dx2, g2, b2 = ops.gn_silu_bwd(nhwc(dy, BF), nhwc(xb, BF), gamma.detach().cuda(), beta.detach().cuda(), mean, rstd)
     assert torch.equal(dx1, dx2) and torch.equal(g1, g2) and torch.equal(b1, b2)
 
 
@@ -156,7 +162,7 @@ def test_weight_gradient_with_fp16_activations(ops, lib, B, S, two, mode, ks, fo
     outs = {}
     try:
         lib.gmk_set_kernel_choice(-1, force, -1)
-        for tag, srcs in (("bf16", [x.to(BF).cuda() for x in xs]), ("f16 exact", [x.to(BF).to(H).cuda() for x in xs]),
+        for tag, srcs in (("bf16", [both16(x).to(BF).cuda() for x in xs]), ("f16 exact", [both16(x).to(H).cuda() for x in xs]),
                           ("f16", [x.to(H).cuda() for x in xs])):
             dw = torch.empty(C, cin, ks, ks, device="cuda")
             ops.conv_wgrad(dy, srcs, ks, mode, dw)
@@ -186,7 +192,7 @@ def test_stem_and_head_with_fp16_activations(ops, cs, S, B):
     assert rel_err(out, F.conv2d(a, wh, bh, padding=1)) < 1e-3
     # head weight gradient (exact-fp32 MFMA on the converted activations): bf16-representable activations give identical bits
     dout = rnd(B, cs, S, S, seed=47).cuda()
-    ab = a.bfloat16().float()
+    ab = both16(a)
     n = cs * C * 9 + cs
     g1 = ops.head_wgrad(dout, nhwc(ab, H), torch.empty(n, device="cuda")).clone()
     g2 = ops.head_wgrad(dout, nhwc(ab, BF), torch.empty(n, device="cuda")).clone()
