@@ -642,14 +642,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
                 if (ty >= 0 && ty < g.lim_h && tx >= 0 && tx < g.lim_w && !((ty | tx) & g.mask)) {
                     const int64_t pix = ((int64_t)b * g.hs + (ty >> g.shift)) * g.ws + (tx >> g.shift);
                     vx = *reinterpret_cast<const u32x4*>(src + pix * cs + ci_off + sc * EPC);
-                    if constexpr (!__is_same(T, TX)) {
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            float lo, hi;
-                            unpack_pair<TX>(vx[d], lo, hi);
-                            vx[d] = pack_pair<T>(lo, hi);
-                        }
-                    }
                 }
             }
             ry[i] = vy; rx[i] = vx;
@@ -659,7 +651,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<u32x4*>(Ys + buf * 16384 + lds_w[i]) = ry[i];
-            *reinterpret_cast<u32x4*>(Xs + buf * 16384 + lds_w[i]) = rx[i];
+            u32x4 vx = rx[i];
+            if constexpr (!__is_same(T, TX)) {      // re-round here, behind the MFMAs the loads were issued under - not where they are issued
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    float lo, hi;
+                    unpack_pair<TX>(vx[d], lo, hi);
+                    vx[d] = pack_pair<T>(lo, hi);
+                }
+            }
+            *reinterpret_cast<u32x4*>(Xs + buf * 16384 + lds_w[i]) = vx;
         }
     };
 

@@ -276,9 +276,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
         auto advance = [&](int& row, int& xe, int dr, int dx) { xe += dx; row += dr; if (xe >= WE) { xe -= WE; ++row; } };
         auto pixel = [&](int row, int xe, int shift) -> unsigned {
             const int b = (int)(((float)row + 0.5f) * inv_re);           // exact for row < 2^22
-            const int ye = row - b * RE;
+            const int ye = row - __mul24(b, RE);                         // (24-bit multiplies: full rate; every product is a pixel / row index < 2^24)
             const bool ok = b < p.B && ye >= 1 && xe >= 1;               // ye <= H and xe <= W hold by construction
-            return ok ? (unsigned)((b * (H >> shift) + ((ye - 1) >> shift)) * (W >> shift) + ((xe - 1) >> shift)) : kBadPix;
+            return ok ? (unsigned)(__mul24(__mul24(b, H >> shift) + ((ye - 1) >> shift), W >> shift) + ((xe - 1) >> shift)) : kBadPix;
         };
         int xc = c_begin - LOOK, yc = c_begin;
         int xrow, xxe, yrow, yxe;
@@ -321,11 +321,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
         if constexpr (kXF16) {
             typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
             constexpr int NSET = AHEAD - 1;                  // register sets: AHEAD - 2 blocks in flight + the one being written
-            const char* xsrc = (const char*)(second ? p.src1 : p.src0);
+            // the X descriptor as four scalars for the inline-asm loads (same words as make_buffer_rsrc: base, size, raw 32-bit format): a
+            // border slot's out-of-range offset reads zeros, as in the DMA form - no validity masks, 32-bit address arithmetic only
+            typedef __attribute__((ext_vector_type(4))) int i32x4;
+            const unsigned long long xbase = (unsigned long long)(second ? p.src1 : p.src0);
+            const i32x4 xdesc = {(int)(unsigned)xbase, (int)((unsigned)(xbase >> 32) & 0xFFFFu), (int)(second ? p.nb1 : p.nb0), 0x00020000};
             u32x4 xr[NSET][2];
-            unsigned xvalid[NSET];                           // bit u: this lane's slot of load u is a pixel (else border: zeros)
             int xrp[NSET];                                   // ring position the set goes to (wave-uniform)
-            auto load_x = [&](u32x4 (&r)[2], unsigned& valid, int& rp) {      // 2 global loads (inline asm: they stay in flight across barriers)
+            auto load_x = [&](u32x4 (&r)[2], int& rp) {      // 2 buffer loads to registers (inline asm: they stay in flight across barriers)
                 unsigned pix0 = kBadPix, pix1 = kBadPix;
                 if (xc >= 0) {
                     int r1 = xrow, x1 = xxe;
@@ -333,15 +336,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
                     pix0 = pixel(xrow, xxe, p.xshift); pix1 = pixel(r1, x1, p.xshift);
                     advance(xrow, xxe, d64r, d64x);
                 }
-                valid = (pix0 != kBadPix ? 1u : 0u) | (pix1 != kBadPix ? 2u : 0u);
-                const char* a0 = xsrc + (pix0 != kBadPix ? __umul24(pix0, xs_b) + xoff_b + lc : 0u);
-                const char* a1 = xsrc + (pix1 != kBadPix ? __umul24(pix1, xs_b) + xoff_b + lc : 0u);
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[0]) : "v"(a0) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[1]) : "v"(a1) : "memory");
+                const unsigned v0 = __umul24(pix0, xs_b) + xoff_b + lc, v1 = __umul24(pix1, xs_b) + xoff_b + lc;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[0]) : "v"(v0), "s"(xdesc) : "memory");
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[1]) : "v"(v1), "s"(xdesc) : "memory");
                 rp = xc & 7;
                 ++xc;
             };
-            auto store_x = [&](u32x4 (&r)[2], unsigned valid, int rp) {       // fp16 -> bf16, ds_write_b128 (+ mirror)
+            auto store_x = [&](u32x4 (&r)[2], int rp) {       // fp16 -> bf16, ds_write_b128 (+ mirror)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     asm volatile("" : "+v"(r[u]));
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
                     for (int d = 0; d < 4; ++d) {
                         float lo, hi;
                         unpack_pair<f16_t>(r[u][d], lo, hi);
-                        o[d] = ((valid >> u) & 1u) ? pack_pair<bf16_t>(lo, hi) : 0u;
+                        o[d] = pack_pair<bf16_t>(lo, hi);
                     }
                     char* dst = smem + kWsXBase + rp * 8192 + pw * 2048 + u * 1024 + lane * 16;
                     *reinterpret_cast<u32x4*>(dst) = o;
@@ -360,17 +361,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
             // prologue: X chunks c-LOOK .. c+LOOK+1 through a temporary register set each, dY chunks c and c+1, all awaited and written:
             // barrier 0 then sees what the DMA form guarantees (every chunk up to c + 1); blocks 2 .. AHEAD-1 follow and stay in flight
             {
-                u32x4 t[2 * LOOK + 2][2]; unsigned tv[2 * LOOK + 2]; int tp[2 * LOOK + 2];
+                u32x4 t[2 * LOOK + 2][2]; int tp[2 * LOOK + 2];
 #pragma unroll
-                for (int k = 0; k < 2 * LOOK + 1; ++k) load_x(t[k], tv[k], tp[k]);
+                for (int k = 0; k < 2 * LOOK + 1; ++k) load_x(t[k], tp[k]);
                 issue_y();
-                load_x(t[2 * LOOK + 1], tv[2 * LOOK + 1], tp[2 * LOOK + 1]); issue_y();
+                load_x(t[2 * LOOK + 1], tp[2 * LOOK + 1]); issue_y();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int k = 0; k < 2 * LOOK + 2; ++k) store_x(t[k], tv[k], tp[k]);
+                for (int k = 0; k < 2 * LOOK + 2; ++k) store_x(t[k], tp[k]);
             }
 #pragma unroll
-            for (int k = 2; k < AHEAD; ++k) { load_x(xr[k % NSET], xvalid[k % NSET], xrp[k % NSET]); issue_y(); }
+            for (int k = 2; k < AHEAD; ++k) { load_x(xr[k % NSET], xrp[k % NSET]); issue_y(); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // step s: block s + 1 (set (s + 1) % NSET) has landed -> write it; barrier; block s + AHEAD goes into the set just freed
             auto step = [&](auto set_tag, int s) {
@@ -378,11 +379,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
                 if (s > 0) {
                     if (AHEAD == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    store_x(xr[SET], xvalid[SET], xrp[SET]);
+                    store_x(xr[SET], xrp[SET]);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_s_barrier();
-                load_x(xr[SET], xvalid[SET], xrp[SET]);
+                load_x(xr[SET], xrp[SET]);
                 issue_y();
             };
             for (int s = 0; s < nsteps;) {        // set of step s = (s + 1) % NSET, statically indexed

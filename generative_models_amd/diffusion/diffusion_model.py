@@ -16,6 +16,8 @@ import random
 from functools import partial
 from pathlib import Path
 
+import os
+
 import torch
 
 from .. import common, ops, parallel
@@ -44,7 +46,7 @@ def make_plugin(GMBase, AttrDict):
         DG.lr_scheduler = "none"
         # additions of the HIP path
         DG.compute_dtype = "bf16"      # 'bf16' (16-bit MFMA mode: bf16 gradients) or 'fp32' (exact-fp32 MFMA, 1e-3 parity mode)
-        DG.act_dtype = "fp16"          # 16-bit mode only: storage of forward activations / forward weight packs, 'fp16' (the precision of the
+        DG.act_dtype = os.environ.get("GMK_ACT_DTYPE", "fp16")      # 16-bit mode only: storage of forward activations / forward weight packs, 'fp16' (the precision of the
                                        # reference's fp16 autocast forward, diffusion_model.py:68) or 'bf16' (the all-bf16 path, A/B)
         DG.in_channels = 1             # reference: 1 (simple_unet.py:93,41)
         DG.attention = 0               # 1: self-attention block behind `turn` (north_star / BASELINE config 5; not in the reference); 2: the same

@@ -25,13 +25,42 @@ def errs(a, b):
     return float((a - b).abs().max() / b.abs().max()), float((a - b).norm() / b.norm())
 
 
+MODES = ((torch.float32, torch.float32), (torch.bfloat16, torch.float16), (torch.bfloat16, torch.bfloat16))
+
+
+def mode_name(dtype, act):
+    return "fp32" if dtype == torch.float32 else ("fp16 fwd + bf16 bwd" if act == torch.float16 else "all bf16 (rounds 1-2)")
+
+
+def ragged():
+    """The oracle-only shapes of tests/test_gpu_unet.py::test_odd_batches_and_sizes_bf16_vs_fp32_vs_oracle and of the config tests
+    (3-channel nets: parity unpinned), forward in training mode (activations kept), per storage mode."""
+    for cin, B, S in ((1, 1, 28), (1, 5, 32), (1, 7, 28), (1, 3, 12), (3, 3, 32), (3, 2, 64)):
+        params = U.reference_init_params(128, cin, seed=0, zero_out_layers=False)
+        g = torch.Generator().manual_seed(B * 100 + S)
+        z = torch.randn((B, cin, S, S), generator=g)
+        l = torch.rand((B,), generator=g) * 30 - 15
+        y = torch.randint(-1, 10, (B,), generator=g)
+        with torch.no_grad():
+            ref = U.unet_forward(params, z, l, guide=y)
+        row = []
+        for dtype, act in MODES:
+            net = SimpleUnet(128, 0.0, in_channels=cin, compute_dtype=dtype, act_dtype=act)
+            net.load_state_dict(params, strict=True)
+            net = net.cuda()
+            out = net.forward_hip(z.cuda(), l.cuda(), y.cuda(), None, ctx={})
+            e = errs(out, ref)
+            row.append(f"{mode_name(dtype, act)}: max {e[0]:.2e} L2 {e[1]:.2e}")
+        print(f"ragged {cin}x{S}x{S} B={B} vs oracle | " + " | ".join(row), flush=True)
+
+
 def main():
     T = torch.from_numpy
     for name in ("definit_c128_s28.npz", "definit_c128_s32.npz"):
         g = np.load(os.path.join(GOLD, name), allow_pickle=True)
         params = U.reference_init_params(128, 1, seed=int(g["init_seed"]), zero_out_layers=False)
-        for dtype in (torch.float32, torch.bfloat16):
-            net = SimpleUnet(128, 0.0, compute_dtype=dtype)
+        for dtype, act in MODES:
+            net = SimpleUnet(128, 0.0, compute_dtype=dtype, act_dtype=act)
             net.load_state_dict(params, strict=True)
             net = net.cuda()
             z, l, y = T(g["z"]).cuda(), T(g["logsnr"]).cuda(), T(g["guide"]).cuda()
@@ -46,10 +75,11 @@ def main():
             ref = T(g["grad_norms"])
             worst = float(((norms - ref).abs() / ref.abs().clamp_min(1e-3 * float(ref.abs().max()))).max())
             eg = {k[6:]: errs(net.grad(k[6:]), T(g[k])) for k in g.files if k.startswith("grad__")}
-            print(f"{name} {str(dtype)[6:]:8s} v max {e_v[0]:.2e} L2 {e_v[1]:.2e} | no-label max {e_n[0]:.2e} L2 {e_n[1]:.2e} | "
+            print(f"{name} {mode_name(dtype, act):22s} v max {e_v[0]:.2e} L2 {e_v[1]:.2e} | no-label max {e_n[0]:.2e} L2 {e_n[1]:.2e} | "
                   f"loss max {e_l[0]:.2e} | worst grad-norm dev {worst:.2e} | " +
                   " ".join(f"{k} max {v[0]:.2e}" for k, v in eg.items()), flush=True)
 
 
 if __name__ == "__main__":
     main()
+    ragged()
