@@ -75,6 +75,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     typedef typename Frag16<T>::type frag_t;
     typedef typename Frag16<T>::half_type half_t;
     constexpr int ES = 2;
+    fp16_saturating_stores<T>();
     __shared__ __attribute__((aligned(16))) char smem[kWOFF + 3 * kWST];
 
     const int tid = threadIdx.x;
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
     typedef typename Frag16<T>::type frag_t;
     typedef typename Frag16<T>::half_type half_t;
     constexpr int ES = 2;
+    fp16_saturating_stores<T>();
     __shared__ __attribute__((aligned(16))) char smem[kWOFF + 3 * kWST];
 
     const int tid = threadIdx.x;

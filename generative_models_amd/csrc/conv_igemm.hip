@@ -76,6 +76,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 template <typename T>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
     constexpr int ES = sizeof(T);
+    fp16_saturating_stores<T>();
     constexpr int KCH = 128 / ES;          // elements per 128-byte K chunk
     constexpr int EPC = 16 / ES;           // elements per 16-byte staging chunk
     __shared__ __attribute__((aligned(16))) char smem[65536];
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 template <typename T>
 __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams p) {
     constexpr int ES = sizeof(T);
+    fp16_saturating_stores<T>();
     constexpr int KCH = 128 / ES;
     constexpr int NS = 3, A_BYTES = 32768, STAGE = 49152;
     constexpr int kEpiStores = ES == 2 ? 8 : 16;

@@ -51,6 +51,12 @@ struct SlotParams {
 
 struct SlotPos { int b, ye, xe; };
 
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {      // a * b + c on the low 24 bits of a and b (full rate)
+    unsigned d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 __device__ __forceinline__ SlotPos slot_decode(int S, int RE, int WE) {
     SlotPos p;
     const int rowi = S / WE;
@@ -278,7 +284,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
             const int b = (int)(((float)row + 0.5f) * inv_re);           // exact for row < 2^22
             const int ye = row - __mul24(b, RE);                         // (24-bit multiplies: full rate; every product is a pixel / row index < 2^24)
             const bool ok = b < p.B && ye >= 1 && xe >= 1;               // ye <= H and xe <= W hold by construction
-            return ok ? (unsigned)(__mul24(__mul24(b, H >> shift) + ((ye - 1) >> shift), W >> shift) + ((xe - 1) >> shift)) : kBadPix;
+            // v_mad_u32_u24 by hand: left to itself the compiler turns these into v_mul_lo_u32 / v_mad_u64_u32 (quarter rate), and every
+            // producer VALU cycle is taken from the consumer wave on the same SIMD
+            const unsigned rowpix = mad24((unsigned)b, (unsigned)(H >> shift), (unsigned)((ye - 1) >> shift));
+            return ok ? mad24(rowpix, (unsigned)(W >> shift), (unsigned)((xe - 1) >> shift)) : kBadPix;
         };
         int xc = c_begin - LOOK, yc = c_begin;
         int xrow, xxe, yrow, yxe;

@@ -150,9 +150,13 @@ template <> __device__ __forceinline__ void unpack_pair<f16_t>(unsigned r, float
 template <typename T> __device__ __forceinline__ unsigned pack_pair(float lo, float hi);
 template <> __device__ __forceinline__ unsigned pack_pair<bf16_t>(float lo, float hi) { const bf16x2 t = {(bf16_t)lo, (bf16_t)hi}; return __builtin_bit_cast(unsigned, t); }
 template <> __device__ __forceinline__ unsigned pack_pair<f16_t>(float lo, float hi) { const f16x2 t = {(f16_t)lo, (f16_t)hi}; return __builtin_bit_cast(unsigned, t); }
-// convolution outputs are unbounded: an fp16 store saturates at the largest finite value instead of producing inf (one v_med3_f32)
+// Convolution outputs are unbounded: an fp16 store has to saturate at the largest finite value instead of producing inf.  The hardware
+// does it for nothing: with MODE.FP16_OVFL set (bit 23 of the MODE register) every instruction that produces an fp16 result clamps an
+// overflow to +-65504 (true infinities pass).  Kernels that store fp16 activations call fp16_saturating_stores<T>() once at their top;
+// sat16 stays as the (now empty) marker of the places that rely on it.
+template <typename T> __device__ __forceinline__ void fp16_saturating_stores() {}
+template <> __device__ __forceinline__ void fp16_saturating_stores<f16_t>() { __builtin_amdgcn_s_setreg((23 << 6) | 1, 1); }      // hwreg(HW_REG_MODE, 23, 1)
 template <typename T> __device__ __forceinline__ float sat16(float v) { return v; }
-template <> __device__ __forceinline__ float sat16<f16_t>(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE `1.0f / d` costs ~12 VALU issue slots more per element (div_scale / fma chain /
 // div_fmas / div_fixup plus hazard nops), which made the GroupNorm kernels VALU-bound instead of HBM-bound

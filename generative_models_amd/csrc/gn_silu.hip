@@ -691,6 +691,7 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ x
 // converts the fp16 forward stream at its boundary
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void cast16_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t nvec) {
+    fp16_saturating_stores<TD>();
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
         float v[8];
         load8(src + i * 8, v);

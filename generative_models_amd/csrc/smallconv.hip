@@ -54,6 +54,7 @@ template <typename T, int CSN, int VW, bool FLIP>
 __global__ __launch_bounds__(256) void expand3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                        const float* __restrict__ bias, T* __restrict__ out, int H, int W, int C,
                                                        float inv_w, unsigned npix, int ppb) {
+    fp16_saturating_stores<T>();
     const int tid = threadIdx.x;
     const int nvec = C / VW, planes = 256 / nvec;
     const int vec = tid % nvec, pl = tid / nvec;
@@ -114,6 +115,7 @@ template <typename T, int CSN, bool FLIP>
 __global__ __launch_bounds__(256) void expand3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                             const float* __restrict__ bias, T* __restrict__ out, int H, int W, int C,
                                                             unsigned npix, unsigned nblocks, unsigned in_bytes, unsigned out_bytes) {
+    fp16_saturating_stores<T>();
     constexpr int K = 9 * CSN, NK = (K + (FLIP ? 0 : 1) + 1) / 2;     // the stem's bias rides as one more k entry: weight bias[c], patch 1
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
