@@ -124,9 +124,15 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const float* __restri
                                                           const float* __restrict__ noise, float lt, float ls, int is_last,
                                                           float* __restrict__ z_next, float* __restrict__ x_pred,
                                                           float* __restrict__ eps_pred, int64_t n,
-                                                          const float* __restrict__ lt_vec, const float* __restrict__ ls_vec, int mt) {
+                                                          const float* __restrict__ lt_vec, const float* __restrict__ ls_vec, int mt,
+                                                          float* __restrict__ z_dup = nullptr, float* __restrict__ logsnr_next = nullptr) {
     const int b = blockIdx.y;
     if (lt_vec) { lt = lt_vec[b]; ls = ls_vec[b]; }      // per-sample times (teacher steps of the distillation loss)
+    // the next iteration's network time: u_t(i - 1) = u_s(i) (gaussian_diffusion.py:288-290), so logsnr_s IS the next logsnr_t
+    if (logsnr_next && blockIdx.x == 0 && threadIdx.x == 0) {
+        logsnr_next[b] = ls;
+        if (z_dup) logsnr_next[gridDim.y + b] = ls;
+    }
     const LogsnrCoef c = logsnr_coef(lt);
     const float alpha_s = sqrtf(1.0f / (1.0f + expf(-ls)));
     const float sigma_s = sqrtf(1.0f / (1.0f + expf(ls)));
@@ -152,6 +158,7 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const float* __restri
         if (noise) zs = (r * alpha_st * zz + omr * alpha_s * xh) + stdv * noise[base + i];   // :242
         else zs = alpha_s * xh + sigma_s * eh;                                                 // :212
         z_next[base + i] = is_last ? xh : zs;                                                  // :292
+        if (z_dup) z_dup[base + i] = is_last ? xh : zs;      // second half of the guided sampler's 2B-image batch (cond + uncond share z)
         if (x_pred) x_pred[base + i] = xh;
         if (eps_pred) eps_pred[base + i] = eh;
     }
@@ -255,7 +262,8 @@ extern "C" int gmk_v_loss(const float* v, const float* z, const float* x, const 
 
 extern "C" int gmk_sampler_step(const float* v, const float* v_uncond, const float* cond_w, const float* z,
                                 const float* noise, float logsnr_t, float logsnr_s, int is_last, float* z_next,
-                                float* x_pred, float* eps_pred, int mean_type, int B, int64_t n, void* stream) {
+                                float* x_pred, float* eps_pred, float* z_dup, float* logsnr_next, int mean_type, int B, int64_t n,
+                                void* stream) {
     GMK_REQUIRE(v && z && z_next, "gmk_sampler_step: null pointer");
     GMK_REQUIRE(mean_type >= 0 && mean_type <= 2, "gmk_sampler_step: mean_type must be 0 (v), 1 (eps) or 2 (x)");
     GMK_REQUIRE((v_uncond == nullptr) == (cond_w == nullptr), "gmk_sampler_step: v_uncond and cond_w go together");
@@ -263,7 +271,8 @@ extern "C" int gmk_sampler_step(const float* v, const float* v_uncond, const flo
     int gx = (int)((n + 255) / 256);
     if (gx > 64) gx = 64;
     sampler_step_kernel<<<dim3(gx, B), 256, 0, gmk_stream(stream)>>>(v, v_uncond, cond_w, z, noise, logsnr_t, logsnr_s,
-                                                                     is_last, z_next, x_pred, eps_pred, n, nullptr, nullptr, mean_type);
+                                                                     is_last, z_next, x_pred, eps_pred, n, nullptr, nullptr, mean_type,
+                                                                     z_dup, logsnr_next);
     return gmk_check_launch("gmk_sampler_step");
 }
 

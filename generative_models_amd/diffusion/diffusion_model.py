@@ -97,7 +97,7 @@ def make_plugin(GMBase, AttrDict):
                 self._sync = parallel.GradSync(self.net)
             world = parallel.world()
             out = self.diffusion.train_forward_backward(net=partial(self.net, guide=y), x=x, grad_scale=1.0 / B,
-                                                        on_grads_ready=self._sync.hook)
+                                                        on_grads_ready=self._sync.hook, join_side_before_ready=False)
             self._sync.finish()
             self.optimizer.step(grad_scale=1.0 / world)
             metrics = {"loss": ops.mean(out["loss"])}

@@ -190,14 +190,14 @@ class GaussianDiffusion:
         return {"loss": loss}
 
     def train_forward_backward(self, *, net, x, grad_scale, u=None, eps=None, i_times=None, cond_w=None,
-                               on_grads_ready=None):
+                               on_grads_ready=None, join_side_before_ready=True):
         """Fused training pass used by DiffusionModel.train_step: forward, loss, dL/dv and the explicit backward
         schedule, leaving d(grad_scale * sum_b loss_b)/d(theta) in `module.flat_grads`.  No autograd graph."""
         module, guide, w, z_t, logsnr, x_t, eps_t, loss_type = self._prepare(net, x, u, eps, i_times, cond_w)
         ctx = {}
         v = module.forward_hip(z_t, logsnr, guide, w, ctx=ctx)
         loss_b, x_mse, eps_mse, dv = ops.v_loss(v, z_t, x_t, eps_t, logsnr, grad_scale=grad_scale, loss_type=loss_type, mean_type=self.mean_type)
-        module.backward_hip(ctx, dv, on_grads_ready=on_grads_ready)
+        module.backward_hip(ctx, dv, on_grads_ready=on_grads_ready, join_side_before_ready=join_side_before_ready)
         return {"loss": loss_b, "x_mse": x_mse, "eps_mse": eps_mse, "logsnr": logsnr}
 
     # ---- sampling ----------------------------------------------------------------------------------------
@@ -226,23 +226,33 @@ class GaussianDiffusion:
             raise ValueError("classifier-free guidance needs class labels (net must carry guide=)")
         z_t = ops.aligned(init_x.float())
         zs, xs, es = [], [], []
-        if w is not None:       # conditional + unconditional evaluations share one 2B-image forward (:176-177)
+        guided = w is not None
+        nb = 2 * B if guided else B
+        if guided:       # conditional + unconditional evaluations share one 2B-image forward (:176-177)
             guide2 = torch.cat([guide, -torch.ones_like(guide)])
-        for i in range(self.num_steps)[::-1]:
+            sw2 = None if student_w is None else torch.cat([student_w, student_w])
+            z2 = torch.cat([z_t, z_t])      # once: afterwards the update kernel writes both halves of the next 2B batch itself
+        # the network's time vector: filled once here, then by the update kernel (the next logsnr_t is this step's logsnr_s);
+        # two buffers alternate so that a forward still queued on the GPU never sees its input overwritten
+        first = logsnr_schedule_cosine_host(sampler_times(self.num_steps - 1, self.num_steps)[0])
+        lvecs = [torch.full((nb,), float(first), device=dev), torch.empty((nb,), device=dev)]
+        for it, i in enumerate(range(self.num_steps)[::-1]):
             u_t, u_s = sampler_times(i, self.num_steps)
             lt, ls = logsnr_schedule_cosine_host(u_t), logsnr_schedule_cosine_host(u_s)
-            if w is None:
-                lvec = torch.full((B,), float(lt), device=dev)
+            lvec, lnext = lvecs[it & 1], lvecs[(it + 1) & 1]
+            if not guided:
                 v = module.forward_hip(z_t, lvec, guide, student_w)
                 vu = None
             else:
-                lvec = torch.full((2 * B,), float(lt), device=dev)
-                v2 = module.forward_hip(torch.cat([z_t, z_t]), lvec, guide2, None if student_w is None else torch.cat([student_w, student_w]))
+                v2 = module.forward_hip(z2, lvec, guide2, sw2)
                 v, vu = v2[:B], v2[B:]
             noise = None
             if self.sampler == "noisy":
                 noise = ops.aligned(noises[i]) if noises is not None else self.rng.normal(z_t.shape, dev)   # :241
-            z_t, xp, ep = ops.sampler_step(v, z_t, lt, ls, i == 0, v_uncond=vu, cond_w=w, noise=noise, want_pred=record, mean_type=self.mean_type)
+            z_t, xp, ep = ops.sampler_step(v, z_t, lt, ls, i == 0, v_uncond=vu, cond_w=w, noise=noise, want_pred=record, mean_type=self.mean_type,
+                                           dup=guided, logsnr_next=lnext)
+            if guided:
+                z_t, z2 = z_t
             if record:
                 zs.append(z_t); xs.append(xp); es.append(ep)
             ops.throttle()                              # at most two sampler iterations queued on the GPU (see ops.throttle)

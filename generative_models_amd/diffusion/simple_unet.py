@@ -564,12 +564,15 @@ class SimpleUnet(nn.Module):
         assert all(srt[i][1] == srt[i + 1][0] for i in range(3)), "gradient buckets must tile the arena"
         return buckets
 
-    def backward_hip(self, ctx, dout, on_grads_ready=None):
+    def backward_hip(self, ctx, dout, on_grads_ready=None, join_side_before_ready=True):
         """dout: NCHW fp32 gradient of the network output.  Fills `flat_grads` (overwrites every touched slice).
-        on_grads_ready(k): called as soon as bucket k of grad_buckets() is final (overlapped gradient all-reduce)."""
+        on_grads_ready(k): called as soon as every kernel that writes bucket k of grad_buckets() has been ENQUEUED (overlapped gradient
+        all-reduce).  A bucket is final only when the side stream's weight gradients are: with join_side_before_ready the current stream
+        joins the side stream in front of every callback (a callback may then read the bucket in current-stream order); a consumer
+        that orders its own stream behind BOTH streams (parallel.GradSync: the all-reduce runs on a third stream) passes False, and
+        the data-gradient chain on the current stream never waits for the weight gradients."""
         ready = on_grads_ready if on_grads_ready is not None else (lambda k: None)
-        # a bucket is final only when the side stream's weight gradients are: join before handing it to the all-reduce
-        join = self._join_side if on_grads_ready is not None else (lambda: None)
+        join = self._join_side if (on_grads_ready is not None and join_side_before_ready) else (lambda: None)
         P, G, C, T = self._pv, self._gv, self.channels, self.compute_dtype
         B, H, W = ctx["dims"]
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
@@ -628,11 +631,12 @@ class SimpleUnet(nn.Module):
         ((dt0, s0t),) = self._res_bwd("down.seq.1", ctx, dt1, s1t, demb_all, 0, extra_add=[dt0a])
         ops.colsum(s0t, G["down.seq.0.conv.bias"], defer=True)
         self._on_side(lambda: ops.stem_wgrad(x, dt0, G["down.seq.0.conv.weight"]), (x, dt0))
-        ops.flush_colsums(); self._join_side()
+        ops.flush_colsums(); join()
         ready(2)
         self._embed_bwd(ctx, demb_all)
         ops.flush_colsums()
         ready(3)
+        self._join_side()          # the caller (optimiser step, next forward) continues on the current stream
 
     def zero_grad_arena(self):
         self.flat_grads.zero_()

@@ -576,7 +576,10 @@ def v_loss(v, z, x, eps, logsnr, grad_scale=None, loss_type=0, mean_type="v"):
     return loss_b, xm, em, dv
 
 
-def sampler_step(v, z, logsnr_t, logsnr_s, is_last, v_uncond=None, cond_w=None, noise=None, want_pred=False, mean_type="v"):
+def sampler_step(v, z, logsnr_t, logsnr_s, is_last, v_uncond=None, cond_w=None, noise=None, want_pred=False, mean_type="v",
+                 dup=False, logsnr_next=None):
+    """dup: z_next is returned as the first half of a [2B, ...] tensor whose second half holds the same values (z2 = returned[1]);
+    logsnr_next: fp32 [B] (or [2B] with dup) filled with logsnr_s."""
     _f32(v, "v"); _f32(z, "z")
     B = z.shape[0]
     n = z.numel() // B
@@ -586,12 +589,16 @@ def sampler_step(v, z, logsnr_t, logsnr_s, is_last, v_uncond=None, cond_w=None, 
             _f32(t, "aux"); assert t.shape == z.shape
     if cond_w is not None:
         _f32(cond_w, "cond_w"); assert cond_w.numel() == B
-    z_next = torch.empty_like(z)
+    z2 = torch.empty((2 * B,) + tuple(z.shape[1:]), device=z.device, dtype=z.dtype) if dup else None
+    z_next = z2[:B] if dup else torch.empty_like(z)
     xp = torch.empty_like(z) if want_pred else None
     ep = torch.empty_like(z) if want_pred else None
+    if logsnr_next is not None:
+        _f32(logsnr_next, "logsnr_next"); assert logsnr_next.numel() == (2 * B if dup else B)
     check(lib.gmk_sampler_step(_p(v), _p(v_uncond), _p(cond_w), _p(z), _p(noise), float(logsnr_t), float(logsnr_s),
-                               int(is_last), _p(z_next), _p(xp), _p(ep), MEAN_TYPES[mean_type], B, n, _s()), "sampler_step")
-    return z_next, xp, ep
+                               int(is_last), _p(z_next), _p(xp), _p(ep), _p(z2[B:]) if dup else None, _p(logsnr_next),
+                               MEAN_TYPES[mean_type], B, n, _s()), "sampler_step")
+    return ((z_next, z2) if dup else z_next), xp, ep
 
 
 def logsnr_schedule(B, device, u=None, i_times=None, num_steps=1, shift=0.0, want_u=False):

@@ -4,8 +4,10 @@ The reference has no distributed code at all; data parallel
 hot path needs: per-sample work is independent (GroupNorm normalises within a sample), so ranks
 take equal shards of the global batch and sum-all-reduce the flat fp32 gradient once per step.  The arena is cut
 into contiguous buckets in backward-readiness order (`SimpleUnet.grad_buckets`: 4 natural ones; `GMK_GRAD_BUCKETS` = 1, 2 or 4
-merges neighbours); each bucket's all-reduce is issued the moment its last gradient kernel has been enqueued, so it runs on
-RCCL's stream underneath the rest of the backward pass.  xGMI is point-to-point and a 24 MB all-reduce is latency-bound, hence
+merges neighbours); each bucket's all-reduce is issued the moment its last gradient kernel has been enqueued, from a third
+("exchange") stream that waits for the data-gradient stream AND the weight-gradient side stream - so RCCL sees the bucket final,
+while the data-gradient chain itself never waits for the weight gradients (round 2 joined the two streams on the main stream
+in front of every bucket: four stalls of the dgrad chain per backward pass) - and runs underneath the rest of the backward pass.  xGMI is point-to-point and a 24 MB all-reduce is latency-bound, hence
 few, large buckets.  The 1/world scaling is folded into the fused Adam kernel (`grad_scale`).
 
 CU carve-out: the convolution kernels are persistent grids of one 160 KiB-LDS workgroup per CU — they leave RCCL's reduction
@@ -78,19 +80,47 @@ class GradSync:
         self.works = []
         self.issued = []                      # (natural index, start, end) of every all-reduce issued this step (tests, bench)
         self.cu_limit = reserve_cus_for_rccl() if net.flat_params.is_cuda else None
+        self._comm = None                     # the exchange stream (GPU only)
+        self._exposed = []                    # (event before, event after) around finish()'s waits: what the step still waits for
 
     def hook(self, k):
         if world() == 1 or k not in self._fire:
             return
         s, e = self._fire[k]
         self.issued.append((k, s, e))
-        self.works.append(dist.all_reduce(self.net.flat_grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        grads = self.net.flat_grads[s:e]
+        if not grads.is_cuda:
+            self.works.append(dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=grads.device)
+        comm = self._comm
+        comm.wait_stream(torch.cuda.current_stream())         # colsums, GroupNorm parameter gradients, embedding GEMMs
+        if getattr(self.net, "_side", None) is not None:
+            comm.wait_stream(self.net._side)                  # the bucket's weight gradients
+        with torch.cuda.stream(comm):                         # the backend orders its own stream behind the stream current HERE
+            self.works.append(dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
+        """The current stream waits for every outstanding bucket; the wait is bracketed by events (`exposed_ms` in describe())."""
+        timed = bool(self.works) and self.net.flat_grads.is_cuda
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
         for w in self.works:
             w.wait()
+        if self._comm is not None:
+            torch.cuda.current_stream().wait_stream(self._comm)
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
+            self._exposed.append((e0, e1))
+            del self._exposed[:-64]
         self.works.clear()
         self.issued.clear()
+
+    def exposed_ms(self):
+        """Mean time the main stream spent waiting in finish() over the last (up to 64) steps; call after a device synchronize."""
+        done = [(a, b) for a, b in self._exposed if b.query()]
+        return round(sum(a.elapsed_time(b) for a, b in done) / len(done), 4) if done else None
 
     def broadcast_params(self, src=0):
         if world() > 1:
@@ -100,7 +130,9 @@ class GradSync:
     def describe(self):
         """What the exchange looks like from this rank (bench.py puts it beside the scaling numbers)."""
         info = {"world": world(), "backend": dist.get_backend() if world() > 1 else None,
-                "bucket_bytes": [4 * (e - s) for s, e, _ in self.buckets], "persistent_kernel_cus": self.cu_limit}
+                "bucket_bytes": [4 * (e - s) for s, e, _ in self.buckets], "persistent_kernel_cus": self.cu_limit,
+                "exposed_ms": self.exposed_ms(),
+                "issue": "each bucket from a third stream behind the data-gradient and weight-gradient streams (no join on the main stream)"}
         if torch.cuda.is_available():
             try:
                 info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())

@@ -215,10 +215,13 @@ int gmk_v_loss(const float* v, const float* z, const float* x, const float* eps,
 /* one reverse step on a batch (gaussian_diffusion.py:189-243,174-187,292):
  *   v: conditional net output; v_uncond/cond_w: NULL or the unconditional output + per-sample guidance weight;
  *   noise: NULL -> DDIM update, else ancestral ('noisy') update with that noise; is_last: the i == 0 select.
- *   z_next is written; x_pred / eps_pred are optional outputs. */
+ *   z_next is written; x_pred / eps_pred are optional outputs.
+ *   z_dup (optional): a second copy of z_next - the other half of the 2B-image batch the guided sampler feeds the network (:176-177
+ *   evaluates the net twice on the same z); logsnr_next (optional, B floats, 2B with z_dup): filled with logsnr_s, which is the next
+ *   iteration's logsnr_t (u_t(i-1) = u_s(i), :288-290) - the loop then needs neither torch.cat nor torch.full per step. */
 int gmk_sampler_step(const float* v, const float* v_uncond, const float* cond_w, const float* z, const float* noise,
                      float logsnr_t, float logsnr_s, int is_last, float* z_next, float* x_pred, float* eps_pred,
-                     int mean_type, int B, int64_t n, void* stream);
+                     float* z_dup, float* logsnr_next, int mean_type, int B, int64_t n, void* stream);
 
 /* ---- self-attention core (north_star "optional self-attention block", BASELINE config 5) -------------
  * The reference SimpleUnet has no attention block: these have NO reference call site (parity unpinned; their definition is the

@@ -254,6 +254,20 @@ def _cli(args, timeout=900):
     return r.stdout
 
 
+def test_cli_at_config_1_flags(tmp_path):
+    """BASELINE.json configs[0] as the reference runs it: `python -m gms.main --model=diffusion` at MNIST 28x28x1, bs=32, T=200 (the
+    reference's CPU plumbing case; here the same command line on the HIP path): one epoch = eval-first test pass, evaluate() with its
+    25-image T=200 sampling, checkpoint, a few train steps - every flag at config 1's literal value."""
+    import yaml
+    out = _cli(["--model=diffusion", "--bs", "32", "--timesteps", "200", "--epochs=1", "--train_batches", "4", "--test_batches", "2",
+                "--logdir", str(tmp_path / "cfg1")])
+    assert "diffusion/test/loss" in out and "diffusion/train/loss" in out and "SAVED MODEL" in out
+    with open(tmp_path / "cfg1" / "hps.yaml") as f:
+        hps = yaml.load(f, Loader=yaml.Loader)
+    assert hps["bs"] == 32 and hps["timesteps"] == 200 and hps["hidden_size"] == 128 and hps["act_dtype"] in ("fp16", "bf16")
+    assert len(torch.load(tmp_path / "cfg1" / "model.pt", map_location="cpu")) == 160
+
+
 def test_checkpoint_hps_and_teacher_round_trip(tmp_path):
     """gms/main.py:55-64,79-82 and diffusion_model.py:34-45 through the CLI: train one epoch -> model.pt + hps.yaml;
     `--weights_from` re-reads the flags from hps.yaml and continues from the saved weights (test loss of epoch 0 equals the

@@ -53,8 +53,10 @@ net = make(); sync = parallel.GradSync(net); sync.broadcast_params(0)
 d = GaussianDiffusion(mean_type="v", num_steps=4); opt = FusedAdam(net)
 sl = slice(r * B // w, (r + 1) * B // w)
 d.train_forward_backward(net=partial(net, guide=y[sl]), x=x[sl], grad_scale=1.0 / (B // w), u=u[sl], eps=eps[sl],
-                         on_grads_ready=sync.hook)
+                         on_grads_ready=sync.hook, join_side_before_ready=False)      # as DiffusionModel.train_step calls it
 sync.finish()
+torch.cuda.synchronize()
+assert sync.exposed_ms() is not None and sync._comm is not None
 # mean over ranks of the per-shard mean gradients == gradient of the whole-batch mean (equal shards)
 gdiff = float((net.flat_grads / w - gref).abs().max()) / float(gref.abs().max())
 assert gdiff < 1e-4, gdiff
@@ -96,4 +98,5 @@ def test_bench_two_ranks_rehearsal():
     assert d["value"] > 0 and "cpu_baseline" not in d and d["roofline"]["kernel"].startswith("conv")
     ex = d["exchange"]
     assert ex["world"] == 2 and ex["backend"] == "gloo" and len(ex["bucket_bytes"]) == 4 and ex["persistent_kernel_cus"] == 248
+    assert ex["exposed_ms"] is not None and ex["exposed_ms"] >= 0.0
     assert d["steady_state"]["steps"] == 50 and d["sampler"]["timed_steps"] == 2
