@@ -463,7 +463,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         // phase — weights FIRST: vmcnt retires in issue order, and the step only needs the weight tile issued two steps ago, so
         // with the halo pieces queued behind the weights of their step they may stay in flight one step longer (HBM latency)
         // without holding up the barrier.
-        const int pw = wave - 4;
+        // Every VALU instruction a producer issues is taken from the consumer wave on its SIMD (measured, round 3: 32 extra producer VALU per
+        // K-step cost the kernel 7 - 10 %), so the steady-state loop is kept scalar: the wave index is made an SGPR (LDS destinations / M0 become
+        // SALU), per-K-step parts of the DMA addresses (tap, phase) ride in the instructions' scalar offset, per-lane parts are precomputed.
+        const int pw = __builtin_amdgcn_readfirstlane(wave) - 4;
         const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, (int)p.nb0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs1 =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.c1 ? p.src1 : p.src0), 0, (int)(p.c1 ? p.nb1 : p.nb0), 0x00020000);
@@ -496,6 +499,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         // source pixel (24 bits) and swizzled chunk offset (bits 24..31, = f_ch >> 4) of this lane's slot in piece j of the
         // tile being filled; resolved one piece at a time, right before the piece is first needed
         unsigned hpix[7][2];
+        unsigned hvoff[7][2];           // plain path: the slot's byte offset in its source (pixel x row bytes + swizzled chunk): the DMA's whole vector offset
+        const unsigned row_b = (unsigned)p.c0 * ES;      // bytes per source pixel (both sources have c0 channels: host-checked)
         auto resolve_piece = [&](int tile, int j) {
             const bool exists = tile < p.ntiles;
             const int gr0 = tile * p.R;
@@ -515,34 +520,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 const int b = b0 + k;
                 const bool ok = exists && y >= 0 && y < H && x >= 0 && x < W && b < p.B;
                 const unsigned pix = ok && !((y | x) & p.pmask) ? (unsigned)((b * (H >> p.shift) + (y >> p.shift)) * (W >> p.shift) + (x >> p.shift)) : kBadPix;
-                hpix[j][u] = pix | ((unsigned)(lch ^ ((n >> 1) & 7)) << 24) | ((unsigned)(k & 1) << 28);      // bit 28: sample b0 + k (fused GroupNorm)
+                if constexpr (kFuse) hpix[j][u] = pix | ((unsigned)(lch ^ ((n >> 1) & 7)) << 24) | ((unsigned)(k & 1) << 28);      // bit 28: sample b0 + k (fused GroupNorm)
+                else hvoff[j][u] = __umul24(pix, row_b) + ((unsigned)(lch ^ ((n >> 1) & 7)) << 4);
             }
         };
-        auto issue_fill = [&](int hbuf, int ph, int j) {
+        auto issue_fill = [&](int hbuf, int ph, int j) {          // (plain path; the fused path loads through registers)
             const int kelem = ph << 6;
             const bool second = kelem >= p.c0;
-            const unsigned cs_b = (unsigned)(second ? p.c1 : p.c0) * ES;
-            const unsigned koff_b = (unsigned)(second ? kelem - p.c0 : kelem) * ES;
+            const unsigned koff_b = (unsigned)(second ? kelem - p.c0 : kelem) * ES;      // scalar: rides in the instruction's soffset
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 GMK_LDS char* dst = (GMK_LDS char*)(smem + hbuf * kHB + j * 8192 + (pw * 2 + u) * 1024);
-                const unsigned voff = __umul24(hpix[j][u], cs_b) + koff_b + (((hpix[j][u] >> 24) & 7u) << 4);
-                if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (GMK_LDS void*)dst, 16, voff, 0, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (GMK_LDS void*)dst, 16, voff, 0, 0, 0);
+                if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (GMK_LDS void*)dst, 16, hvoff[j][u], koff_b, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (GMK_LDS void*)dst, 16, hvoff[j][u], koff_b, 0, 0);
             }
         };
         auto issue_w = [&](int stage, int tap, int ph, int c) {      // c < 0: all 128 rows (4 instructions), else rows of channel half c (2)
-            const unsigned wk = (unsigned)tap * p.w_tap_stride_b + ((unsigned)ph << 7);
+            const unsigned wk = (unsigned)tap * p.w_tap_stride_b + ((unsigned)ph << 7);      // scalar: soffset
             if (c < 0) {
                 GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + pw * 4096);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(dst + u * 1024), 16, w_off[u] + wk, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(dst + u * 1024), 16, w_off[u], wk, 0, 0);
             } else {
                 GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + (c * 64 + 16 * pw) * 128);
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(dst + u * 1024), 16, (c ? wh_off1[u] : wh_off0[u]) + wk, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(dst + u * 1024), 16, c ? wh_off1[u] : wh_off0[u], wk, 0, 0);
             }
         };
 
@@ -1265,6 +1269,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 int gmk_halo_geometry(int B, int H, int W, int c0, int c1, int w_rows, int cout, int out_cstride, int min_tiles, int upsample,
                       int fused_gn, HaloGeometry* g) {
     if (c0 % 64 || c1 % 64 || cout % 128) return 0;
+    if (c1 != 0 && c1 != c0) return 0;                        // the producers precompute byte offsets with one row size for both sources
     if (W < 4 || W > 254 || H < 2) return 0;
     const int R = 256 / W;
     if (R < 1) return 0;

@@ -246,7 +246,11 @@ template <int LOOK> struct SlotWsLds {
 // DMA they replace and counted by the same `s_waitcnt vmcnt`; when they have landed each dword is re-rounded fp16 -> bf16 (3 VALU) and
 // written with ds_write_b128 to the place the DMA would have filled (and to the mirror copy - one load serves both).  The consumers,
 // the dY path and the LDS layout are unchanged: the MFMA sees bf16 x bf16 as before.
-template <int LOOK, bool kXF16 = false>
+// kShare (every launch without the nearest-x2 source): slot S of dY and slot S of X are the same pixel, and the X stream runs LOOK chunks
+// ahead of the dY stream - so the producers decode each chunk's slots ONCE (for X) and the dY issue LOOK steps later reuses the pixel
+// indices from a (LOOK + 1)-deep register FIFO.  Halves the producers' address arithmetic, which sits on the kernel's critical path
+// (producers = DMA issue + ~90 VALU per step against the consumers' 36 MFMAs: adding 30 VALU cost 5 - 8 %, round 3).
+template <int LOOK, bool kXF16 = false, bool kShare = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotParams p) {
     __shared__ __attribute__((aligned(16))) char smem[SlotWsLds<LOOK>::kBytes];
     constexpr unsigned kBadPix = 0x00FFFFFFu;
@@ -295,14 +299,26 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
         decode(64 * yc + 16 * pw + (lane >> 3), yrow, yxe);
         (void)inv_we;
 
-        auto issue_x = [&]() -> int {      // -> number of DMA instructions (2, or 4 with the mirror copy)
-            unsigned pix0 = kBadPix, pix1 = kBadPix;
+        unsigned hist[LOOK + 1][2];          // kShare: pixel indices of this lane's two slots of X chunks xc - 1 - LOOK .. xc - 1 (oldest first)
+#pragma unroll
+        for (int i = 0; i <= LOOK; ++i) { hist[i][0] = kBadPix; hist[i][1] = kBadPix; }
+        auto x_pixels = [&](unsigned& pix0, unsigned& pix1) {      // decode the next X chunk's two slots of this lane (and remember them)
+            pix0 = kBadPix; pix1 = kBadPix;
             if (xc >= 0) {
                 int r1 = xrow, x1 = xxe;
                 advance(r1, x1, d8r, d8x);
-                pix0 = pixel(xrow, xxe, p.xshift); pix1 = pixel(r1, x1, p.xshift);
+                pix0 = pixel(xrow, xxe, kShare ? 0 : p.xshift); pix1 = pixel(r1, x1, kShare ? 0 : p.xshift);
                 advance(xrow, xxe, d64r, d64x);
             }
+            if constexpr (kShare) {
+#pragma unroll
+                for (int i = 0; i < LOOK; ++i) { hist[i][0] = hist[i + 1][0]; hist[i][1] = hist[i + 1][1]; }
+                hist[LOOK][0] = pix0; hist[LOOK][1] = pix1;
+            }
+        };
+        auto issue_x = [&]() -> int {      // -> number of DMA instructions (2, or 4 with the mirror copy)
+            unsigned pix0, pix1;
+            x_pixels(pix0, pix1);
             const unsigned v0 = __umul24(pix0, xs_b) + xoff_b + lc, v1 = __umul24(pix1, xs_b) + xoff_b + lc;
             const int rp = xc & 7;
             GMK_LDS char* dst = (GMK_LDS char*)(smem + kWsXBase + rp * 8192 + pw * 2048);
@@ -318,10 +334,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
             return 2;
         };
         auto issue_y = [&]() {
-            int r1 = yrow, x1 = yxe;
-            advance(r1, x1, d8r, d8x);
-            const unsigned p0 = pixel(yrow, yxe, 0), p1 = pixel(r1, x1, 0);
-            advance(yrow, yxe, d64r, d64x);
+            unsigned p0, p1;
+            if constexpr (kShare) {        // dY chunk yc = the X chunk decoded LOOK issues ago (every issue_y follows an X issue: hist[0])
+                p0 = hist[0][0]; p1 = hist[0][1];
+            } else {
+                int r1 = yrow, x1 = yxe;
+                advance(r1, x1, d8r, d8x);
+                p0 = pixel(yrow, yxe, 0); p1 = pixel(r1, x1, 0);
+                advance(yrow, yxe, d64r, d64x);
+            }
             GMK_LDS char* dst = (GMK_LDS char*)(smem + kWsDyBase + (yc & 7) * 8192 + pw * 2048);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (GMK_LDS void*)dst, 16, __umul24(p0, ys_b) + yoff_b + lc, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (GMK_LDS void*)(dst + 1024), 16, __umul24(p1, ys_b) + yoff_b + lc, 0, 0, 0);
@@ -329,7 +350,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
         };
         if constexpr (kXF16) {
             typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-            constexpr int NSET = AHEAD - 1;                  // register sets: AHEAD - 2 blocks in flight + the one being written
+            constexpr int FA = 5;                            // blocks issued ahead (the X ring only holds WRITTEN chunks here, the dY ring has 8 slots)
+            constexpr int NSET = FA - 1;                     // register sets: blocks s + 2 .. s + FA are live during step s
             // the X descriptor as four scalars for the inline-asm loads (same words as make_buffer_rsrc: base, size, raw 32-bit format): a
             // border slot's out-of-range offset reads zeros, as in the DMA form - no validity masks, 32-bit address arithmetic only
             typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -338,13 +360,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
             u32x4 xr[NSET][2];
             int xrp[NSET];                                   // ring position the set goes to (wave-uniform)
             auto load_x = [&](u32x4 (&r)[2], int& rp) {      // 2 buffer loads to registers (inline asm: they stay in flight across barriers)
-                unsigned pix0 = kBadPix, pix1 = kBadPix;
-                if (xc >= 0) {
-                    int r1 = xrow, x1 = xxe;
-                    advance(r1, x1, d8r, d8x);
-                    pix0 = pixel(xrow, xxe, p.xshift); pix1 = pixel(r1, x1, p.xshift);
-                    advance(xrow, xxe, d64r, d64x);
-                }
+                unsigned pix0, pix1;
+                x_pixels(pix0, pix1);
                 const unsigned v0 = __umul24(pix0, xs_b) + xoff_b + lc, v1 = __umul24(pix1, xs_b) + xoff_b + lc;
                 asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[0]) : "v"(v0), "s"(xdesc) : "memory");
                 asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[1]) : "v"(v1), "s"(xdesc) : "memory");
@@ -368,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
                 }
             };
             // prologue: X chunks c-LOOK .. c+LOOK+1 through a temporary register set each, dY chunks c and c+1, all awaited and written:
-            // barrier 0 then sees what the DMA form guarantees (every chunk up to c + 1); blocks 2 .. AHEAD-1 follow and stay in flight
+            // barrier 0 then sees what the DMA form guarantees (every chunk up to c + 1); blocks 2 .. FA-1 follow and stay in flight
             {
                 u32x4 t[2 * LOOK + 2][2]; int tp[2 * LOOK + 2];
 #pragma unroll
@@ -380,30 +397,27 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
                 for (int k = 0; k < 2 * LOOK + 2; ++k) store_x(t[k], tp[k]);
             }
 #pragma unroll
-            for (int k = 2; k < AHEAD; ++k) { load_x(xr[k % NSET], xrp[k % NSET]); issue_y(); }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // step s: block s + 1 (set (s + 1) % NSET) has landed -> write it; barrier; block s + AHEAD goes into the set just freed
-            auto step = [&](auto set_tag, int s) {
-                constexpr int SET = decltype(set_tag)::value;
-                if (s > 0) {
-                    if (AHEAD == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    store_x(xr[SET], xrp[SET]);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
+            for (int k = 2; k < FA; ++k) { load_x(xr[k % NSET], xrp[k % NSET]); issue_y(); }
+            // Step s.  Block k (X chunk c + k + LOOK, dY chunk c + k) has to be in LDS at barrier k - 1.  Its ds_writes are issued during step
+            // k - 2 and only awaited at the top of step k - 1: a whole step for them to drain through an LDS queue the consumers keep full
+            // (waiting for them in front of the same step's barrier put that latency on the barrier: +7 ... 10 %).
+            //   lgkmcnt(0): block s + 1 is in LDS | barrier | issue block s + FA (set freed by the write of step s - 1) |
+            //   vmcnt: everything but blocks s + 3 .. s + FA has landed | convert + write block s + 2
+            auto step = [&](auto load_tag, auto store_tag) {
+                constexpr int LSET = decltype(load_tag)::value, SSET = decltype(store_tag)::value;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                load_x(xr[SET], xrp[SET]);
+                load_x(xr[LSET], xrp[LSET]);
                 issue_y();
+                static_assert(FA == 5, "the literal below is 4 x (FA - 2)");
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                store_x(xr[SSET], xrp[SSET]);
             };
-            for (int s = 0; s < nsteps;) {        // set of step s = (s + 1) % NSET, statically indexed
-                if constexpr (NSET == 3) {
-                    step(std::integral_constant<int, 1>{}, s); ++s;
-                    if (s < nsteps) { step(std::integral_constant<int, 2>{}, s); ++s; }
-                    if (s < nsteps) { step(std::integral_constant<int, 0>{}, s); ++s; }
-                } else {
-                    step(std::integral_constant<int, 1>{}, s); ++s;
-                    if (s < nsteps) { step(std::integral_constant<int, 0>{}, s); ++s; }
-                }
+            for (int s = 0; s < nsteps;) {        // load set (s + FA) % NSET = (s + 1) % 4, store set (s + 2) % 4: statically indexed
+                step(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}); ++s;
+                if (s < nsteps) { step(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}); ++s; }
+                if (s < nsteps) { step(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}); ++s; }
+                if (s < nsteps) { step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); ++s; }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             return;
@@ -560,11 +574,17 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
         if ((int64_t)ns3 * 9 * cout * ktot * 4 > slab_bytes) return 0;
         p.chunks_per_split = cps3;
         dim3 grid3(ns3, ktot / 64, cout / 64);
-        if (x_f16) {
-            if (wide) conv_wgrad_slots_ws_kernel<2, true><<<grid3, 512, 0, stream>>>(p);
-            else conv_wgrad_slots_ws_kernel<1, true><<<grid3, 512, 0, stream>>>(p);
-        } else if (wide) conv_wgrad_slots_ws_kernel<2><<<grid3, 512, 0, stream>>>(p);
-        else conv_wgrad_slots_ws_kernel<1><<<grid3, 512, 0, stream>>>(p);
+        const bool share = !upsample;          // dY slot S and X slot S are the same pixel: decode once (kShare)
+#define GMK_SLOT_WS(LK)                                                                                        \
+    do {                                                                                                       \
+        if (x_f16 && share) conv_wgrad_slots_ws_kernel<LK, true, true><<<grid3, 512, 0, stream>>>(p);         \
+        else if (x_f16) conv_wgrad_slots_ws_kernel<LK, true, false><<<grid3, 512, 0, stream>>>(p);            \
+        else if (share) conv_wgrad_slots_ws_kernel<LK, false, true><<<grid3, 512, 0, stream>>>(p);            \
+        else conv_wgrad_slots_ws_kernel<LK, false, false><<<grid3, 512, 0, stream>>>(p);                      \
+    } while (0)
+        if (wide) GMK_SLOT_WS(2);
+        else GMK_SLOT_WS(1);
+#undef GMK_SLOT_WS
         gmk_note_kernel(13);
         return ns3;
     }
