@@ -14,7 +14,7 @@ checkpoints load; every arithmetic op runs in libgmk.so (include/gmk.h).  Differ
   exposes the pair to torch.autograd so `loss.backward()` style code keeps working.
 
 Extension over the reference: `in_channels` (the reference hard-codes 1, simple_unet.py:93,41).
-Restriction: `channels` must be a multiple of 128 (the MFMA tile width); other widths raise.
+Restriction: `channels` is 128 or 256 (multiples of the 128-channel MFMA tile with >= 4 channels per GroupNorm group); other widths raise.
 """
 import math
 import os
@@ -88,9 +88,12 @@ def _attach(root, dotted, param):
 class SimpleUnet(nn.Module):
     def __init__(self, channels, dropout=0.0, in_channels=1, compute_dtype=torch.bfloat16, attention=False, act_dtype=None):
         super().__init__()
-        if channels != 128:
-            raise ValueError(f"the HIP path is built for hidden_size 128 (the reference default, every BASELINE config; the MFMA "
-                             f"tiles are 128 output channels wide); got {channels}")
+        if channels not in (128, 256):
+            raise ValueError(f"the HIP path is built for hidden_size 128 (DiffusionModel's default, every BASELINE config) and 256 (the default of "
+                             f"gms/main.py:23): the MFMA tiles are 128 output channels wide and GroupNorm(32) needs >= 4 channels per "
+                             f"group; got {channels}")
+        if attention and channels != 128:
+            raise ValueError("the self-attention extension is built for 128 channels (one head over C = 128)")
         if not 0.0 <= dropout < 1.0:
             raise ValueError(f"dropout probability has to be in [0, 1), got {dropout}")
         if not 1 <= in_channels <= 4:
@@ -179,6 +182,11 @@ class SimpleUnet(nn.Module):
             flat[o:o + k].copy_(named[n].data.reshape(-1).float())
         self._bind(flat)
         return self
+
+    def _conv(self, *args, **kw):
+        """ops.conv_igemm with this net's width as the output-channel count (the C-ABI default is one 128-channel block)."""
+        kw.setdefault("cout", self.channels)
+        return ops.conv_igemm(*args, **kw)
 
     def mark_params_changed(self):
         self._packs_stale = True
@@ -323,7 +331,7 @@ class SimpleUnet(nn.Module):
             # GroupNorm / conv1 / GroupNorm and is joined in front of conv2 (-1 % of a forward).  OFF by default: that co-residency
             # (conv_igemm_kernel's LDS staging next to the GroupNorm kernel) is where round 1's unexplained fault lived.
             wfs, _ = self._packs[f"{name}.skip_connection"]
-            run_skip = lambda: skip.__setitem__("res", ops.conv_igemm(srcs, wfs, C, 1, ops.NORMAL, (H, W),
+            run_skip = lambda: skip.__setitem__("res", self._conv(srcs, wfs, C, 1, ops.NORMAL, (H, W),
                                                                       bias=P[f"{name}.skip_connection.bias"]))
             if fwd_side:
                 self._on_side(run_skip, tuple(srcs))
@@ -342,7 +350,7 @@ class SimpleUnet(nn.Module):
             for i, s in enumerate(srcs):
                 ops.gn_stats(s, P[f"{name}.in_layers.0.weight"][i * C:(i + 1) * C], P[f"{name}.in_layers.0.bias"][i * C:(i + 1) * C], gpc,
                              tsc[:, i * C:(i + 1) * C], tsh[:, i * C:(i + 1) * C])
-            h = ops.conv_igemm(srcs, wf1, C, 3, ops.NORMAL, (H, W), gn=(tsc, tsh))
+            h = self._conv(srcs, wf1, C, 3, ops.NORMAL, (H, W), gn=(tsc, tsh))
             t2c = torch.empty((B, C), device=h.device, dtype=torch.float32)
             t2h = torch.empty_like(t2c)
             ops.gn_stats(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], 32, t2c, t2h, xadd=eadd)
@@ -353,14 +361,14 @@ class SimpleUnet(nn.Module):
                     res.record_stream(torch.cuda.current_stream())
             else:
                 res = srcs[0]
-            return ops.conv_igemm([h], wf2, C, 3, ops.NORMAL, (H, W), bias=P[f"{name}.out_layers.3.bias"], residual=res, gn=(t2c, t2h))
+            return self._conv([h], wf2, C, 3, ops.NORMAL, (H, W), bias=P[f"{name}.out_layers.3.bias"], residual=res, gn=(t2c, t2h))
         a, stats1 = [], []
         for i, s in enumerate(srcs):
             g = P[f"{name}.in_layers.0.weight"][i * C:(i + 1) * C]
             b = P[f"{name}.in_layers.0.bias"][i * C:(i + 1) * C]
             y, mean, rstd = ops.gn_silu_fwd(s, g, b, gpc)
             a.append(y); stats1.append((mean, rstd))
-        h = ops.conv_igemm(a, wf1, C, 3, ops.NORMAL, (H, W))      # bias + embedding enter through `xadd` below
+        h = self._conv(a, wf1, C, 3, ops.NORMAL, (H, W))      # bias + embedding enter through `xadd` below
         drop = None
         # reference quirk kept: `up.seq[3]`'s ResBlock is built WITHOUT the dropout argument (simple_unet.py:138), so it never drops
         if dropping:      # mask = Philox uniform >= p, regenerated by the backward kernel
@@ -375,7 +383,7 @@ class SimpleUnet(nn.Module):
                 res.record_stream(torch.cuda.current_stream())      # allocated on the side stream, consumed here
         else:
             res = srcs[0]
-        out = ops.conv_igemm([a2], wf2, C, 3, ops.NORMAL, (H, W), bias=P[f"{name}.out_layers.3.bias"], residual=res,
+        out = self._conv([a2], wf2, C, 3, ops.NORMAL, (H, W), bias=P[f"{name}.out_layers.3.bias"], residual=res,
                              gn_stats=True)
         if ctx is not None:
             ctx[name] = (srcs, a, stats1, h, a2, (mean2, rstd2))
@@ -393,7 +401,7 @@ class SimpleUnet(nn.Module):
             raise ValueError(f"the attention level has {N} tokens: the HIP path needs a multiple of 8, at most 1024 "
                              f"(input sizes 32 / 64: 64 / 256 tokens)")
         a, mean, rstd = ops.gn_silu_fwd(x, P["attn.norm.weight"], P["attn.norm.bias"], 32)
-        qkv = ops.conv_igemm([a], self._packs["attn.qkv"][0], 3 * C, 1, ops.NORMAL, (H, W), cout=3 * C, bias=P["attn.qkv.bias"])
+        qkv = self._conv([a], self._packs["attn.qkv"][0], 3 * C, 1, ops.NORMAL, (H, W), cout=3 * C, bias=P["attn.qkv.bias"])
         t = qkv.view(B, N, 3 * C)
         q, k, v = t[:, :, :C], t[:, :, C:2 * C], t[:, :, 2 * C:]
         if T == torch.bfloat16 and N in (64, 128, 256):       # fused: K / V resident in LDS, no fp32 score matrix in HBM
@@ -403,7 +411,7 @@ class SimpleUnet(nn.Module):
             S = ops.bgemm_nt(q, k, out_dtype=torch.float32)
             Pm = ops.softmax_fwd(S, C ** -0.5, T)
             o = ops.bgemm_nt(Pm, ops.transpose_last2(v)).view(B, H, W, C)
-        out = ops.conv_igemm([o], self._packs["attn.proj"][0], C, 1, ops.NORMAL, (H, W), bias=P["attn.proj.bias"], residual=x)
+        out = self._conv([o], self._packs["attn.proj"][0], C, 1, ops.NORMAL, (H, W), bias=P["attn.proj.bias"], residual=x)
         if ctx is not None:
             ctx["attn"] = (x, a, mean, rstd, qkv, Pm, o)
         return ops.cast16(out, self.act_dtype) if self.act_dtype != T else out
@@ -420,7 +428,7 @@ class SimpleUnet(nn.Module):
         # out = x + proj(o)
         ops.colsum(ops.chansum(dout), G["attn.proj.bias"], defer=True)
         self._wgrad(dout, [o], 1, ops.NORMAL, G["attn.proj.weight"])
-        do = ops.conv_igemm([dout], self._packs["attn.proj"][1], C, 1, ops.NORMAL, (H, W)).view(B, N, C)
+        do = self._conv([dout], self._packs["attn.proj"][1], C, 1, ops.NORMAL, (H, W)).view(B, N, C)
         # o = P v,  P = softmax(scale * q k^T)
         dP = ops.bgemm_nt(do, v, out_dtype=torch.float32)
         dS = ops.softmax_bwd(Pm, dP, scale)
@@ -432,7 +440,7 @@ class SimpleUnet(nn.Module):
         # (q, k, v) = conv1x1(a)
         G["attn.qkv.bias"].copy_(dqkv.float().sum((0, 1, 2)))        # 3C-channel bias gradient: tiny, off the hot path
         self._wgrad(dqkv, [a], 1, ops.NORMAL, G["attn.qkv.weight"])
-        da = ops.conv_igemm([dqkv], self._packs["attn.qkv"][1], C, 1, ops.NORMAL, (H, W))
+        da = self._conv([dqkv], self._packs["attn.qkv"][1], C, 1, ops.NORMAL, (H, W))
         s = torch.empty((B, C), device=x.device, dtype=torch.float32)
         dx, dgp, dbp = ops.gn_silu_bwd(da, x, P["attn.norm.weight"], P["attn.norm.bias"], mean, rstd, dadd1=dout, dxsum=s)
         ops.colsum(dgp, G["attn.norm.weight"], defer=True); ops.colsum(dbp, G["attn.norm.bias"], defer=True)
@@ -473,7 +481,7 @@ class SimpleUnet(nn.Module):
         ops.colsum(dout_sum, G[f"{name}.out_layers.3.bias"], defer=True)
         self._wgrad(dout, [a2], 3, ops.NORMAL, G[f"{name}.out_layers.3.weight"])
         _, wd2 = self._packs[f"{name}.out_layers.3"]
-        da2 = ops.conv_igemm([dout], wd2, C, 3, ops.NORMAL, (H, W))
+        da2 = self._conv([dout], wd2, C, 3, ops.NORMAL, (H, W))
         dh, dgp, dbp = ops.gn_silu_bwd(da2, h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], mean2,
                                        rstd2, dxsum=demb_all[:, blk * C:(blk + 1) * C], dropout=ctx.pop(name + ".dropout", None),
                                        xadd=ctx["emb_all"][:, blk * C:(blk + 1) * C])
@@ -488,9 +496,14 @@ class SimpleUnet(nn.Module):
             _, wds = self._packs[f"{name}.skip_connection"]
         outs = []
         gw, gb = G[f"{name}.in_layers.0.weight"], G[f"{name}.in_layers.0.bias"]
-        dskips = ops.conv1x1_pair(dout, wds, 2 * C) if two else (dout,)      # both halves from one read of dout
+        if two and C == 128:
+            dskips = ops.conv1x1_pair(dout, wds, 2 * C)                      # both halves from one read of dout (128-channel blocks)
+        elif two:
+            dskips = tuple(self._conv([dout], wds, 2 * C, 1, ops.NORMAL, (H, W), n0=i * C) for i in range(2))
+        else:
+            dskips = (dout,)
         for i, s in enumerate(srcs):
-            da = ops.conv_igemm([dh], wd1, len(srcs) * C, 3, ops.NORMAL, (H, W), n0=i * C)
+            da = self._conv([dh], wd1, len(srcs) * C, 3, ops.NORMAL, (H, W), n0=i * C)
             dskip = dskips[i]
             add2 = extra_add[i] if extra_add is not None else None
             ssum = torch.empty((B, C), device=dout.device, dtype=torch.float32)
@@ -517,22 +530,22 @@ class SimpleUnet(nn.Module):
         t0 = ops.stem_fwd(x, P["down.seq.0.conv.weight"], P["down.seq.0.conv.bias"], C, T)
         t1 = self._res_fwd("down.seq.1", [t0], emb_all, 0, ctx)
         t2 = self._res_fwd("down.seq.2", [t1], emb_all, 1, ctx)
-        t3 = ops.conv_igemm([t2], self._packs["down.seq.3.conv"][0], C, 3, ops.STRIDE2, (H2, W2),
+        t3 = self._conv([t2], self._packs["down.seq.3.conv"][0], C, 3, ops.STRIDE2, (H2, W2),
                             bias=P["down.seq.3.conv.bias"])
         t4 = self._res_fwd("down.seq.4", [t3], emb_all, 2, ctx)
         t5 = self._res_fwd("down.seq.5", [t4], emb_all, 3, ctx)
-        t6 = ops.conv_igemm([t5], self._packs["down.seq.6.conv"][0], C, 3, ops.STRIDE2, (H4, W4),
+        t6 = self._conv([t5], self._packs["down.seq.6.conv"][0], C, 3, ops.STRIDE2, (H4, W4),
                             bias=P["down.seq.6.conv.bias"])
         t7 = self._res_fwd("turn", [t6], emb_all, 4, ctx)
         if self.attention:
             t7 = self._attn_fwd(t7, ctx)
         u0r = self._res_fwd("up.seq.0.0", [t7, t6], emb_all, 5, ctx)
-        u0 = ops.conv_igemm([u0r], self._packs["up.seq.0.1.conv"][0], C, 3, ops.UPSAMPLE2, (H2, W2),
+        u0 = self._conv([u0r], self._packs["up.seq.0.1.conv"][0], C, 3, ops.UPSAMPLE2, (H2, W2),
                             bias=P["up.seq.0.1.conv.bias"], gn_stats=True)
         u1 = self._res_fwd("up.seq.1", [u0, t5], emb_all, 6, ctx)
         u2 = self._res_fwd("up.seq.2", [u1, t4], emb_all, 7, ctx)
         u3r = self._res_fwd("up.seq.3.0", [u2, t3], emb_all, 8, ctx)
-        u3 = ops.conv_igemm([u3r], self._packs["up.seq.3.1.conv"][0], C, 3, ops.UPSAMPLE2, (H, W),
+        u3 = self._conv([u3r], self._packs["up.seq.3.1.conv"][0], C, 3, ops.UPSAMPLE2, (H, W),
                             bias=P["up.seq.3.1.conv.bias"], gn_stats=True)
         u4 = self._res_fwd("up.seq.4", [u3, t2], emb_all, 9, ctx)
         u5 = self._res_fwd("up.seq.5", [u4, t1], emb_all, 10, ctx)
@@ -599,7 +612,7 @@ class SimpleUnet(nn.Module):
         # up.seq.3.1: nearest x2 + conv
         ops.colsum(s3, G["up.seq.3.1.conv.bias"], defer=True)
         self._wgrad(du3, [u3r], 3, ops.UPSAMPLE2, G["up.seq.3.1.conv.weight"])
-        dU = ops.conv_igemm([du3], self._packs["up.seq.3.1.conv"][1], C, 3, ops.NORMAL, (H, W))
+        dU = self._conv([du3], self._packs["up.seq.3.1.conv"][1], C, 3, ops.NORMAL, (H, W))
         du3r = ops.sumpool2x2(dU)
         s3r = ops.chansum(du3r)
         (du2, s2), (dt3a, _) = self._res_bwd("up.seq.3.0", ctx, du3r, s3r, demb_all, 8)
@@ -607,7 +620,7 @@ class SimpleUnet(nn.Module):
         (du0, s0), (dt5a, _) = self._res_bwd("up.seq.1", ctx, du1, s1, demb_all, 6)
         ops.colsum(s0, G["up.seq.0.1.conv.bias"], defer=True)
         self._wgrad(du0, [u0r], 3, ops.UPSAMPLE2, G["up.seq.0.1.conv.weight"])
-        dU = ops.conv_igemm([du0], self._packs["up.seq.0.1.conv"][1], C, 3, ops.NORMAL, (H2, W2))
+        dU = self._conv([du0], self._packs["up.seq.0.1.conv"][1], C, 3, ops.NORMAL, (H2, W2))
         du0r = ops.sumpool2x2(dU)
         s0r = ops.chansum(du0r)
         (dt7, s7), (dt6a, _) = self._res_bwd("up.seq.0.0", ctx, du0r, s0r, demb_all, 5)
@@ -619,13 +632,13 @@ class SimpleUnet(nn.Module):
         # down.seq.6: stride-2 conv; its data gradient is the transposed gather
         ops.colsum(s6t, G["down.seq.6.conv.bias"], defer=True)
         self._wgrad(dt6, [t5], 3, ops.STRIDE2, G["down.seq.6.conv.weight"])
-        dt5 = ops.conv_igemm([dt6], self._packs["down.seq.6.conv"][1], C, 3, ops.TRANSPOSED2, (H2, W2), residual=dt5a)
+        dt5 = self._conv([dt6], self._packs["down.seq.6.conv"][1], C, 3, ops.TRANSPOSED2, (H2, W2), residual=dt5a)
         s5t = ops.chansum(dt5)
         ((dt4, s4t),) = self._res_bwd("down.seq.5", ctx, dt5, s5t, demb_all, 3, extra_add=[dt4a])
         ((dt3, s3t),) = self._res_bwd("down.seq.4", ctx, dt4, s4t, demb_all, 2, extra_add=[dt3a])
         ops.colsum(s3t, G["down.seq.3.conv.bias"], defer=True)
         self._wgrad(dt3, [t2], 3, ops.STRIDE2, G["down.seq.3.conv.weight"])
-        dt2 = ops.conv_igemm([dt3], self._packs["down.seq.3.conv"][1], C, 3, ops.TRANSPOSED2, (H, W), residual=dt2a)
+        dt2 = self._conv([dt3], self._packs["down.seq.3.conv"][1], C, 3, ops.TRANSPOSED2, (H, W), residual=dt2a)
         s2t = ops.chansum(dt2)
         ((dt1, s1t),) = self._res_bwd("down.seq.2", ctx, dt2, s2t, demb_all, 1, extra_add=[dt1a])
         ((dt0, s0t),) = self._res_bwd("down.seq.1", ctx, dt1, s1t, demb_all, 0, extra_add=[dt0a])

@@ -327,8 +327,18 @@ def gen_metrics(name):
     save(name, **out)
 
 
+def gen_c256():
+    """hidden_size 256 - the default of the reference's driver (gms/main.py:23); round 3: the HIP path accepts it."""
+    gen_unet(256, 8, 2, 15, "unet_c256_s8.npz")
+    gen_train(256, 8, 2, 24, "train_c256_s8.npz")
+    gen_default_init(16, 2, 72, "definit_c256_s16.npz", C=256)
+
+
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "c256":       # only the sets added in round 3 (the others are unchanged)
+        gen_c256()
+        return
     gen_schedule()
     gen_unet(32, 8, 3, 10, "unet_c32_s8.npz")
     gen_unet(32, 12, 2, 11, "unet_c32_s12.npz")
@@ -349,6 +359,7 @@ def main():
     gen_metrics("metrics.npz")
     gen_default_init(28, 4, 70, "definit_c128_s28.npz")
     gen_default_init(32, 3, 71, "definit_c128_s32.npz")
+    gen_c256()
 
 
 if __name__ == "__main__":

@@ -254,6 +254,54 @@ def _cli(args, timeout=900):
     return r.stdout
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hidden_size_256_vs_oracle_and_through_the_plugin(dtype):
+    """`--hidden_size 256` (the default of gms/main.py:23; simple_unet.py:17 takes any width): two 128-channel output blocks per
+    convolution, 8 / 16 channels per GroupNorm group.  Forward + every gradient against the oracle (itself pinned at this width by
+    tests/golden/*_c256_*.npz), then a train step and a guided sample through the plugin surface.  Other widths raise."""
+    from generative_models_amd import common
+    from generative_models_amd.diffusion.simple_unet import SimpleUnet
+    from oracle import unet_ref as U
+    C, B, S = 256, 3, 16
+    params = U.reference_init_params(C, 1, seed=5, zero_out_layers=False)
+    net = SimpleUnet(C, 0.0, compute_dtype=dtype); net.load_state_dict(params, strict=True); net = net.cuda()
+    g = torch.Generator().manual_seed(6)
+    z = torch.randn((B, 1, S, S), generator=g); l = torch.tensor([-4.0, 0.3, 6.0]); y = torch.tensor([3, -1, 8])
+    dout = torch.randn((B, 1, S, S), generator=g)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = U.unet_forward(p, z, l, guide=y)
+    ref.backward(dout)
+    ctx = {}
+    out = net.forward_hip(z.cuda(), l.cuda(), y.cuda(), None, ctx=ctx)
+    tol = TOL[dtype]
+    assert rel_err(out, ref) < tol, rel_err(out, ref)
+    net.backward_hip(ctx, dout.cuda())
+    gmax = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None)
+    bad = []
+    for name, v in p.items():
+        if v.grad is None:
+            continue
+        err = float((net.grad(name).cpu() - v.grad).abs().max())
+        if err > (3 if dtype == torch.float32 else 6) * tol * max(float(v.grad.abs().max()), 1e-3 * gmax):
+            bad.append((name, err))
+    assert not bad, bad[:8]
+    for width in (64, 192, 512):
+        with pytest.raises(ValueError):
+            SimpleUnet(width, 0.0)
+    if dtype == torch.bfloat16:
+        Model = common.discover_models()["diffusion"]
+        G = common.AttrDict(dict(Model.DG)); G.update(hidden_size=256, timesteps=4, bs=8, lr=1e-3, seed=0)
+        m = Model(G).cuda(); m.train()
+        x = (torch.rand((8, 1, 28, 28), generator=g) * 2 - 1).cuda(); yy = torch.randint(0, 10, (8,), generator=g).cuda()
+        l0 = float(m.train_step(x, yy.clone())["loss"])
+        for _ in range(5):
+            l1 = float(m.train_step(x, yy.clone())["loss"])
+        assert np.isfinite(l0) and np.isfinite(l1)
+        m.eval()
+        s = m.sample(4, yy[:4])
+        assert s.shape == (4, 1, 28, 28) and bool(torch.isfinite(s).all())
+
+
 def test_cli_at_config_1_flags(tmp_path):
     """BASELINE.json configs[0] as the reference runs it: `python -m gms.main --model=diffusion` at MNIST 28x28x1, bs=32, T=200 (the
     reference's CPU plumbing case; here the same command line on the HIP path): one epoch = eval-first test pass, evaluate() with its

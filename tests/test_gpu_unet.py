@@ -40,9 +40,11 @@ def make_net(dtype, C=128, in_channels=1, closed_form=True):
     return net.cuda(), params
 
 
-def test_unet_forward_vs_golden(golden):
-    g = golden("unet_c128_s28.npz")
-    net, _ = make_net(torch.float32)
+@pytest.mark.parametrize("name,C", [("unet_c128_s28.npz", 128), ("unet_c256_s8.npz", 256)])
+def test_unet_forward_vs_golden(golden, name, C):
+    """Reference outputs (closed-form fill) at hidden_size 128 (DiffusionModel's default) and 256 (the default of gms/main.py:23)."""
+    g = golden(name)
+    net, _ = make_net(torch.float32, C=C)
     z, l, y = T(g["z"]).cuda(), T(g["logsnr"]).cuda(), T(g["guide"]).cuda()
     with torch.no_grad():
         assert rel_err(net(z, l, guide=y), T(g["v"])) < 1e-3
@@ -51,16 +53,16 @@ def test_unet_forward_vs_golden(golden):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("name", ["definit_c128_s28.npz", "definit_c128_s32.npz"])
-def test_default_init_goldens(golden, dtype, name):
+@pytest.mark.parametrize("name,C", [("definit_c128_s28.npz", 128), ("definit_c128_s32.npz", 128), ("definit_c256_s16.npz", 256)])
+def test_default_init_goldens(golden, dtype, name, C):
     """Reference-pinned vectors at default-init scale (oracle/make_golden.py:gen_default_init): forward with / without labels,
     per-sample training loss, every gradient norm, two full gradients.  fp32 mode 1e-3, bf16 mode 1e-2 - max-norm, no slack."""
     from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
     from generative_models_amd.diffusion.simple_unet import SimpleUnet
     from oracle import unet_ref as U
     g = golden(name)
-    params = U.reference_init_params(128, 1, seed=int(g["init_seed"]), zero_out_layers=False)
-    net = SimpleUnet(128, 0.0, compute_dtype=dtype); net.load_state_dict(params, strict=True); net = net.cuda()
+    params = U.reference_init_params(C, 1, seed=int(g["init_seed"]), zero_out_layers=False)
+    net = SimpleUnet(C, 0.0, compute_dtype=dtype); net.load_state_dict(params, strict=True); net = net.cuda()
     tol = TOL[dtype]
     z, l, y = T(g["z"]).cuda(), T(g["logsnr"]).cuda(), T(g["guide"]).cuda()
     with torch.no_grad():
@@ -128,13 +130,14 @@ def test_unet_forward_backward_vs_oracle(dtype, in_channels, S):
     assert not bad, bad[:8]
 
 
-def test_training_step_vs_golden(golden, dtype=torch.float32):
+@pytest.mark.parametrize("name,C", [("train_c128_s28.npz", 128), ("train_c256_s8.npz", 256)])
+def test_training_step_vs_golden(golden, name, C, dtype=torch.float32):
     """(x0, y, u, eps) -> loss[B], gradient norms of every tensor, selected gradients, two Adam steps (row H1).  Closed-form
-    fill, exact-fp32 mode; the bf16 bar on a training step is held by test_default_init_goldens."""
+    fill, exact-fp32 mode; the 16-bit bar on a training step is held by test_default_init_goldens."""
     from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
     from generative_models_amd.diffusion.optim import FusedAdam
-    g = golden("train_c128_s28.npz")
-    net, params = make_net(dtype)
+    g = golden(name)
+    net, params = make_net(dtype, C=C)
     diff = GaussianDiffusion(mean_type="v", num_steps=250)
     opt = FusedAdam(net, lr=3e-4)
     x0, y, u, eps = (T(g[k]).cuda() for k in ("x0", "y", "u", "eps"))

@@ -62,7 +62,7 @@ def test_embedding_and_algebra(golden):
 
 
 @pytest.mark.parametrize("name,C", [("unet_c32_s8.npz", 32), ("unet_c32_s12.npz", 32), ("unet_c32_s16.npz", 32),
-                                    ("unet_c128_s28.npz", 128), ("unet_c64_s8.npz", 64)])
+                                    ("unet_c128_s28.npz", 128), ("unet_c64_s8.npz", 64), ("unet_c256_s8.npz", 256)])
 def test_unet_forward(golden, name, C):
     g = golden(name)
     p = U.closed_form_params(C)
@@ -73,7 +73,8 @@ def test_unet_forward(golden, name, C):
         close(U.unet_forward(p, z, l, guide=y, cond_w=T(g["cond_w"])), g["v_condw"], 2e-5)
 
 
-@pytest.mark.parametrize("name,C", [("train_c32_s8.npz", 32), ("train_c32_s16.npz", 32), ("train_c128_s28.npz", 128), ("train_c64_s8.npz", 64)])
+@pytest.mark.parametrize("name,C", [("train_c32_s8.npz", 32), ("train_c32_s16.npz", 32), ("train_c128_s28.npz", 128), ("train_c64_s8.npz", 64),
+                                    ("train_c256_s8.npz", 256)])
 def test_training_loss_and_grads(golden, name, C):
     g = golden(name)
     p = {k: v.clone().requires_grad_(True) for k, v in U.closed_form_params(C).items()}
@@ -205,12 +206,12 @@ def test_attention_block_definition_matches_sdpa():
     assert len(U.param_spec(C)) == 160
 
 
-@pytest.mark.parametrize("name", ["definit_c128_s28.npz", "definit_c128_s32.npz"])
-def test_default_init_goldens_pin_the_oracle(golden, name):
+@pytest.mark.parametrize("name,C", [("definit_c128_s28.npz", 128), ("definit_c128_s32.npz", 128), ("definit_c256_s16.npz", 256)])
+def test_default_init_goldens_pin_the_oracle(golden, name, C):
     """The default-init-scale set (oracle/make_golden.py:gen_default_init) the bf16 bar is held on: forward with / without
     labels, per-sample loss and every gradient norm of the reference, reproduced by the oracle."""
     g = golden(name)
-    p = U.reference_init_params(128, 1, seed=int(g["init_seed"]), zero_out_layers=False)
+    p = U.reference_init_params(C, 1, seed=int(g["init_seed"]), zero_out_layers=False)
     z, l, y = T(g["z"]), T(g["logsnr"]), T(g["guide"])
     with torch.no_grad():
         close(U.unet_forward(p, z, l, guide=y), g["v"])
