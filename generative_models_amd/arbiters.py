@@ -1,0 +1,72 @@
+"""Stand-in feature extractors for the heavy eval (reference gms/main.py:85-90, gms/arbiters/*).
+
+The reference embeds samples and test images with a PRETRAINED autoencoder (64-dim latents: FID, precision / recall) and scores
+class-conditional samples with a pretrained classifier; both are TorchScript blobs that are not part of its checkout
+(`.MISSING_LARGE_BLOBS`) and cannot be produced here (their training scripts and MNIST are out of reach).  When the files named by
+`--autoencoder` / `--classifier` exist they are loaded exactly as the reference does.  When they do not, these two stand-ins keep
+`--eval_heavy 1` running end to end on the HIP path's samples:
+
+* `RandomFeatureEncoder` - a fixed-seed, untrained convolutional encoder to 64 features (stock torch ops: evaluation only, far
+  off the hot path).  Fréchet distance and k-NN precision / recall in a random-feature space are well-defined and move the right
+  way (tests/test_host_logic.py), but their VALUES are not comparable with numbers taken in the reference's autoencoder space.
+* `CentroidClassifier` - nearest-class-centroid logits in that feature space, fitted in closed form on labelled real batches
+  (one pass over the test set): `classifier_loss` then measures whether a class-conditional sample lands nearer to its own class.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class RandomFeatureEncoder(nn.Module):
+    def __init__(self, z_size=64, width=32, seed=1234):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        def conv(cin, cout, k):
+            w = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5
+            return nn.Parameter(w, requires_grad=False)
+        self.w1, self.w2, self.w3 = conv(1, width, 5), conv(width, 2 * width, 3), conv(2 * width, 2 * width, 3)
+        self.proj = nn.Parameter(torch.randn((z_size, 2 * width * 2), generator=g) * (1.0 / (4 * width)) ** 0.5, requires_grad=False)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x [N, C, H, W] in [-1, 1] (any C: channels are averaged) -> [N, z_size]"""
+        h = x.float().mean(1, keepdim=True)
+        h = F.leaky_relu(F.conv2d(h, self.w1, stride=2, padding=2), 0.2)
+        h = F.leaky_relu(F.conv2d(h, self.w2, stride=2, padding=1), 0.2)
+        h = F.leaky_relu(F.conv2d(h, self.w3, stride=2, padding=1), 0.2)
+        feat = torch.cat([h.mean((2, 3)), h.amax((2, 3))], 1)          # average + max pooling: position-tolerant statistics
+        return feat @ self.proj.t()
+
+
+class CentroidClassifier(nn.Module):
+    """logits[n, c] = -|z_n - mu_c|^2 / (2 s^2): a Gaussian class model with shared isotropic variance on the encoder's features."""
+
+    def __init__(self, encoder, classes=10):
+        super().__init__()
+        self.encoder, self.classes = encoder, classes
+        self.register_buffer("mu", torch.zeros(classes, 1))
+        self.register_buffer("count", torch.zeros(classes))
+        self.register_buffer("var", torch.ones(()))
+        self._sum, self._sq, self._n = None, 0.0, 0
+
+    @torch.no_grad()
+    def fit(self, batches):
+        """batches: iterable of (x, y) with integer labels; one pass."""
+        for x, y in batches:
+            z = self.encoder(x)
+            if self._sum is None:
+                self._sum = torch.zeros((self.classes, z.shape[1]), device=z.device)
+                self.count = self.count.to(z.device)
+            keep = (y >= 0) & (y < self.classes)
+            self._sum.index_add_(0, y[keep], z[keep])
+            self.count.index_add_(0, y[keep], torch.ones_like(y[keep], dtype=torch.float32))
+            self._sq += float((z[keep] ** 2).sum()); self._n += int(keep.sum())
+        self.mu = self._sum / self.count.clamp_min(1.0)[:, None]
+        within = self._sq - float((self.mu ** 2 * self.count[:, None]).sum())
+        self.var = torch.tensor(max(within / max(1, self._n * self.mu.shape[1]), 1e-6), device=self.mu.device)
+        return self
+
+    @torch.no_grad()
+    def forward(self, x):
+        z = self.encoder(x)
+        return -torch.cdist(z, self.mu.to(z.dtype)) ** 2 / (2.0 * self.var)

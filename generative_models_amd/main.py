@@ -214,19 +214,27 @@ def _run_device(flag):
     return str(flag)
 
 
-def _feature_extractors(G, device):
-    """TorchScript autoencoder / classifier of the heavy eval (gms/main.py:86-91).  The reference's weight files are not in its
-    checkout (.MISSING_LARGE_BLOBS): without them the heavy eval is switched off with a message instead of failing the run."""
+def _feature_extractors(G, device, test_ds=None):
+    """TorchScript autoencoder / classifier of the heavy eval (gms/main.py:86-91) when the files exist.  The reference's weight files
+    are not in its checkout (.MISSING_LARGE_BLOBS): without them the stand-ins of `arbiters.py` take over (a fixed random-feature
+    encoder; a nearest-class-centroid classifier fitted on the labelled test batches), so `--eval_heavy 1` runs end to end."""
     if not G.eval_heavy:
         return None, None
-    wanted = [Path(G.autoencoder)] + ([Path(G.classifier)] if G.get("class_cond", 0) else [])
-    absent = [str(f) for f in wanted if not f.exists()]
-    if absent:
-        print(f"eval_heavy disabled: {', '.join(absent)} not found (the reference's weight files are not in its checkout)")
-        G.eval_heavy = 0
-        return None, None
-    autoencoder = torch.jit.load(str(G.autoencoder)).to(device)
-    classifier = torch.jit.load(str(G.classifier)).to(device) if G.get("class_cond", 0) else None
+    from . import arbiters
+    cond = bool(G.get("class_cond", 0))
+    if Path(G.autoencoder).exists():
+        autoencoder = torch.jit.load(str(G.autoencoder)).to(device)
+    else:
+        print(f"eval_heavy: {G.autoencoder} not found - using the built-in random-feature encoder (values not comparable with the "
+              f"reference's autoencoder space)")
+        autoencoder = arbiters.RandomFeatureEncoder().to(device)
+    classifier = None
+    if cond and Path(G.classifier).exists():
+        classifier = torch.jit.load(str(G.classifier)).to(device)
+    elif cond:
+        print(f"eval_heavy: {G.classifier} not found - fitting the built-in nearest-centroid classifier on the test batches")
+        batches = ((b[0].to(device), b[1].to(device)) for b in test_ds)
+        classifier = arbiters.CentroidClassifier(arbiters.RandomFeatureEncoder().to(device)).to(device).fit(batches)
     return autoencoder, classifier
 
 
@@ -254,7 +262,7 @@ def load_model_and_data(argv=None):
     train_ds, test_ds = _datasets(G, device)
     if parallel.rank() == 0:
         print("num_vars", common.count_vars(model))
-    autoencoder, classifier = _feature_extractors(G, device)
+    autoencoder, classifier = _feature_extractors(G, device, test_ds)
     return model, train_ds, test_ds, autoencoder, classifier, G
 
 

@@ -310,6 +310,11 @@ def test_cli_at_config_1_flags(tmp_path):
     out = _cli(["--model=diffusion", "--bs", "32", "--timesteps", "200", "--epochs=1", "--train_batches", "4", "--test_batches", "2",
                 "--logdir", str(tmp_path / "cfg1")])
     assert "diffusion/test/loss" in out and "diffusion/train/loss" in out and "SAVED MODEL" in out
+    # DiffusionModel.DG.eval_heavy = 1 (diffusion_model.py:22): with the reference's TorchScript arbiters absent the built-in
+    # stand-ins run the heavy eval on the HIP samples (N3): FID / precision / recall / classifier loss are logged
+    assert "RUNNING HEAVY EVAL" in out and "DONE HEAVY EVAL" in out
+    for key in ("eval/fid", "eval/precision", "eval/recall", "eval/f1", "eval/cond_fid", "eval/classifier_loss"):
+        assert key in out, key
     with open(tmp_path / "cfg1" / "hps.yaml") as f:
         hps = yaml.load(f, Loader=yaml.Loader)
     assert hps["bs"] == 32 and hps["timesteps"] == 200 and hps["hidden_size"] == 128 and hps["act_dtype"] in ("fp16", "bf16")
