@@ -130,10 +130,17 @@ def test_unet_forward_backward_vs_oracle(dtype, in_channels, S):
     assert not bad, bad[:8]
 
 
-@pytest.mark.parametrize("name,C", [("train_c128_s28.npz", 128), ("train_c256_s8.npz", 256)])
-def test_training_step_vs_golden(golden, name, C, dtype=torch.float32):
+# the closed-form fill's head cancels to 1/10 of its operands, so a storage rounding shows ~10x larger on these vectors than on the
+# default-init ones: the 16-bit mode is held to 3x its bar here (measured with fp16 forward storage: see profiles/r03_parity_report.txt)
+CLOSED_FORM_SLACK = {torch.float32: 1.0, torch.bfloat16: 3.0}
+
+
+@pytest.mark.parametrize("name,C,dtype", [("train_c128_s28.npz", 128, torch.float32), ("train_c256_s8.npz", 256, torch.float32),
+                                          ("train_c128_s28.npz", 128, torch.bfloat16)])
+def test_training_step_vs_golden(golden, name, C, dtype):
     """(x0, y, u, eps) -> loss[B], gradient norms of every tensor, selected gradients, two Adam steps (row H1).  Closed-form
-    fill, exact-fp32 mode; the 16-bit bar on a training step is held by test_default_init_goldens."""
+    fill (the bug-exposing set): exact-fp32 mode at 1e-3, and the 16-bit mode too - loss, gradient norms, the loss after each of the
+    two Adam steps and the first parameter delta (round 2 had dropped the 16-bit run of this set)."""
     from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
     from generative_models_amd.diffusion.optim import FusedAdam
     g = golden(name)
@@ -142,7 +149,7 @@ def test_training_step_vs_golden(golden, name, C, dtype=torch.float32):
     opt = FusedAdam(net, lr=3e-4)
     x0, y, u, eps = (T(g[k]).cuda() for k in ("x0", "y", "u", "eps"))
     B = x0.shape[0]
-    tol = TOL[dtype]
+    tol = TOL[dtype] * CLOSED_FORM_SLACK[dtype]
     for step in (1, 2):
         out = diff.train_forward_backward(net=partial(net, guide=y), x=x0, grad_scale=1.0 / B, u=u, eps=eps)
         if step == 1:
@@ -163,9 +170,13 @@ def test_training_step_vs_golden(golden, name, C, dtype=torch.float32):
                     assert float((full[:4, :6] - gs).abs().max()) < 3 * tol * float(full.abs().max()), k
         assert rel_err(out["loss"].mean(), T(g[f"loss_step{step}"])) < tol
         opt.step()
-        if dtype == torch.float32:
-            d = net.param("down.seq.0.conv.weight").cpu() - params["down.seq.0.conv.weight"]
-            assert rel_err(d, T(g[f"delta_stem_step{step}"])) < 2e-2
+        d = net.param("down.seq.0.conv.weight").cpu() - params["down.seq.0.conv.weight"]
+        # Adam's first steps are ~ lr * sign(g): an element whose gradient is within the rounding noise of zero may flip
+        assert rel_err(d, T(g[f"delta_stem_step{step}"])) < (2e-2 if dtype == torch.float32 else 2.0)
+        if dtype != torch.float32:
+            ref_d = T(g[f"delta_stem_step{step}"])
+            agree = float(((d * ref_d) > 0).float().mean())
+            assert agree > 0.97, agree                      # ... but the update direction agrees almost everywhere
 
 
 def test_autograd_bridge_matches_fused_path(golden):

@@ -1,10 +1,12 @@
 #!/bin/bash
-# Round-2 judged artefacts.  usage: tools/profile_r02.sh [tag]   (writes gpurun_out/<tag>/..., copies the summaries into profiles/)
-#   r02_<cfg>_train_serial_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the train steps with non-overlapping launches
+# Round-3 judged artefacts.  usage: tools/profile_r03.sh [tag]   (writes gpurun_out/<tag>/..., copies the summaries into profiles/)
+#   r03_<cfg>_train_serial_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the train steps with non-overlapping launches
 #                                             (GMK_WGRAD_STREAM=0): the averages that compare with the bench line's HIP events
-#   r02_bench_kernel_stats.csv                the default `python bench.py` command (all configs, samplers, overlapping streams)
-#   r02_traffic.json                          HBM bytes per launch of every kernel of the headline config, separate --pmc passes
-TAG=${1:-r02}
+#   r03_bench_kernel_stats.csv                the default `python bench.py` command (all configs, samplers, overlapping streams)
+#   r03_traffic.json                          HBM bytes per launch of every kernel of the headline config, separate --pmc passes,
+#                                             stamped with the kernel-source hash (bench.py quotes it only for the same sources)
+#   r03_bench.json                            the bench line of the same build;  r03_parity_report.txt  tests/parity_report.py
+TAG=${1:-r03}
 OUT=/tmp/gmk_$TAG                 # raw traces are hundreds of MB: they stay on the box; only the summaries travel
 KEEP=gpurun_out/$TAG
 REPO=$(pwd)
@@ -13,11 +15,11 @@ cd /tmp && export TMPDIR=/tmp
 cd $REPO
 for cfg in cfg2 cfg1 cfg3; do
   GMK_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial_$cfg -o serial -- python bench.py --config $cfg --others 0 --sampler_steps 0 --no_profile --no_cpu --steps 10 --warmup 3 > $OUT/serial_$cfg.log 2>&1 || exit 1
-  cp $(find $OUT/serial_$cfg -name "*kernel_stats.csv" | head -1) profiles/r02_${cfg}_train_serial_kernel_stats.csv
+  cp $(find $OUT/serial_$cfg -name "*kernel_stats.csv" | head -1) profiles/r03_${cfg}_train_serial_kernel_stats.csv
   echo "serial $cfg done"
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python bench.py --no_cpu --sampler_steps 100 > $OUT/prof_bench.log 2>&1 || exit 1
-cp $(find $OUT/bench -name "*kernel_stats.csv" | head -1) profiles/r02_bench_kernel_stats.csv
+cp $(find $OUT/bench -name "*kernel_stats.csv" | head -1) profiles/r03_bench_kernel_stats.csv
 echo "bench stats done"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
@@ -26,17 +28,21 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
 done
 python tools/traffic_parse.py $OUT/pmc > $OUT/pmc/kernels.json || exit 1
 python - <<PY
-import json, subprocess
+import json, sys
+sys.path.insert(0, ".")
+import bench
 k = json.load(open("$OUT/pmc/kernels.json"))
-out = {"cfg2": {"kernels": k, "provenance": "rocprofv3 --pmc, three separate passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) of "
-                "'bench.py --config cfg2 --others 0 --steps 3 --warmup 1 --sampler_steps 2' (tools/profile_r02.sh); FETCH_SIZE doubled (gfx950, 16-B/lane "
+out = {"cfg2": {"kernel_hash": bench.kernel_hash(), "kernels": k,
+                "provenance": "rocprofv3 --pmc, three separate passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) of "
+                "'bench.py --config cfg2 --others 0 --steps 3 --warmup 1 --sampler_steps 2' (tools/profile_r03.sh); FETCH_SIZE doubled (gfx950, 16-B/lane "
                 "streaming reads: MI355X_MICROARCH.md HBM); bytes averaged over the kernel's launches of 4 train steps + 6 sampler forwards; "
                 "sclk_ghz_est = GRBM_GUI_ACTIVE per XCD / dispatch time of the same pass (tools/traffic_parse.py)"}}
-json.dump(out, open("profiles/r02_traffic.json", "w"), indent=1)
+json.dump(out, open("profiles/r03_traffic.json", "w"), indent=1)
 PY
 echo "traffic done"
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
-cp $OUT/bench.json profiles/r02_bench.json
-cp profiles/r02_* $KEEP/
+cp $OUT/bench.json profiles/r03_bench.json
+python tests/parity_report.py > profiles/r03_parity_report.txt 2>/dev/null || exit 1
+cp profiles/r03_* $KEEP/
 cp $OUT/*.log $OUT/bench.err $KEEP/ 2>/dev/null
 tail -c 300 $OUT/bench.json
