@@ -233,7 +233,8 @@ def _feature_extractors(G, device, test_ds=None):
         classifier = torch.jit.load(str(G.classifier)).to(device)
     elif cond:
         print(f"eval_heavy: {G.classifier} not found - fitting the built-in nearest-centroid classifier on the test batches")
-        batches = ((b[0].to(device), b[1].to(device)) for b in test_ds)
+        import copy
+        batches = ((b[0].to(device), b[1].to(device)) for b in copy.deepcopy(test_ds))      # a copy: the run's own test stream stays untouched
         classifier = arbiters.CentroidClassifier(arbiters.RandomFeatureEncoder().to(device)).to(device).fit(batches)
     return autoencoder, classifier
 
