@@ -12,11 +12,11 @@ def timeit(fn, n=10):
         torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / n)
     return best * 1e6
 for B, S, nsrc in ((1024, 28, 1), (1024, 28, 2), (2048, 32, 1), (2048, 32, 2), (2048, 16, 1), (1024, 64, 1)):
-    srcs = [torch.randn(B, S, S, C, device="cuda").bfloat16() for _ in range(nsrc)]
+    srcs = [torch.randn(B, S, S, C, device="cuda").half() for _ in range(nsrc)]
     ct = C * nsrc
     gamma = torch.ones(ct, device="cuda"); beta = torch.zeros(ct, device="cuda")
     w = torch.randn(128, ct, 3, 3, device="cuda") / (ct * 9) ** 0.5
-    wf = torch.empty(w.numel(), device="cuda", dtype=torch.bfloat16); ops.pack_conv_weight(w, wf, None)
+    wf = torch.empty(w.numel(), device="cuda", dtype=torch.float16); ops.pack_conv_weight(w, wf, None)
     gpc = 32 // nsrc
     tsc = torch.empty((B, ct), device="cuda"); tsh = torch.empty_like(tsc)
     def gn_all():
