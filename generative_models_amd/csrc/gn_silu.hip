@@ -292,14 +292,14 @@ template <int NVEC>
 __device__ __forceinline__ float vec_lane_sum(float v) { return lanes_sum_from<NVEC>(v); }
 
 template <typename T, int ITER, int NVEC>       // T: bf16_t or f16_t (input and output)
-__global__ __launch_bounds__(512) void gn_silu_fwd_reg_kernel(const T* __restrict__ x, T* __restrict__ y,
+__global__ __launch_bounds__(1024) void gn_silu_fwd_reg_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ mean, float* __restrict__ rstd, int HW, int C,
                                                              int G, float eps, int B, int planes, float drop_p,
                                                              uint64_t drop_seed, uint64_t drop_off, const float* __restrict__ xadd,
                                                              int xadd_stride, float* __restrict__ tab_sc = nullptr,
                                                              float* __restrict__ tab_sh = nullptr, int tab_stride = 0) {
-    __shared__ float red[8][NVEC][4];       // [wave][vec][s0, q0, s1, q1]
+    __shared__ float red[16][NVEC][4];      // [wave][vec][s0, q0, s1, q1]
     __shared__ float smean[16], srstd[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     constexpr int CS = NVEC * 8, LOGV = NVEC == 8 ? 3 : 2;
@@ -737,10 +737,14 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
     const int gn_mode = gmk_kernel_choice(2, "GMK_GN_KERNEL");
     // (at 7x7 / 8x8 the whole-sample streaming kernel wins: 19 vs 26 us at 8x8, B = 2048 - the slabs are too small to pay for a workgroup each)
     GMK_REQUIRE(dtype != GMK_F16 || !stats_part, "gmk_gn_silu_fwd: producer statistics go with bf16 tensors only");
-    if (gmk_is16(dtype) && !stats_part && (gn_mode == 5 || gn_mode == 6 || (gn_mode == 0 && HW > 64)) && C % 64 == 0 &&
-               32 % (C / groups) == 0 && gn_reg_iter(HW, 8) > 0) {
-        const int nvec = gn_mode == 5 ? 4 : 8;                 // 32- or 64-channel slabs (64 = whole 128-B lines)
-        const int it = gn_reg_iter(HW, nvec), planes = (HW + it - 1) / it, threads = (planes * nvec + 63) / 64 * 64;
+    // 64 x 64 (HW up to 4096): a 32-channel slab of a sample is 256 KiB - the registers of ONE 1024-thread workgroup (16 pixels x 16 B per
+    // thread); single read instead of the streaming kernel's two sweeps
+    const bool big = gmk_is16(dtype) && !stats_part && (gn_mode == 8 || gn_mode == 0) && HW > 1024 && HW <= 4096 && HW % 16 == 0 &&
+                     C % 32 == 0 && 32 % (C / groups) == 0;
+    if (big || (gmk_is16(dtype) && !stats_part && (gn_mode == 5 || gn_mode == 6 || (gn_mode == 0 && HW > 64)) && C % 64 == 0 &&
+               32 % (C / groups) == 0 && gn_reg_iter(HW, 8) > 0)) {
+        const int nvec = (big || gn_mode == 5) ? 4 : 8;        // 32- or 64-channel slabs (64 = whole 128-B lines)
+        const int it = big ? 16 : gn_reg_iter(HW, nvec), planes = (HW + it - 1) / it, threads = (planes * nvec + 63) / 64 * 64;
         const int nblk = B * (C / (nvec * 8));
         gmk_note_kernel(21);
 #define GMK_GN_FWD_REG(IT, NV)                                                                                                           \
@@ -758,7 +762,8 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
             if (it == 1) GMK_GN_FWD_REG(1, 4);
             else if (it == 2) GMK_GN_FWD_REG(2, 4);
             else if (it == 4) GMK_GN_FWD_REG(4, 4);
-            else GMK_GN_FWD_REG(8, 4);
+            else if (it == 8) GMK_GN_FWD_REG(8, 4);
+            else GMK_GN_FWD_REG(16, 4);
         } else {
             if (it == 1) GMK_GN_FWD_REG(1, 8);
             else if (it == 2) GMK_GN_FWD_REG(2, 8);
@@ -825,6 +830,18 @@ extern "C" int gmk_gn_stats(const void* x, const float* gamma, const float* beta
         else if (it == 8) GMK_GN_STATS_REG(8);
         else GMK_GN_STATS_REG(16);
 #undef GMK_GN_STATS_REG
+    } else if (HW > 1024 && HW <= 4096 && HW % 16 == 0 && C % 32 == 0 && 32 % (C / groups) == 0) {
+        // 64 x 64: the 1024-thread register kernel on 32-channel slabs, as gmk_gn_silu_fwd chooses (same statistics bits)
+        const int planes = HW / 16, nblk = B * (C / 32);
+        gmk_note_kernel(21);
+        if (dtype == GMK_F16)
+            gn_silu_fwd_reg_kernel<f16_t, 16, 4><<<nblk, planes * 4, 0, gmk_stream(stream)>>>((const f16_t*)x, (f16_t*)nullptr, gamma, beta, mean, rstd,
+                                                                                             HW, C, groups, eps, B, planes, 0.f, 0, 0, xadd, xadd_stride,
+                                                                                             tab_scale, tab_shift, tab_stride);
+        else
+            gn_silu_fwd_reg_kernel<bf16_t, 16, 4><<<nblk, planes * 4, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)nullptr, gamma, beta, mean, rstd,
+                                                                                              HW, C, groups, eps, B, planes, 0.f, 0, 0, xadd, xadd_stride,
+                                                                                              tab_scale, tab_shift, tab_stride);
     } else {
         const int CS = gn_slab_channels(0, C, groups, HW, 2, false);
         gmk_note_kernel(22);
