@@ -415,15 +415,26 @@ __device__ __forceinline__ f32x2_t silu_grad2(f32x2_t x, f32x2_t dy, f32x2_t s, 
 // 3 workgroups per CU (LDS), thread = (vec = tid & 3, plane = tid >> 2), pixel p = plane + 64 i.
 // NVEC = 2 (16-channel slabs, 1024 threads, x in 128 KiB of LDS) carries the same scheme to 64 x 64 images, where a 32-channel slab
 // fits neither the registers nor the LDS and the two-sweep streaming kernel used to run (5 passes over HBM instead of 3).
-template <typename TX, int ITER, int THREADS, int NVEC = 4>      // TX: storage type of the saved activation x (bf16_t / f16_t); gradients are bf16
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? 3 : 4, 4))) void gn_silu_bwd_hybrid_kernel(
+// KEEP: iterations whose dy vector stays in registers between the sweeps (default: all; the others are read again in the second sweep).
+// XREG: the last XREG iterations keep their x in registers instead of LDS.  EXACT: HW == ITER * PL, no pixel masks, and both sweeps are
+// software-pipelined (the loads of the next pixel chunk are in flight under the arithmetic of the current one).
+// The 64 x 64 form on 32-channel slabs is <32, 512, 4, 28, 13>: 512 KiB of x + dy per slab against 160 KiB of LDS, so ONE 512-thread
+// workgroup per CU at 256 registers per lane holds 19 / 32 of x in LDS, 13 / 32 of x and 28 / 32 of dy in registers and reads an eighth
+// of dy twice: 3.125 passes on 64-byte segments per pixel row (the 16-channel form: 3 passes on 32-byte segments, 11 - 25 % slower).
+// With two waves per SIMD this form is VALU-bound in its second sweep (exp + rcp are quarter rate: 8 of ~ 17 issue slots per element),
+// which is why the gradient addends are almost free there.
+template <typename TX, int ITER, int THREADS, int NVEC = 4, int KEEP = ITER, int XREG = 0, bool EXACT = (XREG > 0)>      // TX: storage type of the saved activation x (bf16_t / f16_t); gradients are bf16
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(XREG > 0 ? 2 : THREADS == 256 ? 3 : 4, XREG > 0 ? 2 : 4))) void gn_silu_bwd_hybrid_kernel(
     const bf16_t* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ dadd1,
     const bf16_t* __restrict__ dadd2, bf16_t* __restrict__ dx, float* __restrict__ dgp, float* __restrict__ dbp,
     float* __restrict__ dxsum, int dxsum_stride, int HW, int C, int G, int B, float drop_p, uint64_t drop_seed,
     uint64_t drop_off, const float* __restrict__ xadd, int xadd_stride) {
     constexpr int CS = NVEC * 8;
-    extern __shared__ __attribute__((aligned(16))) char xs_lds[];        // [HW][NVEC] x 16 B
+    constexpr int XLDS = ITER - XREG;                                    // iterations whose x is parked in LDS
+    constexpr int CH = ITER >= 32 ? 4 : 2;                               // pixels per load chunk of the first sweep
+    constexpr bool kExact = EXACT;                                       // HW == ITER * PL (the host checks): no pixel masks, pipelined sweeps
+    extern __shared__ __attribute__((aligned(16))) char xs_lds[];        // [min(HW, XLDS * PL)][NVEC] x 16 B
     constexpr int NW = THREADS / 64, PL = THREADS / NVEC;      // waves, pixel planes
     __shared__ float red[NW][NVEC][16];
     __shared__ float chg[CS], chb[CS];
@@ -455,42 +466,66 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
         }
     }
     constexpr float kNegLog2e = -1.4426950408889634f;
-    u32x4_t dr[ITER];
+    u32x4_t dr[KEEP];
+    u32x4_t xk[XREG > 0 ? XREG : 1];
     f32x2_t ax[4], ab[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) { ax[jj] = f32x2_t{0.f, 0.f}; ab[jj] = f32x2_t{0.f, 0.f}; }
-    // chunks of 2 pixels: 4 independent 16-B loads in flight per thread, then their arithmetic; the fence keeps the
+    // chunks of CH pixels: 2 CH independent 16-B loads in flight per thread, then their arithmetic; the fence keeps the
     // scheduler from hoisting every load of the sweep to the top (26 x 4 VGPRs)
+    // (running offsets, opaque to the optimiser: with the sweep unrolled it otherwise materialises every iteration's 64-bit address and
+    // LDS address up front - 100+ spilled registers in the 16-iteration form)
+    size_t eoff = base + (size_t)pl * C;
+    const size_t estride = (size_t)PL * C;
+    uint32_t loff = ((uint32_t)pl * NVEC + vec) * 16;
+    // kPipe: the loads of chunk c + 1 are issued before the arithmetic of chunk c (the 512-thread form has one workgroup per CU and
+    // nothing else to hide the load latency behind)
+    constexpr int NCH = (ITER + CH - 1) / CH, kPipe = kExact ? 1 : 0;
+    u32x4_t xr[2][CH], dq[2][CH];
 #pragma unroll
-    for (int i0 = 0; i0 < ITER; i0 += 2) {
-        u32x4_t xr[2];
+    for (int c = 0; c < NCH + kPipe; ++c) {
+        if (c < NCH) {
+            if (ITER > 8) asm volatile("" : "+v"(eoff));
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = i0 + u;
-            if (i >= ITER) continue;
-            const int p = pl + PL * i;
-            const bool ok = p < HW;
-            xr[u] = ok ? *reinterpret_cast<const u32x4_t*>(x + base + (size_t)p * C) : u32x4_t{0u, 0u, 0u, 0u};
-            dr[i] = ok ? *reinterpret_cast<const u32x4_t*>(dy + base + (size_t)p * C) : u32x4_t{0u, 0u, 0u, 0u};     // dy = 0 masks the pixel
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = i0 + u;
-            if (i >= ITER) continue;
-            const int p = pl + PL * i;
-            if (p < HW) *reinterpret_cast<u32x4_t*>(xs_lds + ((size_t)p * NVEC + vec) * 16) = xr[u];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const f32x2_t xv = unpack2<TX>(xr[u][jj]), dv = unpack2<bf16_t>(dr[i][jj]);
-                const f32x2_t dg = silu_grad2(xv, dv, sv[jj], tv[jj], kNegLog2e);
-                ax[jj] = __builtin_elementwise_fma(dg, xv, ax[jj]);
-                ab[jj] += dg;
+            for (int u = 0; u < CH; ++u) {
+                const int i = c * CH + u;
+                if (i >= ITER) continue;
+                const int p = pl + PL * i;
+                const bool ok = kExact || p < HW;
+                xr[c & 1][u] = ok ? *reinterpret_cast<const u32x4_t*>(x + eoff + u * estride) : u32x4_t{0u, 0u, 0u, 0u};
+                dq[c & 1][u] = ok ? *reinterpret_cast<const u32x4_t*>(dy + eoff + u * estride) : u32x4_t{0u, 0u, 0u, 0u};     // dy = 0 masks the pixel
             }
+            eoff += CH * estride;
+            if (kPipe) __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (c >= kPipe) {
+            const int cc = c - kPipe;
+            if (ITER > 8) asm volatile("" : "+v"(loff));
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int i = cc * CH + u;
+                if (i >= ITER) continue;
+                const int p = pl + PL * i;
+                const u32x4_t xq = xr[cc & 1][u], dv4 = dq[cc & 1][u];
+                if (i < KEEP) dr[i < KEEP ? i : 0] = dv4;
+                if (i >= XLDS) xk[i >= XLDS ? i - XLDS : 0] = xq;
+                else if (kExact || p < HW) *reinterpret_cast<u32x4_t*>(xs_lds + loff + u * (PL * NVEC * 16)) = xq;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const f32x2_t xv = unpack2<TX>(xq[jj]), dv = unpack2<bf16_t>(dv4[jj]);
+                    const f32x2_t dg = silu_grad2(xv, dv, sv[jj], tv[jj], kNegLog2e);
+                    ax[jj] = __builtin_elementwise_fma(dg, xv, ax[jj]);
+                    ab[jj] += dg;
+                }
+            }
+            loff += CH * PL * NVEC * 16;
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
-    for (int i = 0; i < ITER; ++i) asm volatile("" : "+v"(dr[i]));          // stay packed across the reduction
+    for (int i = 0; i < KEEP; ++i) asm volatile("" : "+v"(dr[i]));          // stay packed across the reduction
+#pragma unroll
+    for (int i = 0; i < XREG; ++i) asm volatile("" : "+v"(xk[i]));
     float ag[8], abk[8];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -540,16 +575,69 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
     float xs[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) xs[k] = 0.f;
+    eoff = base + (size_t)pl * C;
+    loff = ((uint32_t)pl * NVEC + vec) * 16;
+    if constexpr (kExact) {
+        // pipelined like the first sweep: the global loads of pixel pair c + 1 (gradient addends, the part of dy that was not kept) are
+        // issued before the arithmetic and the stores of pair c
+        constexpr int N2 = ITER / 2;
+        u32x4_t a1[2][2], a2[2][2], dq2[2][2];
+        size_t lo = eoff;
 #pragma unroll
-    for (int i = 0; i < ITER; ++i) {
+        for (int c = 0; c < N2 + 1; ++c) {
+            if (c < N2) {
+                asm volatile("" : "+v"(lo));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = 2 * c + u;
+                    if (i >= KEEP) dq2[c & 1][u] = *reinterpret_cast<const u32x4_t*>(dy + lo + u * estride);
+                    if (dadd1) a1[c & 1][u] = *reinterpret_cast<const u32x4_t*>(dadd1 + lo + u * estride);
+                    if (dadd2) a2[c & 1][u] = *reinterpret_cast<const u32x4_t*>(dadd2 + lo + u * estride);
+                }
+                lo += 2 * estride;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (c >= 1) {
+                const int cc = c - 1;
+                asm volatile("" : "+v"(eoff), "+v"(loff));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = 2 * cc + u;
+                    const u32x4_t xq = i >= XLDS ? xk[i >= XLDS ? i - XLDS : 0]
+                                                 : *reinterpret_cast<const u32x4_t*>(xs_lds + loff + u * (PL * NVEC * 16));
+                    const u32x4_t dv4 = i < KEEP ? dr[i < KEEP ? i : 0] : dq2[cc & 1][u];
+                    u32x4_t ow;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const f32x2_t xv = unpack2<TX>(xq[jj]), dv = unpack2<bf16_t>(dv4[jj]);
+                        const f32x2_t dg = silu_grad2(xv, dv, sv[jj], tv[jj], kNegLog2e);
+                        f32x2_t ov = __builtin_elementwise_fma(dg, sv[jj], __builtin_elementwise_fma(xv, npv[jj], qv[jj]));
+                        if (dadd1) ov += unpack2<bf16_t>(a1[cc & 1][u][jj]);
+                        if (dadd2) ov += unpack2<bf16_t>(a2[cc & 1][u][jj]);
+                        xs[2 * jj] += ov[0]; xs[2 * jj + 1] += ov[1];
+                        ow[jj] = pack_pair<bf16_t>(ov[0], ov[1]);
+                    }
+                    *reinterpret_cast<u32x4_t*>(dx + eoff + u * estride) = ow;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(xs[k]));    // (or the adds are sunk into the `if (dxsum)` below)
+                eoff += 2 * estride; loff += 2 * PL * NVEC * 16;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else
+#pragma unroll
+    for (int i = 0; i < ITER; ++i, eoff += estride, loff += PL * NVEC * 16) {
+        if (ITER > 8) asm volatile("" : "+v"(eoff), "+v"(loff));
         const int p = pl + PL * i;
-        if (p >= HW) continue;
-        const size_t off = base + (size_t)p * C;
-        const u32x4_t xr = *reinterpret_cast<const u32x4_t*>(xs_lds + ((size_t)p * NVEC + vec) * 16);
+        if (!kExact && p >= HW) continue;
+        const size_t off = eoff;
+        const u32x4_t xr = i >= XLDS ? xk[i >= XLDS ? i - XLDS : 0] : *reinterpret_cast<const u32x4_t*>(xs_lds + loff);
+        const u32x4_t dq2 = i < KEEP ? dr[i < KEEP ? i : 0] : *reinterpret_cast<const u32x4_t*>(dy + off);
         float o[8];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const f32x2_t xv = unpack2<TX>(xr[jj]), dv = unpack2<bf16_t>(dr[i][jj]);
+            const f32x2_t xv = unpack2<TX>(xr[jj]), dv = unpack2<bf16_t>(dq2[jj]);
             // (recomputing the sigmoid here instead of caching dy * silu'(g) costs 3-4 % of the kernel: a timing-only build without it)
             const f32x2_t dg = silu_grad2(xv, dv, sv[jj], tv[jj], kNegLog2e);
             const f32x2_t ov = __builtin_elementwise_fma(dg, sv[jj], __builtin_elementwise_fma(xv, npv[jj], qv[jj]));
@@ -882,17 +970,45 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
         if (xf16)                                                                                                                       \
             gn_silu_bwd_hybrid_kernel<f16_t, IT, TH><<<B * (C / 32), TH, lds, gmk_stream(stream)>>>(                                     \
                 (const bf16_t*)dy, (const f16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,     \
-                dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);       \
+                dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);   \
         else                                                                                                                            \
             gn_silu_bwd_hybrid_kernel<bf16_t, IT, TH><<<B * (C / 32), TH, lds, gmk_stream(stream)>>>(                                    \
                 (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,    \
-                dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);       \
+                dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);   \
     } while (0)
+        if (HW == 1024) {                            // 32x32 exactly: the pipelined form (-0.3 % of the headline step against the masked one)
+            if (xf16)
+                gn_silu_bwd_hybrid_kernel<f16_t, 8, 512, 4, 8, 0, true><<<B * (C / 32), 512, lds, gmk_stream(stream)>>>(
+                    (const bf16_t*)dy, (const f16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,
+                    dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);
+            else
+                gn_silu_bwd_hybrid_kernel<bf16_t, 8, 512, 4, 8, 0, true><<<B * (C / 32), 512, lds, gmk_stream(stream)>>>(
+                    (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,
+                    dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);
+        } else
         if (HW <= 256) GMK_GN_BWD_HYB(4, 256);       // 14x14 (-16 % against the streaming kernel), 16x16 (-10 %); at 7x7 / 8x8 the whole-sample
                                                      // streaming kernel is as fast or faster (42 vs 46 us at 8x8, B = 2048)
         else if (HW <= 832) GMK_GN_BWD_HYB(13, 256); // 28x28: 3 workgroups of 4 waves per CU
         else GMK_GN_BWD_HYB(8, 512);                 // 32x32: 2 workgroups of 8 waves (-13 % against the streaming kernel)
 #undef GMK_GN_BWD_HYB
+    } else if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 9) && C % 32 == 0 && 32 % (C / groups) == 0 && HW == 4096 && drop_p == 0.f) {
+        // 64 x 64 on 32-channel slabs (64-byte segments per pixel row instead of the 16-channel form's 32): one 512-thread workgroup
+        // per CU at 256 registers per lane - 19 / 32 of x in 152 KiB of LDS, the rest of x and 7 / 8 of dy in registers
+        gmk_note_kernel(23);
+        constexpr int kParkBytes = 19 * 128 * 64;
+        static const hipError_t attr = hipFuncSetAttribute((const void*)gn_silu_bwd_hybrid_kernel<bf16_t, 32, 512, 4, 28, 13>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kParkBytes);
+        static const hipError_t attr16 = hipFuncSetAttribute((const void*)gn_silu_bwd_hybrid_kernel<f16_t, 32, 512, 4, 28, 13>,
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, kParkBytes);
+        (void)attr; (void)attr16;
+        if (xf16)
+            gn_silu_bwd_hybrid_kernel<f16_t, 32, 512, 4, 28, 13><<<B * (C / 32), 512, kParkBytes, gmk_stream(stream)>>>(
+                (const bf16_t*)dy, (const f16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,
+                dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);
+        else
+            gn_silu_bwd_hybrid_kernel<bf16_t, 32, 512, 4, 28, 13><<<B * (C / 32), 512, kParkBytes, gmk_stream(stream)>>>(
+                (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dadd1, (const bf16_t*)dadd2, (bf16_t*)dx,
+                dgamma_part, dbeta_part, dxsum, dxsum_stride, HW, C, groups, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);
     } else if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 16 == 0 && 16 % (C / groups) == 0 && HW > 1024 &&
                HW <= 4096 && drop_p == 0.f) {
         // 64 x 64: 16-channel slabs, one workgroup of 16 waves per CU

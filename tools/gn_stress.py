@@ -16,6 +16,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     dy = torch.randn((B, H, W, C), generator=g).cuda().to(T)
     gamma = (1 + 0.1 * torch.randn(C, generator=g)).cuda(); beta = (0.1 * torch.randn(C, generator=g)).cuda()
     d1 = torch.randn((B, H, W, C), generator=g).cuda().to(T) if rng.random() < 0.5 else None
+    d2 = torch.randn((B, H, W, C), generator=g).cuda().to(T) if d1 is not None and rng.random() < 0.5 else None
     xa_full = torch.randn((B, 3 * C), generator=g).cuda()
     xadd = xa_full[:, C:2 * C] if rng.random() < 0.5 else None
     drop = (0.2, 1234, 16 * it) if rng.random() < 0.3 else None
@@ -24,12 +25,12 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         lib.gmk_set_kernel_choice(-1, -1, mode)
         y, mean, rstd = ops.gn_silu_fwd(x, gamma, beta, G, dropout=drop, xadd=xadd)
         xs = torch.empty((B, C), device="cuda")
-        dx, dgp, dbp = ops.gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=d1, dxsum=xs, dropout=drop, xadd=xadd)
+        dx, dgp, dbp = ops.gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=d1, dadd2=d2, dxsum=xs, dropout=drop, xadd=xadd)
         res[mode] = [t.float() for t in (y, mean, rstd, dx, dgp, dbp, xs)]
     errs = [float((a - b).abs().max() / (b.abs().max() + 1e-9)) for a, b in zip(res[0], res[1])]
     bad = max(errs[0], errs[3]) > 1.2e-2 or max(errs[1], errs[2]) > 1e-4 or max(errs[4:]) > 2e-3
     nfail += bad
-    print(("FAIL " if bad else "ok   ") + f"B={B} {H}x{W} G={G} dadd={d1 is not None} xadd={xadd is not None} drop={drop is not None} "
+    print(("FAIL " if bad else "ok   ") + f"B={B} {H}x{W} G={G} dadd={(d1 is not None) + (d2 is not None)} xadd={xadd is not None} drop={drop is not None} "
           f"err={[round(e, 5) for e in errs]}", flush=True)
 lib.gmk_set_kernel_choice(-1, -1, -1)
 print("failures:", nfail)
