@@ -42,7 +42,9 @@ __device__ __forceinline__ void slab_of_block(int idx, int nslab, int B, int& b,
     }
 }
 
-template <typename T>
+// NARROW: groups of 1 or 2 channels (hidden_size 32 / 64 zero-padded to the 128-channel tiles: GroupNorm(32, C) over the real channels is
+// GroupNorm(128 / cpg) over the padded ones, the all-zero groups normalise to zero): per-channel instead of per-half-vector sums.
+template <typename T, bool NARROW = false>
 __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
@@ -53,8 +55,8 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
                                                               uint64_t drop_off, const float* __restrict__ xadd,
                                                               int xadd_stride, float* __restrict__ tab_sc = nullptr,
                                                               float* __restrict__ tab_sh = nullptr, int tab_stride = 0) {
-    __shared__ float red[kThreads * 4];
-    __shared__ float smean[64], srstd[64];
+    __shared__ float red[kThreads * (NARROW ? 16 : 4)];
+    __shared__ float smean[NARROW ? 256 : 64], srstd[NARROW ? 256 : 64];
     const int tid = threadIdx.x;
     int b, slab;
     slab_of_block(blockIdx.x, C / CS, B, b, slab);
@@ -90,6 +92,38 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
             const float r = 1.0f / sqrtf(var + eps);
             smean[tid] = m; srstd[tid] = r;
             mean[b * G + tid] = m; rstd[b * G + tid] = r;
+        }
+    } else if constexpr (NARROW) {
+        float s[8], q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
+#pragma unroll 4
+        for (int p = pl; p < HW; p += planes) {
+            float v[8];
+            load8(xb + (size_t)p * C, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[i] += ea[i]; s[i] += v[i]; q[i] = fmaf(v[i], v[i], q[i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { red[tid * 16 + i] = s[i]; red[tid * 16 + 8 + i] = q[i]; }
+        __syncthreads();
+        float cs = 0.f, cq = 0.f;
+        if (tid < CS) {
+            const int vv = tid >> 3, i = tid & 7;
+            for (int p = 0; p < planes; ++p) { cs += red[(p * nvec + vv) * 16 + i]; cq += red[(p * nvec + vv) * 16 + 8 + i]; }
+        }
+        __syncthreads();
+        if (tid < CS) { red[tid] = cs; red[256 + tid] = cq; }
+        __syncthreads();
+        if (tid < gps) {
+            float ss = 0.f, qq = 0.f;
+            for (int j = 0; j < cpg; ++j) { ss += red[tid * cpg + j]; qq += red[256 + tid * cpg + j]; }
+            const float n = (float)cpg * (float)HW;
+            const float m = ss / n;
+            const float var = fmaxf(qq / n - m * m, 0.f);
+            const float r = 1.0f / sqrtf(var + eps);
+            smean[tid] = m; srstd[tid] = r;
+            mean[b * G + g0 + tid] = m; rstd[b * G + g0 + tid] = r;
         }
     } else {
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
@@ -160,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
     uint64_t drop_off, const float* __restrict__ xadd, int xadd_stride) {
     __shared__ float red[kThreads * 16];
     __shared__ float chg[256], chb[256];
-    __shared__ float sA[64], sB[64];
+    __shared__ float sA[256], sB[256];          // (up to 256 one-channel groups: the zero-padded narrow widths)
     const int tid = threadIdx.x;
     int b, slab;
     slab_of_block(blockIdx.x, C / CS, B, b, slab);
@@ -791,10 +825,12 @@ __global__ __launch_bounds__(256) void cast16_kernel(const TS* __restrict__ src,
 
 bool gn_shape_ok(int C, int G) {
     if (C <= 0 || C > 256 || (C & 7) || 256 % (C >> 3)) return false;
-    if (G <= 0 || G > 64 || C % G) return false;
+    if (G <= 0 || G > 256 || C % G) return false;
     const int cpg = C / G;
-    return cpg == 4 || cpg == 8 || cpg == 16;
+    return cpg == 1 || cpg == 2 || cpg == 4 || cpg == 8 || cpg == 16;
 }
+// groups of 1 or 2 channels: the whole-sample streaming kernels with per-channel sums only (no register-resident / hybrid / fused forms)
+static bool gn_narrow(int C, int G) { return C / G < 4; }
 
 // Channel slab width of one workgroup: GMK_GN_KERNEL / gmk_set_kernel_choice(gn) 1 = whole sample, 3 = 32 channels,
 // 4 = 64 channels, otherwise automatic.
@@ -827,6 +863,22 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
     GMK_REQUIRE(dtype != GMK_F16 || !stats_part, "gmk_gn_silu_fwd: producer statistics go with bf16 tensors only");
     // 64 x 64 (HW up to 4096): a 32-channel slab of a sample is 256 KiB - the registers of ONE 1024-thread workgroup (16 pixels x 16 B per
     // thread); single read instead of the streaming kernel's two sweeps
+    if (gn_narrow(C, groups)) {
+        GMK_REQUIRE(!stats_part, "gmk_gn_silu_fwd: producer statistics come in 4-channel units; groups of %d channels", C / groups);
+        gmk_note_kernel(22);
+        if (dtype == GMK_BF16)
+            gn_silu_fwd_kernel<bf16_t, true><<<B, kThreads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, HW, C, groups,
+                                                                                   eps, nullptr, 0, 0, C, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);
+        else if (dtype == GMK_F16)
+            gn_silu_fwd_kernel<f16_t, true><<<B, kThreads, 0, gmk_stream(stream)>>>((const f16_t*)x, (f16_t*)y, gamma, beta, mean, rstd, HW, C, groups,
+                                                                                  eps, nullptr, 0, 0, C, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);
+        else if (dtype == GMK_F32)
+            gn_silu_fwd_kernel<float, true><<<B, kThreads, 0, gmk_stream(stream)>>>((const float*)x, (float*)y, gamma, beta, mean, rstd, HW, C, groups,
+                                                                                  eps, nullptr, 0, 0, C, B, drop_p, drop_seed, drop_offset, xadd, xadd_stride);
+        else
+            GMK_REQUIRE(false, "gmk_gn_silu_fwd: bad dtype %d", dtype);
+        return gmk_check_launch("gmk_gn_silu_fwd");
+    }
     const bool big = gmk_is16(dtype) && !stats_part && (gn_mode == 8 || gn_mode == 0) && HW > 1024 && HW <= 4096 && HW % 16 == 0 &&
                      C % 32 == 0 && 32 % (C / groups) == 0;
     if (big || (gmk_is16(dtype) && !stats_part && (gn_mode == 5 || gn_mode == 6 || (gn_mode == 0 && HW > 64)) && C % 64 == 0 &&
@@ -896,6 +948,7 @@ extern "C" int gmk_gn_stats(const void* x, const float* gamma, const float* beta
     GMK_REQUIRE(tab_stride >= C, "gmk_gn_stats: tab_stride %d < C %d", tab_stride, C);
     GMK_REQUIRE(B > 0 && HW > 0 && gn_shape_ok(C, groups), "gmk_gn_stats: unsupported shape B=%d HW=%d C=%d G=%d", B, HW, C, groups);
     GMK_REQUIRE(gmk_is16(dtype), "gmk_gn_stats: 16-bit tensors only (the fused apply lives in the halo convolution)");
+    GMK_REQUIRE(!gn_narrow(C, groups), "gmk_gn_stats: groups of %d channels run the unfused GroupNorm only", C / groups);
     if (C % 64 == 0 && 32 % (C / groups) == 0 && HW > 64 && gn_reg_iter(HW, 8) > 0) {      // same choice as gmk_gn_silu_fwd: same statistics bits
         const int nvec = 8;
         const int it = gn_reg_iter(HW, nvec), planes = (HW + it - 1) / it, threads = (planes * nvec + 63) / 64 * 64;
@@ -960,7 +1013,7 @@ extern "C" int gmk_gn_silu_bwd(const void* dy, const void* x, const float* gamma
     GMK_REQUIRE(B > 0 && HW > 0 && gn_shape_ok(C, groups), "gmk_gn_silu_bwd: unsupported shape B=%d HW=%d C=%d G=%d", B,
                 HW, C, groups);
     GMK_REQUIRE(!dxsum || dxsum_stride >= C, "gmk_gn_silu_bwd: dxsum_stride %d < C %d", dxsum_stride, C);
-    const int gn_mode = gmk_kernel_choice(2, "GMK_GN_KERNEL");
+    const int gn_mode = gn_narrow(C, groups) ? 1 : gmk_kernel_choice(2, "GMK_GN_KERNEL");      // narrow groups: whole-sample streaming kernel
     if (dtype == GMK_BF16 && (gn_mode == 0 || gn_mode == 7) && C % 32 == 0 && 32 % (C / groups) == 0 && HW > (gn_mode == 7 ? 511 : 64) &&
                HW <= 1024 && drop_p == 0.f) {
         const size_t lds = (size_t)HW * 64;

@@ -14,7 +14,11 @@ checkpoints load; every arithmetic op runs in libgmk.so (include/gmk.h).  Differ
   exposes the pair to torch.autograd so `loss.backward()` style code keeps working.
 
 Extension over the reference: `in_channels` (the reference hard-codes 1, simple_unet.py:93,41).
-Restriction: `channels` is 128 or 256 (multiples of the 128-channel MFMA tile with >= 4 channels per GroupNorm group); other widths raise.
+Widths: `channels` 128 and 256 are native (multiples of the 128-channel MFMA tile).  32 and 64 run ZERO-PADDED to 128 channels: every
+parameter lives in its padded shape in the arena (the padding stays exactly zero under Adam: its gradients are exactly zero),
+GroupNorm(32, C) over the real channels becomes GroupNorm(128 / (C / 32)) over the padded ones (all-zero groups normalise to zero), and
+state_dict() / load_state_dict() / param() / grad() translate to and from the reference's shapes.  A compatibility path (3/4 or 15/16 of
+the MFMA work multiplies zeros), there so that reference checkpoints and goldens of those widths run on the HIP kernels; other widths raise.
 """
 import math
 import os
@@ -74,6 +78,29 @@ def param_inventory(C, in_channels=1, attention=False):
     return inv
 
 
+def _is_cat_dim(name, dim):
+    """True if dimension `dim` of parameter `name` runs over torch.cat([x, skip]) channels (the up blocks' first GroupNorm, conv1 and skip
+    convolution inputs): in the padded layout the two C-channel halves sit at [0, C) and [CP, CP + C)."""
+    if not name.startswith("up.seq."):
+        return False
+    return (".in_layers.0." in name and dim == 0) or (name.endswith(".in_layers.2.weight") and dim == 1) or \
+           (name.endswith(".skip_connection.weight") and dim == 1)
+
+
+def _pad_indices(name, real_shape, pad_shape, C, CP):
+    """Per-dimension index lists: position of every real index inside the padded tensor."""
+    out = []
+    for d, (r, p) in enumerate(zip(real_shape, pad_shape)):
+        if r == p:
+            out.append(None)
+        elif _is_cat_dim(name, d):
+            assert r == 2 * C and p == 2 * CP
+            out.append(torch.cat([torch.arange(C), CP + torch.arange(C)]))
+        else:
+            out.append(torch.arange(r))          # C -> CP, 2C -> 2CP (embedding width): the real entries come first
+    return out
+
+
 def _attach(root, dotted, param):
     """Register `param` under the nested attribute path `dotted`, creating container modules on the way."""
     parts = dotted.split(".")
@@ -88,10 +115,9 @@ def _attach(root, dotted, param):
 class SimpleUnet(nn.Module):
     def __init__(self, channels, dropout=0.0, in_channels=1, compute_dtype=torch.bfloat16, attention=False, act_dtype=None):
         super().__init__()
-        if channels not in (128, 256):
+        if channels not in (32, 64, 128, 256):
             raise ValueError(f"the HIP path is built for hidden_size 128 (DiffusionModel's default, every BASELINE config) and 256 (the default of "
-                             f"gms/main.py:23): the MFMA tiles are 128 output channels wide and GroupNorm(32) needs >= 4 channels per "
-                             f"group; got {channels}")
+                             f"gms/main.py:23); 32 and 64 run zero-padded to the 128-channel MFMA tiles; got {channels}")
         if attention and channels != 128:
             raise ValueError("the self-attention extension is built for 128 channels (one head over C = 128)")
         if not 0.0 <= dropout < 1.0:
@@ -107,6 +133,13 @@ class SimpleUnet(nn.Module):
             act_dtype = torch.float16 if compute_dtype == torch.bfloat16 and os.environ.get("GMK_ACT_DTYPE", "fp16") != "bf16" else compute_dtype
         if act_dtype != compute_dtype and not (compute_dtype == torch.bfloat16 and act_dtype == torch.float16):
             raise ValueError("act_dtype must equal compute_dtype, or be torch.float16 next to compute_dtype=torch.bfloat16")
+        # hidden_size: the reference's `channels`; self.channels: the width the kernels run at (narrow nets zero-padded to one 128-channel tile)
+        self.hidden_size = channels
+        self._narrow = channels < 128
+        self._g1 = max(channels, 128) // (channels // 32)              # GroupNorm(32, C) in the padded layout: 32 unless narrow
+        self._g2 = max(channels, 128) // (2 * channels // 32)          # GroupNorm(32, 2C) of the up blocks, groups per C-channel source: 16
+        self._real_inventory = param_inventory(channels, in_channels, bool(attention))
+        channels = max(channels, 128)
         self.channels, self.in_channels, self.compute_dtype, self.act_dtype = channels, in_channels, compute_dtype, act_dtype
         self.dropout = float(dropout)      # nn.Dropout(p) of every ResBlock's out_layers (simple_unet.py:171); training mode only
         self.drop_seed, self._drop_counter = 0x5EEDD0, 0
@@ -133,15 +166,20 @@ class SimpleUnet(nn.Module):
         for n, shp in self._inventory:
             _attach(self, n, nn.Parameter(flat[self._offsets[n]:self._offsets[n] + math.prod(shp)].view(shp)))
         self._shapes = shapes
+        self._real_shapes = dict(self._real_inventory)
         self._bind(flat)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_params_changed())
+        if self._narrow:
+            self._register_load_state_dict_pre_hook(self._pad_incoming_state)
 
     # ---- initialisation: torch defaults for Linear / Conv2d / GroupNorm, `out_layers.3` zeroed (simple_unet.py:172)
     def _init_values(self, flat, shapes):
+        real = dict(self._real_inventory)
         for n, shp in self._inventory:
-            view = flat[self._offsets[n]:self._offsets[n] + math.prod(shp)].view(shp)
+            padded = flat[self._offsets[n]:self._offsets[n] + math.prod(shp)].view(shp)
+            view = padded if real[n] == shp else torch.empty(real[n])      # narrow: draw in the reference's shape (its fan-in), then pad
             base, kind = n.rsplit(".", 1)
-            wshape = shapes.get(base + ".weight")
+            wshape = real.get(base + ".weight")
             if len(wshape) >= 2:                      # Linear / Conv2d: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
                 bound = 1.0 / math.sqrt(math.prod(wshape[1:]))
                 if ".out_layers.3" in n or n.startswith("attn.proj"):
@@ -150,6 +188,43 @@ class SimpleUnet(nn.Module):
                     view.uniform_(-bound, bound)
             else:                                      # GroupNorm affine
                 view.fill_(1.0 if kind == "weight" else 0.0)
+            if view is not padded:
+                padded.copy_(self._pad(n, view))
+
+    # ---- narrow widths: reference shapes <-> zero-padded arena shapes -----------------------------------------------
+    def _pad(self, name, t):
+        """Reference-shaped tensor -> its zero-padded arena shape."""
+        pshape = self._shapes[name] if hasattr(self, "_shapes") else dict(self._inventory)[name]
+        if tuple(t.shape) == tuple(pshape):
+            return t
+        idx = _pad_indices(name, tuple(t.shape), pshape, self.hidden_size, self.channels)
+        out = torch.zeros(pshape, dtype=t.dtype, device=t.device)
+        grids = [torch.arange(s, device=t.device) if ix is None else ix.to(t.device) for s, ix in zip(t.shape, idx)]
+        out[torch.meshgrid(*grids, indexing="ij")] = t
+        return out
+
+    def _unpad(self, name, t):
+        """Padded arena tensor -> a reference-shaped copy."""
+        rshape = self._real_shapes[name]
+        if tuple(t.shape) == tuple(rshape):
+            return t
+        for d, ix in enumerate(_pad_indices(name, rshape, tuple(t.shape), self.hidden_size, self.channels)):
+            if ix is not None:
+                t = t.index_select(d, ix.to(t.device))
+        return t
+
+    def _pad_incoming_state(self, state_dict, prefix, *unused):
+        for n, rshape in self._real_inventory:
+            v = state_dict.get(prefix + n)
+            if v is not None and tuple(v.shape) == tuple(rshape):
+                state_dict[prefix + n] = self._pad(n, v)
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        if self._narrow:      # the reference's shapes (copies: the padded parameters are not views of them)
+            for n, _ in self._real_inventory:
+                sd[prefix + n] = self._unpad(n, sd[prefix + n])
+        return sd
 
     # ---- flat arena management -------------------------------------------------------------------------
     def _bind(self, flat):
@@ -198,10 +273,11 @@ class SimpleUnet(nn.Module):
         return sum(p._version for p in self._plist)
 
     def param(self, name):
-        return self._pv[name]
+        """The parameter in the reference's shape (a view of the arena; a copy for the zero-padded narrow widths)."""
+        return self._unpad(name, self._pv[name]) if self._narrow else self._pv[name]
 
     def grad(self, name):
-        return self._gv[name]
+        return self._unpad(name, self._gv[name]) if self._narrow else self._gv[name]
 
     def arena_range(self, names):
         """(start, end) of the contiguous arena range spanned by `names` (used for gradient buckets)."""
@@ -323,7 +399,7 @@ class SimpleUnet(nn.Module):
     def _res_fwd(self, name, srcs, emb_all, blk, ctx):
         P, C = self._pv, self.channels
         B, H, W, _ = srcs[0].shape
-        gpc = 32 // len(srcs)                                    # GroupNorm(32, cin): 16 groups per 128-ch source
+        gpc = self._g2 if len(srcs) == 2 else self._g1           # GroupNorm(32, cin): 16 groups per C-channel source
         skip = {}
         fwd_side = len(srcs) == 2 and ops.FWD_SIDE and ops.WGRAD_STREAM
         if len(srcs) == 2:
@@ -341,7 +417,7 @@ class SimpleUnet(nn.Module):
         wf1, _ = self._packs[f"{name}.in_layers.2"]
         wf2, _ = self._packs[f"{name}.out_layers.3"]
         dropping = self.dropout > 0.0 and self.training and name != "up.seq.3.0"
-        if ctx is None and not dropping and ops.GN_FUSE and ops.conv_gn_fusable(srcs):
+        if ctx is None and not dropping and ops.GN_FUSE and not self._narrow and ops.conv_gn_fusable(srcs):
             # Inference (nothing is kept for a backward pass): GroupNorm-apply + SiLU run inside the convolutions' producer waves.
             # A statistics-only launch reads the raw tensor once and leaves the per-(sample, channel) affine tables; the normalised
             # tensors `a` / `a2` of simple_unet.py:161-163,169-172 are never written or read back (bit-identical results).
@@ -353,7 +429,7 @@ class SimpleUnet(nn.Module):
             h = self._conv(srcs, wf1, C, 3, ops.NORMAL, (H, W), gn=(tsc, tsh))
             t2c = torch.empty((B, C), device=h.device, dtype=torch.float32)
             t2h = torch.empty_like(t2c)
-            ops.gn_stats(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], 32, t2c, t2h, xadd=eadd)
+            ops.gn_stats(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], self._g1, t2c, t2h, xadd=eadd)
             if len(srcs) == 2:
                 res = skip["res"]
                 if fwd_side:
@@ -374,7 +450,7 @@ class SimpleUnet(nn.Module):
         if dropping:      # mask = Philox uniform >= p, regenerated by the backward kernel
             drop = (self.dropout, self.drop_seed, self._drop_counter)
             self._drop_counter += (h.numel() + 3) // 4
-        a2, mean2, rstd2 = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], 32, dropout=drop,
+        a2, mean2, rstd2 = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], self._g1, dropout=drop,
                                            xadd=eadd)
         if len(srcs) == 2:
             res = skip["res"]
@@ -550,7 +626,7 @@ class SimpleUnet(nn.Module):
         u4 = self._res_fwd("up.seq.4", [u3, t2], emb_all, 9, ctx)
         u5 = self._res_fwd("up.seq.5", [u4, t1], emb_all, 10, ctx)
         u6 = self._res_fwd("up.seq.6", [u5, t0], emb_all, 11, ctx)
-        ao, mo, ro = ops.gn_silu_fwd(u6, P["out.0.weight"], P["out.0.bias"], 32)
+        ao, mo, ro = ops.gn_silu_fwd(u6, P["out.0.weight"], P["out.0.bias"], self._g1)
         out = ops.head_fwd(ao, P["out.2.weight"], P["out.2.bias"])
         if ctx is not None:
             ctx["net"] = (x, t2, t5, u0r, u3r, u6, ao, mo, ro)

@@ -255,14 +255,16 @@ def _cli(args, timeout=900):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_hidden_size_256_vs_oracle_and_through_the_plugin(dtype):
+@pytest.mark.parametrize("C", [256, 64, 32])
+def test_hidden_size_256_vs_oracle_and_through_the_plugin(dtype, C):
     """`--hidden_size 256` (the default of gms/main.py:23; simple_unet.py:17 takes any width): two 128-channel output blocks per
-    convolution, 8 / 16 channels per GroupNorm group.  Forward + every gradient against the oracle (itself pinned at this width by
-    tests/golden/*_c256_*.npz), then a train step and a guided sample through the plugin surface.  Other widths raise."""
+    convolution, 8 / 16 channels per GroupNorm group; `--hidden_size 64 / 32`: zero-padded to one 128-channel tile, 2 / 1 (4 / 2 in the up
+    blocks' first GroupNorm) channels per group.  Forward + every gradient against the oracle (itself pinned at these widths by
+    tests/golden/*_c256_* / *_c64_* / *_c32_*), then a train step and a guided sample through the plugin surface.  Other widths raise."""
     from generative_models_amd import common
     from generative_models_amd.diffusion.simple_unet import SimpleUnet
     from oracle import unet_ref as U
-    C, B, S = 256, 3, 16
+    B, S = 3, 16
     params = U.reference_init_params(C, 1, seed=5, zero_out_layers=False)
     net = SimpleUnet(C, 0.0, compute_dtype=dtype); net.load_state_dict(params, strict=True); net = net.cuda()
     g = torch.Generator().manual_seed(6)
@@ -285,12 +287,12 @@ def test_hidden_size_256_vs_oracle_and_through_the_plugin(dtype):
         if err > (3 if dtype == torch.float32 else 6) * tol * max(float(v.grad.abs().max()), 1e-3 * gmax):
             bad.append((name, err))
     assert not bad, bad[:8]
-    for width in (64, 192, 512):
+    for width in (96, 192, 512):
         with pytest.raises(ValueError):
             SimpleUnet(width, 0.0)
     if dtype == torch.bfloat16:
         Model = common.discover_models()["diffusion"]
-        G = common.AttrDict(dict(Model.DG)); G.update(hidden_size=256, timesteps=4, bs=8, lr=1e-3, seed=0)
+        G = common.AttrDict(dict(Model.DG)); G.update(hidden_size=C, timesteps=4, bs=8, lr=1e-3, seed=0)
         m = Model(G).cuda(); m.train()
         x = (torch.rand((8, 1, 28, 28), generator=g) * 2 - 1).cuda(); yy = torch.randint(0, 10, (8,), generator=g).cuda()
         l0 = float(m.train_step(x, yy.clone())["loss"])
@@ -300,6 +302,10 @@ def test_hidden_size_256_vs_oracle_and_through_the_plugin(dtype):
         m.eval()
         s = m.sample(4, yy[:4])
         assert s.shape == (4, 1, 28, 28) and bool(torch.isfinite(s).all())
+        sd = m.state_dict()                                   # checkpoints carry the reference's shapes at every width
+        assert tuple(sd["net.turn.in_layers.2.weight"].shape) == (C, C, 3, 3) and tuple(sd["net.up.seq.1.in_layers.0.weight"].shape) == (2 * C,)
+        m2 = Model(G).cuda(); m2.load_state_dict(sd)
+        assert torch.equal(m2.net.flat_params, m.net.flat_params)
 
 
 def test_cli_at_config_1_flags(tmp_path):

@@ -120,7 +120,7 @@ def test_fused_groupnorm_conv_fp16_is_bit_identical(ops, lib, B, S, two):
     assert torch.equal(fused, plain)
 
 
-@pytest.mark.parametrize("C,G,S", [(128, 32, 28), (128, 16, 14), (128, 32, 7), (256, 32, 8), (128, 32, 32), (128, 16, 64), (128, 32, 16)])
+@pytest.mark.parametrize("C,G,S", [(128, 32, 28), (128, 16, 14), (128, 32, 7), (256, 32, 8), (128, 32, 32), (128, 16, 64), (128, 32, 16), (128, 64, 16)])
 def test_groupnorm_fp16_forward_and_mixed_backward(ops, C, G, S):
     """Forward fp16 -> fp16; backward with the saved input in fp16 and every gradient tensor in bf16 (register, hybrid and streaming
     kernels by size), against torch autograd on the rounded inputs."""

@@ -48,7 +48,8 @@ def rnd(*shape, seed=0, scale=1.0):
 
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("C,G,S", [(128, 32, 28), (128, 16, 14), (128, 32, 7), (256, 32, 8), (256, 16, 4), (128, 32, 32), (128, 32, 64)])
+@pytest.mark.parametrize("C,G,S", [(128, 32, 28), (128, 16, 14), (128, 32, 7), (256, 32, 8), (256, 16, 4), (128, 32, 32), (128, 32, 64),
+                                   (128, 64, 12), (128, 128, 8), (128, 64, 32)])      # the last three: 2 / 1 channels per group (narrow widths)
 def test_gn_silu_fwd_bwd(ops, dtype, C, G, S):
     B = 3
     x = q(rnd(B, C, S, S, seed=1) * 1.5 + 0.3, dtype).requires_grad_(True)

@@ -40,9 +40,11 @@ def make_net(dtype, C=128, in_channels=1, closed_form=True):
     return net.cuda(), params
 
 
-@pytest.mark.parametrize("name,C", [("unet_c128_s28.npz", 128), ("unet_c256_s8.npz", 256)])
+@pytest.mark.parametrize("name,C", [("unet_c128_s28.npz", 128), ("unet_c256_s8.npz", 256), ("unet_c64_s8.npz", 64), ("unet_c32_s8.npz", 32),
+                                    ("unet_c32_s12.npz", 32), ("unet_c32_s16.npz", 32)])
 def test_unet_forward_vs_golden(golden, name, C):
-    """Reference outputs (closed-form fill) at hidden_size 128 (DiffusionModel's default) and 256 (the default of gms/main.py:23)."""
+    """Reference outputs (closed-form fill) at hidden_size 128 (DiffusionModel's default), 256 (the default of gms/main.py:23) and the
+    narrow widths 64 / 32 (zero-padded to one 128-channel tile; GroupNorm groups of 2 / 1 channels)."""
     g = golden(name)
     net, _ = make_net(torch.float32, C=C)
     z, l, y = T(g["z"]).cuda(), T(g["logsnr"]).cuda(), T(g["guide"]).cuda()
@@ -136,7 +138,9 @@ CLOSED_FORM_SLACK = {torch.float32: 1.0, torch.bfloat16: 3.0}
 
 
 @pytest.mark.parametrize("name,C,dtype", [("train_c128_s28.npz", 128, torch.float32), ("train_c256_s8.npz", 256, torch.float32),
-                                          ("train_c128_s28.npz", 128, torch.bfloat16)])
+                                          ("train_c128_s28.npz", 128, torch.bfloat16), ("train_c64_s8.npz", 64, torch.float32),
+                                          ("train_c32_s8.npz", 32, torch.float32), ("train_c32_s16.npz", 32, torch.float32),
+                                          ("train_c64_s8.npz", 64, torch.bfloat16)])
 def test_training_step_vs_golden(golden, name, C, dtype):
     """(x0, y, u, eps) -> loss[B], gradient norms of every tensor, selected gradients, two Adam steps (row H1).  Closed-form
     fill (the bug-exposing set): exact-fp32 mode at 1e-3, and the 16-bit mode too - loss, gradient norms, the loss after each of the
@@ -269,16 +273,70 @@ def test_diffusion_model_methods():
     assert model.last_eval["samples"].dtype == torch.uint8 and model.last_eval["sampling_process"].shape[0] == 3
 
 
+@pytest.mark.parametrize("name,C,steps", [("sample_c32_s8_T4.npz", 32, 4), ("sample_c32_s12_T8.npz", 32, 8)])
+def test_sampler_chains_vs_golden_narrow(golden, name, C, steps):
+    """The reference's own sampler chains (DDIM, classifier-free guided DDIM, ancestral with recorded noise) at hidden_size 32, on the HIP
+    path in fp32 mode: every intermediate z and x prediction (5 x 1e-3: errors compound over the chain, as in test_sampler_vs_oracle)."""
+    from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    g = golden(name)
+    net, _ = make_net(torch.float32, C=C)
+    init, y = T(g["init"]).cuda(), T(g["y"]).cuda()
+    tol = 5e-3
+    ddim = GaussianDiffusion(mean_type="v", num_steps=steps, sampler="ddim", sample_cond_w=-1.0)
+    zs, xs, es = ddim.sample(net=partial(net, guide=y), init_x=init)
+    assert rel_err(zs, T(g["ddim_zs"])) < tol and rel_err(xs, T(g["ddim_xs"])) < tol and rel_err(es, T(g["ddim_eps"])) < tol
+    w = T(g["cfg_w"]).cuda()
+    zs, xs, _ = ddim.sample(net=partial(net, guide=y), init_x=init, cond_w=0.5, net_cond_w=w)
+    assert rel_err(zs, T(g["cfg_zs"])) < tol and rel_err(xs, T(g["cfg_xs"])) < tol
+    anc = GaussianDiffusion(mean_type="v", num_steps=steps, sampler="noisy", sample_cond_w=-1.0)
+    zs, xs, _ = anc.sample(net=partial(net, guide=y), init_x=init, noises=T(g["anc_noise"]).cuda())
+    assert rel_err(zs, T(g["anc_zs"])) < tol and rel_err(xs, T(g["anc_xs"])) < tol
+    assert torch.equal(zs[-1], xs[-1])
+
+
+def test_narrow_width_state_dict_and_padding():
+    """hidden_size 64: state_dict() carries the reference's keys and shapes, load_state_dict() takes them back bit for bit, and after
+    optimiser steps the zero padding of every arena tensor is still exactly zero (its gradients are exactly zero)."""
+    from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    from generative_models_amd.diffusion.optim import FusedAdam
+    from generative_models_amd.diffusion.simple_unet import SimpleUnet
+    from oracle import unet_ref as U
+    net, params = make_net(torch.bfloat16, C=64, closed_form=False)
+    assert net.hidden_size == 64 and net.channels == 128
+    sd = net.state_dict()
+    assert list(sd.keys()) == [n for n, _ in U.param_spec(64)]
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(params[k].shape) and torch.equal(v.cpu(), params[k]), k
+    ones = {k: torch.ones_like(v) for k, v in params.items()}
+    probe = SimpleUnet(64, 0.0); probe.load_state_dict(ones); mask = probe.flat_params != 0          # real entries of the arena
+    assert int(mask.sum()) == sum(v.numel() for v in params.values())
+    opt = FusedAdam(net, lr=1e-3)
+    diff = GaussianDiffusion(mean_type="v", num_steps=250)
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn((4, 1, 16, 16), generator=g).cuda(); y = torch.tensor([1, 2, 3, 4]).cuda()
+    for _ in range(3):
+        diff.train_forward_backward(net=partial(net, guide=y), x=x0, grad_scale=0.25)
+        assert float(net.flat_grads[~mask.cuda()].abs().max()) == 0.0
+        opt.step()
+    assert float(net.flat_params[~mask.cuda()].abs().max()) == 0.0
+    moved = net.state_dict()
+    assert all(tuple(moved[k].shape) == tuple(params[k].shape) for k in params)
+    assert not torch.equal(moved["down.seq.1.in_layers.2.weight"].cpu(), params["down.seq.1.in_layers.2.weight"])
+    net2 = SimpleUnet(64, 0.0); net2.load_state_dict(moved); net2 = net2.cuda()
+    assert torch.equal(net2.flat_params, net.flat_params)
+
+
 @pytest.mark.parametrize("mode", ["step1", "step2"])
-def test_distillation_vs_golden(golden, mode):
+@pytest.mark.parametrize("name,C", [("distill_c128_s8.npz", 128), ("distill_c64_s8.npz", 64)])
+def test_distillation_vs_golden(golden, mode, name, C):
     """teacher branches of the loss on the HIP path (fp32 mode) vs the reference's own numbers."""
     from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
     from generative_models_amd.diffusion.simple_unet import SimpleUnet
     from oracle import unet_ref as U
-    g = golden("distill_c128_s8.npz")
-    params = U.closed_form_params(128)
-    teacher = SimpleUnet(128, 0.0, compute_dtype=torch.float32); teacher.load_state_dict(params); teacher = teacher.cuda().eval()
-    student = SimpleUnet(128, 0.0, compute_dtype=torch.float32)
+    g = golden(name)
+    params = U.closed_form_params(C)
+    teacher = SimpleUnet(C, 0.0, compute_dtype=torch.float32); teacher.load_state_dict(params); teacher = teacher.cuda().eval()
+    student = SimpleUnet(C, 0.0, compute_dtype=torch.float32)
     student.load_state_dict({k: 0.9 * v for k, v in params.items()}); student = student.cuda()
     diff = GaussianDiffusion(mean_type="v", num_steps=8, teacher_net=teacher, teacher_mode=mode)
     x0, y = T(g["x0"]).cuda(), T(g["y"]).cuda()
