@@ -54,6 +54,7 @@ KERNEL_DESC = {
     "conv3x3_halo_kernel": "3x3 stride-1 bf16 convolution, LDS-resident halo (forward + data gradients)",
     "conv3x3_halo_ws_kernel[zero-stuffed transposed conv]": "data gradient of the stride-2 convs = the same kernel on the zero-stuffed gradient (algorithmic FLOPs are 1/4 of its MFMA work)",
     "conv_igemm_dma_kernel": "im2col LDS-DMA convolution (1x1, strided, upsampled, fp32)",
+    "conv_igemm_dma_kernel[stride-2 dgrad phases]": "data gradient of the stride-2 convs where the halo kernel declines: four output-parity phase launches of the LDS-DMA kernel (1 / 2 / 2 / 4 taps); one timed unit = the four launches",
     "conv_igemm_kernel": "im2col register-staged convolution (small problems)",
     "conv_wgrad_slots_kernel": "3x3 weight gradient over padded slots, 8 compute waves (+ slab reduce)",
     "conv_wgrad_slots_ws_kernel": "3x3 weight gradient over padded slots, wave-specialised (+ slab reduce)",

@@ -34,12 +34,22 @@ struct GatherParams {
     int ho, wo;          // output spatial size
     int ksize, pad;
     int mul, shift, mask, lim_h, lim_w;
+    // LDS-DMA kernel: tap slot t gathers source pixel (base + ty[t], base + tx[t]) against weight tap tapw[t]; ntaps slots are live.
+    // Plain convolutions: slot = tap (ty = t / 3, tx = t % 3).  The four output-parity phases of the stride-2 data gradient
+    // (make_phase_gather) list only the taps that meet a non-zero of the zero-stuffed gradient: 1, 2, 2 and 4 of the 9.
+    signed char ty[9], tx[9];
+    unsigned char tapw[9];
+    int ntaps;
+    int oscale, ooy, oox, out_w, out_hw;      // oscale = 2: row m = (b, i, j) of the phase grid is written to pixel (2 i + ooy, 2 j + oox) of out
 };
 
 __host__ bool make_gather(int mode, int ksize, int hs, int ws, int ho, int wo, GatherParams* g) {
     g->hs = hs; g->ws = ws; g->ho = ho; g->wo = wo;
     g->ksize = ksize; g->pad = ksize == 3 ? 1 : 0;
     g->mul = 1; g->shift = 0; g->mask = 0; g->lim_h = hs; g->lim_w = ws;
+    for (int t = 0; t < 9; ++t) { g->ty[t] = (signed char)(ksize == 3 ? t / 3 : 0); g->tx[t] = (signed char)(ksize == 3 ? t % 3 : 0); g->tapw[t] = (unsigned char)t; }
+    g->ntaps = ksize * ksize;
+    g->oscale = 1; g->ooy = 0; g->oox = 0; g->out_w = wo; g->out_hw = ho * wo;
     switch (mode) {
         case GMK_CONV_NORMAL:
             return ho == hs && wo == ws;
@@ -55,6 +65,25 @@ __host__ bool make_gather(int mode, int ksize, int hs, int ws, int ho, int wo, G
         default:
             return false;
     }
+}
+
+// Data gradient of the stride-2 3x3 convolution (GMK_CONV_TRANSPOSED2), output pixels of parity (a, b) only: dx[2i + a][2j + b] =
+// sum over the taps (ky, kx) of the flipped kernel with (a + ky - 1), (b + kx - 1) even of dy[i + (ky == 2)][j + (kx == 2)] . Wd[ky][kx] -
+// a 1-, 2- or 4-tap convolution ON THE GRADIENT'S OWN GRID (hs x ws) with a stride-2 scatter of its rows; the four phases together do
+// 9 / 4 tap-images of MFMA work where the zero-stuffed form does 9.
+__host__ void make_phase_gather(int a, int b, int hs, int ws, int ho, int wo, GatherParams* g) {
+    g->hs = hs; g->ws = ws; g->ho = hs; g->wo = ws;       // the phase's rows run over the gradient's grid
+    g->ksize = 3; g->pad = 0; g->mul = 1; g->shift = 0; g->mask = 0; g->lim_h = hs; g->lim_w = ws;
+    int n = 0;
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+            if (((a + ky - 1) & 1) || ((b + kx - 1) & 1)) continue;
+            g->ty[n] = (signed char)(ky == 2); g->tx[n] = (signed char)(kx == 2); g->tapw[n] = (unsigned char)(ky * 3 + kx);
+            ++n;
+        }
+    g->ntaps = n;
+    for (int t = n; t < 9; ++t) { g->ty[t] = 0; g->tx[t] = 0; g->tapw[t] = 0; }
+    g->oscale = 2; g->ooy = a; g->oox = b; g->out_w = wo; g->out_hw = ho * wo;
 }
 
 struct ConvParams {
@@ -323,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
             const int by = oy * g.mul - g.pad, bx = (rem - oy * g.wo) * g.mul - g.pad;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int ty = by + t / 3, tx = bx + t % 3;
+                const int ty = by + g.ty[t], tx = bx + g.tx[t];
                 const bool ok = live && ty >= 0 && ty < g.lim_h && tx >= 0 && tx < g.lim_w && !((ty | tx) & g.mask);
                 pixi[i][t] = ok ? (unsigned)((b * g.hs + (ty >> g.shift)) * g.ws + (tx >> g.shift)) : kBadPix;
             }
@@ -341,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
 
     const int kpt = p.ktot / KCH;            // K chunks per tap (>= 2)
-    const int ntaps = g.ksize * g.ksize;     // 1 or 9 (a 1x1 conv uses tap slot 0: pad 0, offsets (0,0))
+    const int ntaps = g.ntaps;               // 1 or 9 (a 1x1 conv uses tap slot 0: pad 0, offsets (0,0)); 1 / 2 / 4 for a stride-2 dgrad phase
 
     // DMA of K-step (tap, kc) into ring slot `stage`; `tap` is a compile-time constant at every call site
     auto issue = [&](int stage, const unsigned (&pix)[4], int tap, int kc, unsigned wblock = 0u) {
@@ -362,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
                                                          __umul24(pix[i], cs_b) + koff_b + a_ch[i], 0, 0, 0);
         }
         GMK_LDS char* lds_b = (GMK_LDS char*)(smem + stage * STAGE + A_BYTES + wave * 2048);
-        const unsigned wk = ((unsigned)tap * (unsigned)p.w_tap_stride + (unsigned)kelem) * ES + wblock;
+        const unsigned wk = ((unsigned)g.tapw[tap] * (unsigned)p.w_tap_stride + (unsigned)kelem) * ES + wblock;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(lds_b + i * 1024), 16, w_off[i] + wk, 0, 0, 0);
@@ -423,7 +452,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
         for (int i = 0; i < 2; ++i) {
             const int m = tile * 256 + wm * 64 + i * 32 + r;
             const bool live = m < p.M;
-            const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
+            int orow = m;
+            if (g.oscale == 2) {       // stride-2 scatter of a data-gradient phase
+                const int mm = live ? m : 0;
+                const int b = mm / hw_o, rem = mm - b * hw_o, oy = rem / g.wo, ox = rem - oy * g.wo;
+                orow = b * g.out_hw + (2 * oy + g.ooy) * g.out_w + 2 * ox + g.oox;
+            }
+            const unsigned row_b = (unsigned)orow * (unsigned)p.out_cstride * ES;
             const float* embp = p.emb ? p.emb + (int64_t)((live ? m : 0) / hw_o) * p.emb_stride : nullptr;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -942,6 +977,11 @@ static int conv_igemm_impl(const void* src0, const void* src1, int c0, int c1, i
     p.out_cstride = out_cstride; p.M = B * ho * wo;
     // kernel choice: 0 = automatic, 1 = register-staged 128x128, 2 = LDS-DMA im2col 256x128, 3 = LDS halo (3x3 s1 bf16)
     const int force = gmk_kernel_choice(0, "GMK_CONV_KERNEL");
+    const int es = gmk_esize(dtype);
+    // kBadOff and (kBadPix * bytes-per-pixel) mod 2^32 (>= 0xFFFFF000 for pixels of up to 4 KiB) must lie beyond every buffer
+    const int64_t lim = 0xFFFF0000ll;
+    const int64_t nb0 = (int64_t)B * hs * ws * c0 * es, nb1 = (int64_t)B * hs * ws * c1 * es;
+    const int64_t nbw = (int64_t)ksize * ksize * w_rows * (c0 + c1) * es;
     // the transposed form (data gradient of the stride-2 conv) is the plain 3x3 conv of the zero-stuffed gradient: on the halo
     // kernel 3/4 of the resident pixels are zeros, but it still beats the im2col gather by 1.7x (215 vs 360 us at 28x28)
     const bool stuffed = mode == GMK_CONV_TRANSPOSED2 && !((ho | wo) & 1);
@@ -954,15 +994,35 @@ static int conv_igemm_impl(const void* src0, const void* src1, int c0, int c1, i
             return gmk_check_launch("gmk_conv_igemm(halo)");
         }
     }
+    // Where the halo kernel does not take the transposed form (fp32, fewer than 32 tiles, GMK_CONV_KERNEL=2): four output-parity phases on
+    // the LDS-DMA kernel, each a 1- / 2- / 2- / 4-tap convolution over the gradient's own grid with a stride-2 scatter of its rows
+    // (make_phase_gather): 9 / 4 tap-images of MFMA work where the masked im2col gather does 9.  At the train step's sizes the zero-stuffed
+    // halo form stays in front (536 vs 565 us at 16x16 -> 32x32, B = 2048, with the residual: each phase launch walks every DRAM page
+    // of the output and of the residual for a quarter of their bytes; without a residual the phases win, 393 vs 462 us; tools/tconv_ab.py).
+    if (stuffed && force != 1 && !out2 && !gn_scale && !gn_stats) {
+        const int64_t nbo = (int64_t)B * ho * wo * out_cstride * es;
+        if (nb0 < lim && nb1 < lim && nbw < lim && nbo < lim && (int64_t)B * hs * ws < 0x00FFFFFF && (int64_t)c0 * es <= 4096 &&
+            (int64_t)c1 * es <= 4096) {
+            gmk_note_kernel(6);
+            const int ncu = gmk_cu_limit();
+            for (int ph = 0; ph < 4; ++ph) {
+                ConvParams q = p;
+                make_phase_gather(ph >> 1, ph & 1, hs, ws, ho, wo, &q.g);
+                q.M = B * hs * ws;
+                q.nb0 = (unsigned)nb0; q.nb1 = (unsigned)nb1; q.nbw = (unsigned)nbw; q.nbo = (unsigned)nbo;
+                const int ntiles = (q.M + 255) / 256;
+                dim3 grid(ntiles < ncu ? ntiles : ncu, cout / kBN);
+                if (dtype == GMK_BF16) conv_igemm_dma_kernel<bf16_t><<<grid, 512, 0, gmk_stream(stream)>>>(q);
+                else if (dtype == GMK_F16) conv_igemm_dma_kernel<f16_t><<<grid, 512, 0, gmk_stream(stream)>>>(q);
+                else conv_igemm_dma_kernel<float><<<grid, 512, 0, gmk_stream(stream)>>>(q);
+            }
+            return gmk_check_launch("gmk_conv_igemm(stride-2 dgrad phases)");
+        }
+    }
     GMK_REQUIRE(!gn_scale, "gmk_conv_igemm: the fused GroupNorm-apply needs the 3x3 halo kernel (bf16, plain 3x3, a tile within two samples, "
                            ">= 32 tiles): ask gmk_conv_gn_fusable first");
-    const int es = gmk_esize(dtype);
-    const int64_t nb0 = (int64_t)B * hs * ws * c0 * es, nb1 = (int64_t)B * hs * ws * c1 * es;
-    const int64_t nbw = (int64_t)ksize * ksize * w_rows * (c0 + c1) * es;
     // LDS-DMA kernel: problems with at least ~2 tiles of 256 pixels per CU, buffers addressable with 32-bit offsets
     const int64_t nbo = (int64_t)p.M * out_cstride * es;
-    // kBadOff and (kBadPix * bytes-per-pixel) mod 2^32 (>= 0xFFFFF000 for pixels of up to 4 KiB) must lie beyond every buffer
-    const int64_t lim = 0xFFFF0000ll;
     const bool fits = nb0 < lim && nb1 < lim && nbw < lim && nbo < lim && (int64_t)B * hs * ws < 0x00FFFFFF &&
                       (int64_t)c0 * es <= 4096 && (int64_t)c1 * es <= 4096;
     const bool dma = fits && (force == 2 || (force != 1 && p.M >= 256 * 512));

@@ -27,6 +27,8 @@ KERNEL_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_dma_kernel", 3: "conv3x3_
                 # same binary as 4, launched on the zero-stuffed gradient of a stride-2 conv: 4x the algorithmic MFMA work by
                 # construction, so the profile keeps it apart from the plain 3x3 convolutions
                 5: "conv3x3_halo_ws_kernel[zero-stuffed transposed conv]",
+                # stride-2 data gradient where the halo kernel declines (fp32, small problems): four output-parity phase launches of the LDS-DMA kernel
+                6: "conv_igemm_dma_kernel[stride-2 dgrad phases]",
                 21: "gn_silu_fwd_reg_kernel", 22: "gn_silu_fwd_kernel", 23: "gn_silu_bwd_hybrid_kernel", 24: "gn_silu_bwd_kernel"}
 
 

@@ -333,7 +333,7 @@ def test_forced_kernel_variants_agree_with_torch(ops, two, S, B, mode):
 
 @pytest.mark.parametrize("S,B", [(28, 3), (14, 5), (32, 2), (64, 1), (8, 37)])
 def test_transposed_dgrad_on_halo_kernels(ops, S, B):
-    """Data gradient of the stride-2 conv: at full size it runs on the halo kernels as a 3x3 conv of the zero-stuffed gradient
+    """Data gradient of the stride-2 conv, the older form (GMK_CONV_KERNEL=3): on the halo kernels as a 3x3 conv of the zero-stuffed gradient
     (kernel id 5).  Force that path on small problems (tiles spanning several images at 8x8 / 14x14) and compare with autograd
     and with the im2col gather it replaces."""
     from generative_models_amd._lib import lib
@@ -360,6 +360,43 @@ def test_transposed_dgrad_on_halo_kernels(ops, S, B):
     finally:
         lib.gmk_set_kernel_choice(-1, -1, -1)
         lib.gmk_set_dev_variant(0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S,B,res", [(28, 3, True), (14, 5, False), (32, 2, True), (64, 1, False), (8, 37, True), (4, 3, False), (16, 70, True)])
+def test_transposed_dgrad_as_four_phases(ops, dtype, S, B, res):
+    """Data gradient of the stride-2 conv as four output-parity phases on the LDS-DMA kernel (kernel id 6: the path of fp32 tensors and of
+    problems the halo kernel declines; GMK_CONV_KERNEL=2 elsewhere) - 1 / 2 / 2 / 4 taps over the gradient's own grid, rows scattered with
+    stride 2 - with and without the residual the net adds there (the skip path's gradient).  Against autograd, against the zero-stuffed
+    halo form (same products, other summation order), in fp32 and bf16."""
+    from generative_models_amd._lib import lib
+    C = 128
+    x = q(rnd(B, C, S, S, seed=150), dtype).requires_grad_(True)
+    w = q(rnd(C, C, 3, 3, seed=151) / math.sqrt(C * 9), dtype).requires_grad_(True)
+    out_ref = F.conv2d(x, w, None, stride=2, padding=1)
+    dy = q(rnd(*out_ref.shape, seed=152), dtype)
+    out_ref.backward(dy)
+    r = q(rnd(B, C, S, S, seed=153), dtype) if res else None
+    wf = torch.empty(w.numel(), device="cuda", dtype=dtype); wd = torch.empty_like(wf)
+    ops.pack_conv_weight(w.detach().cuda(), wf, wd)
+    dyd = nhwc(dy, dtype)
+    rd = nhwc(r, dtype) if res else None
+    ref = x.grad + (r if res else 0)
+    dx0 = ops.conv_igemm([dyd], wd, C, 3, ops.TRANSPOSED2, (S, S), residual=rd)       # automatic choice
+    assert lib.gmk_last_kernel() == 6 if dtype == torch.float32 else lib.gmk_last_kernel() in (5, 6)
+    assert rel_err(nchw(dx0), ref) < TOL[dtype]
+    try:
+        lib.gmk_set_kernel_choice(2, -1, -1)
+        dx = ops.conv_igemm([dyd], wd, C, 3, ops.TRANSPOSED2, (S, S), residual=rd)
+        assert lib.gmk_last_kernel() == 6
+        assert rel_err(nchw(dx), ref) < TOL[dtype]
+        if dtype == torch.bfloat16 and S >= 8:
+            lib.gmk_set_kernel_choice(3, -1, -1)
+            dx_h = ops.conv_igemm([dyd], wd, C, 3, ops.TRANSPOSED2, (S, S), residual=rd)
+            assert lib.gmk_last_kernel() == 5
+            assert rel_err(nchw(dx), nchw(dx_h).cpu()) < 8e-3
+    finally:
+        lib.gmk_set_kernel_choice(-1, -1, -1)
 
 
 @pytest.mark.parametrize("S,B,two,mode", [(14, 400, False, 0), (28, 90, False, 0), (14, 330, True, 0), (16, 300, False, 2), (28, 100, False, 3)])
