@@ -717,9 +717,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         }
         const __amdgpu_buffer_rsrc_t rsr =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
-        unsigned pf0 = 0, pf1 = 0;
+        // Residual hand-over (whole jobs with a residual): the consumers have no registers to keep the residual tile's loads in flight under
+        // the K loop (253 - 255 VGPRs), the producers have ~ 200 idle ones.  During taps 0..6 of a job's LAST phase each producer lane loads
+        // 2 x 16 bytes per step of the tile's residual (14 loads: 7 / 8 of the 64-KiB tile; the counted waits below include them), all landed
+        // at the top of tap 8.  After that step (barrier A: the consumers are done with the phase's halo buffer) the producers write
+        // them into that buffer as R[unit 0..6][pixel 0..255][32 B] (unit = 16 channels; 7 x 8 KiB = the 56 KiB of a half-buffer), barrier
+        // B, and the consumers' epilogue reads its residual from LDS (conflict-free: 64 lanes = 1 KiB contiguous) - only unit 7 still comes
+        // from memory, issued ahead of everything else.  Replaces the L2 warm-up loads of round 2.
+        const bool hand = kPrefetchW && p.residual != nullptr && p.variant != 7;      // (GMK_DEV_VARIANT=7: the A/B switch)
+        u32x4 rr[14];
+        unsigned roff[2] = {kBadOff, kBadOff};
+        auto resolve_res = [&](int tl) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ml = pw * 64 + u * 32 + (lane >> 1);
+                const int m = tl * p.TP + ml;
+                roff[u] = (ml < p.TP && m < p.M) ? (unsigned)m * (unsigned)p.out_cstride * ES + (unsigned)nblk * ES + (unsigned)(lane & 1) * 16u : kBadOff;
+            }
+        };
         int sq = 2, hbuf = 0;
         int tile = job_tile(0), ch = job_half(0);
+        if (hand) resolve_res(tile);
 #pragma unroll
         for (int j = 0; j < 7; ++j) { resolve_piece(tile, j); issue_fill(0, 0, j); }
         issue_w(0, 0, 0, ch);
@@ -737,16 +755,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     // at barrier q the weight tile of step q+1 (the first 4 ops of step q-1) must have landed — the consumers read its
                     // first fragments before barrier q+1; only the 2 halo pieces issued behind it may still fly.  Tap 0 also needs
                     // the phase's whole halo (all older).
-                    const bool warmed = last_ph && p.residual != nullptr;     // tap 7 carried 2 extra (L2 warm-up) loads
+                    const bool handing = last_ph && hand && ch < 0;     // taps 0..6 carry 2 residual loads each, behind the halo pieces
                     if (kPrefetchW) {
-                        if (tap == 0 || (tap == 8 && !warmed)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (tap == 0 || tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tap 8: every residual load has landed too
+                        else if (handing) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                     } else {      // only the weight tile of THIS step (issued two steps ago) has to be there
                         if (tap == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                        else if (tap == 1 || (tap == 8 && !warmed)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                        else if (tap == 1 || tap == 8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     }
-                    if (tap == 0) asm volatile("" :: "v"(pf0), "v"(pf1));         // the warm-up loads' registers stay reserved until here
                     __builtin_amdgcn_s_barrier();
                     if (tap < 7) issue_w(sq, tap + 2, ph, ch);
                     else issue_w(sq, tap - 7, ph_next, last_ph ? nch : ch);      // the first two weight tiles of the next job
@@ -754,20 +772,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         if (last_ph) resolve_piece(ntile, tap);                  // the next fills belong to the next job's tile (or are zeros)
                         issue_fill(hbuf ^ 1, ph_next, tap);
                     }
-                    if (tap == 7 && warmed) {
-                        // pull the residual tile (TP pixels x 256 B, one dword per 128-B line) into L2 two K-steps before the
-                        // consumers' epilogue reads it: their loads then see an L2 hit instead of an HBM miss per pixel block
-                        const int ml = pw * 64 + lane;
-                        const int m = tile * p.TP + ml;
-                        const unsigned off = (ml < p.TP && m < p.M) ? (unsigned)m * (unsigned)p.out_cstride * ES + (unsigned)nblk * ES : kBadOff;
-                        pf0 = __builtin_amdgcn_raw_buffer_load_b32(rsr, off, 0, 0);
-                        pf1 = __builtin_amdgcn_raw_buffer_load_b32(rsr, off + 128u, 0, 0);
+                    if (tap < 7 && handing) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)      // unit `tap` (32 bytes per pixel: the scalar offset), pixels pw * 64 + u * 32 + lane / 2
+                            rr[2 * tap + u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, roff[u], tap * 32, 0));
+                    }
+                    if (tap == 8 && handing) {
+                        __builtin_amdgcn_s_barrier();                              // A: the consumers have read this phase's halo for the last time
+                        GMK_LDS char* dst = (GMK_LDS char*)(smem + hbuf * kHB + pw * 2048 + lane * 16);
+#pragma unroll
+                        for (int t = 0; t < 7; ++t)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) *reinterpret_cast<GMK_LDS u32x4*>(dst + t * 8192 + u * 1024) = rr[2 * t + u];
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();                              // B: the residual tile is in LDS
                     }
                     sq = sq == 2 ? 0 : sq + 1;
                 }
                 hbuf ^= 1;
             }
             tile = ntile; ch = nch;
+            if (hand && ch < 0 && tile < p.ntiles) resolve_res(tile);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the speculative DMA before the LDS is released
         return;
@@ -907,6 +932,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             phase(IntTag<1>{}, 0);
             for (int ph = 1; ph < nph; ++ph) phase(IntTag<0>{}, ph);
             asm volatile("" ::: "memory");
+            // residual hand-over (see the producers): units 0..6 of the tile's residual arrive in the halo buffer this job's last phase
+            // just finished with; unit 7 (channels 112..127) is loaded from memory here, ahead of the two barriers that hide its latency
+            constexpr bool kHandJob = kPrefetchW && !kFuse && NCB == 8;
+            const bool hand = kHandJob && p.residual != nullptr && p.variant != 7;
+            u32x4 r7[2];
+            const char* Rl = smem + (hbuf ^ 1) * kHB;
+            if (hand) {
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip) {
+                    const int ml = pxbase + (2 * ip + (q & 1)) * 16 + r16;
+                    const int m = tile * p.TP + ml;
+                    const unsigned off = (ml < p.TP && m < p.M) ? (unsigned)m * (unsigned)p.out_cstride * ES + (unsigned)(nblk + (q >> 1) * 8 + 7 * 16) * ES : kBadOff;
+                    r7[ip] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, off, 0, 0));
+                }
+                __builtin_amdgcn_s_barrier();            // A
+                __builtin_amdgcn_s_barrier();            // B
+            }
             // ---- epilogue: lane (r16, q) holds channels 16 cb + 4 q .. + 3 of pixel 16 i + r16.  One v_permlane16_swap per dword between
             // the packed values of pixel blocks (i, i + 1) leaves every lane with 8 consecutive channels (16 bytes) of ONE pixel: even
             // rows (q = 0, 2) pixel block i, odd rows pixel block i + 1, channel offset 8 (q >> 1).  Loads (bias once per tile, residual as
@@ -929,7 +971,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     (void)ml0; (void)ml1;
                 }
                 u32x4 rres[NCB];
-                if (p.residual) {
+                if (hand) {
+#pragma unroll
+                    for (int cb = 0; cb < NCB - 1; ++cb)
+                        rres[cb] = *reinterpret_cast<const u32x4*>(Rl + cb * 8192 + ml * 32 + (q >> 1) * 16);
+                    rres[NCB - 1] = r7[ip];
+                } else if (p.residual) {
 #pragma unroll
                     for (int cb = 0; cb < NCB; ++cb)
                         rres[cb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, live ? row_b + (unsigned)(cb * 16) * ES : kBadOff, 0, 0));
@@ -1102,6 +1149,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 for (int i = 0; i < NI; ++i)
                     acc[j][i] = mfma_32x32x16<T>(wt[set][j], px[set][i], kFresh ? z : acc[j][i]);
         };
+        // residual hand-over (see the producers): set before the epilogue runs
+        constexpr bool kHandJob = kPrefetchW && !kFuse && NI == 4;
+        const bool hand = kHandJob && p.residual != nullptr && p.variant != 7;
+        u32x4 r7[4];
+        const char* Rl = smem;
         auto epilogue = [&]() {
             // every global load of the epilogue is issued up front, in as few and as wide instructions as possible: the bias once
             // per tile (not once per accumulator), the residual as 16-B loads at the addresses the stores use (the lane layout after
@@ -1121,6 +1173,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             u32x4 rres[2][2][2];            // residual of pixel block i (set i & 1), loaded one block ahead
             auto load_res = [&](int i) {
                 const int ml = pxbase + i * 32 + r;
+                if (hand) {                 // from the producers' hand-over: unit = 16 channels, R[unit][pixel][32 B]; unit 7 was loaded ahead
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int qq = 0; qq < 2; ++qq) {
+                            if (j == 1 && qq == 1 && cwe == 1) rres[i & 1][j][qq] = r7[i];
+                            else rres[i & 1][j][qq] = *reinterpret_cast<const u32x4*>(Rl + (cwe * 4 + j * 2 + qq) * 8192 + ml * 32 + h * 16);
+                        }
+                    return;
+                }
                 const int m = tile * p.TP + ml;
                 const bool live = ml < p.TP && m < p.M;
                 const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES;
@@ -1234,6 +1296,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         phase(IntTag<1>{}, 0);
         for (int ph = 1; ph < nph; ++ph) phase(IntTag<0>{}, ph);
         asm volatile("" ::: "memory");
+        if (hand) {
+            // units 0..6 of the tile's residual arrive in the halo buffer the last phase just finished with; unit 7 (channels 112..127: this
+            // wave's j = 1, qq = 1 if it owns channel half 1) is loaded here, ahead of the two barriers that hide its latency
+            Rl = smem + (hbuf ^ 1) * kHB;
+            if (cwe == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ml = pxbase + i * 32 + r;
+                    const int m = tile * p.TP + ml;
+                    const unsigned off = (ml < p.TP && m < p.M) ? (unsigned)m * (unsigned)p.out_cstride * ES + (unsigned)(nblk + 112 + 8 * h) * ES : kBadOff;
+                    r7[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, off, 0, 0));
+                }
+            }
+            __builtin_amdgcn_s_barrier();            // A
+            __builtin_amdgcn_s_barrier();            // B
+        }
         // the epilogue is bound by store issue: it also re-zeroes the accumulators (and the caller resolves the next tile's pixel
         // rows) in that shadow, so the next tile starts on its first barrier
         epilogue();
@@ -1326,7 +1404,7 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
         // not for variant 4 (its vmcnt waits count 4 weight DMAs per step); variant 6 is the A/B switch
         if (ntiles > G && rem > 0 && 2 * rem <= G && p.variant != 4 && p.variant != 6) { p.nfull = (int)ntiles - rem; p.nhalf = 2 * rem; }
     }
-    const bool use16 = p.variant != 32 && (p.variant == 16 || (p.variant == 0 && (p.ktot >= 256 || W >= 32 || W <= 16)));
+    const bool use16 = p.variant != 32 && (p.variant == 16 || ((p.variant == 0 || p.variant == 7) && (p.ktot >= 256 || W >= 32 || W <= 16)));
     // MFMA shape of the consumers: bit-identical results either way; v_mfma_f32_16x16x32 measured +2 ... +4 % at K = 2304, at
     // 64- / 32- / 14-pixel rows, and -2 % at 28 x 28 with K = 1152 (tools/halo_ab.py).  GMK_DEV_VARIANT 16 / 32 force one form.
     // kind: 0 the 8-compute-wave kernel (variants 1, 3, or statistics wanted), 1 fused GroupNorm-apply + SiLU in the producer waves
