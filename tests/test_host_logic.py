@@ -112,7 +112,20 @@ def test_param_inventory_and_arena():
     net.load_state_dict(sd)
     assert float(net.flat_params[net._offsets["turn.in_layers.2.weight"]]) == 0.5 and net._packs_stale
     with pytest.raises(ValueError):
-        SimpleUnet(32)
+        SimpleUnet(96)
+    # narrow widths live zero-padded in a 128-channel arena and speak the reference's shapes at the state-dict boundary
+    from oracle import unet_ref as U
+    for width in (32, 64):
+        narrow = SimpleUnet(width)
+        assert narrow.hidden_size == width and narrow.channels == 128 and narrow.flat_params.numel() == net.flat_params.numel()
+        spec = U.param_spec(width)
+        sdn = narrow.state_dict()
+        assert [(k, tuple(v.shape)) for k, v in sdn.items()] == [(k, tuple(s)) for k, s in spec]
+        filled = {k: torch.full_like(v, 0.25) for k, v in sdn.items()}
+        narrow.load_state_dict(filled)
+        assert int((narrow.flat_params == 0.25).sum()) == sum(int(np.prod(s)) for _, s in spec)       # everything else is padding: zeros
+        assert int((narrow.flat_params != 0).sum()) == int((narrow.flat_params == 0.25).sum())
+        assert all(torch.equal(v, filled[k]) for k, v in narrow.state_dict().items())
     net3 = SimpleUnet(128, in_channels=3)
     assert sum(p.numel() for p in net3.parameters()) == 6038275
 
