@@ -452,9 +452,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
     // The host sets nhalf = 2 x (ntiles mod G) when that remainder fits (<= G/2): the last, partly filled round of whole tiles
     // (0.45 of a round at 28x28, 0.11 at 14x14 for B = 1024) then costs about half a tile time on all CUs instead of a whole one.
     const int G = gridDim.x, g = blockIdx.x;
-    const int nk_full = (p.nfull - g + G - 1) / G;
+    // XCD-aware order of the whole tiles: workgroup ids round-robin over the 8 XCDs (each with its own L2), neighbouring tiles share two
+    // halo rows (a quarter of a tile's input at 8 rows per tile), so the tiles of a round are dealt out in 8 contiguous runs, one per XCD:
+    // the shared rows are fetched from HBM once per XCD run instead of once per tile
+    const int pg = (G & 7) == 0 && p.variant != 9 ? (g & 7) * (G >> 3) + (g >> 3) : g;
+    const int nk_full = (p.nfull - pg + G - 1) / G;
     const int njobs = nk_full + (g < p.nhalf ? 1 : 0);
-    auto job_tile = [&](int k) { return k < nk_full ? g + k * G : (k < njobs ? p.nfull + (g >> 1) : p.ntiles); };
+    auto job_tile = [&](int k) { return k < nk_full ? pg + k * G : (k < njobs ? p.nfull + (g >> 1) : p.ntiles); };
     auto job_half = [&](int k) { return k >= nk_full && k < njobs ? (g & 1) : -1; };
 
     if (wave >= 4) {
@@ -1404,7 +1408,7 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
         // not for variant 4 (its vmcnt waits count 4 weight DMAs per step); variant 6 is the A/B switch
         if (ntiles > G && rem > 0 && 2 * rem <= G && p.variant != 4 && p.variant != 6) { p.nfull = (int)ntiles - rem; p.nhalf = 2 * rem; }
     }
-    const bool use16 = p.variant != 32 && (p.variant == 16 || ((p.variant == 0 || p.variant == 7) && (p.ktot >= 256 || W >= 32 || W <= 16)));
+    const bool use16 = p.variant != 32 && (p.variant == 16 || ((p.variant == 0 || p.variant == 7 || p.variant == 9) && (p.ktot >= 256 || W >= 32 || W <= 16)));
     // MFMA shape of the consumers: bit-identical results either way; v_mfma_f32_16x16x32 measured +2 ... +4 % at K = 2304, at
     // 64- / 32- / 14-pixel rows, and -2 % at 28 x 28 with K = 1152 (tools/halo_ab.py).  GMK_DEV_VARIANT 16 / 32 force one form.
     // kind: 0 the 8-compute-wave kernel (variants 1, 3, or statistics wanted), 1 fused GroupNorm-apply + SiLU in the producer waves

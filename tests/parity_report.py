@@ -80,6 +80,25 @@ def main():
                   " ".join(f"{k} max {v[0]:.2e}" for k, v in eg.items()), flush=True)
 
 
+def widths():
+    """Reference outputs at the other widths (closed-form fill, tests/golden/unet_c*_*.npz): 256 native, 64 / 32 zero-padded to 128 channels."""
+    T = torch.from_numpy
+    for name, C in (("unet_c256_s8.npz", 256), ("unet_c64_s8.npz", 64), ("unet_c32_s16.npz", 32)):
+        g = np.load(os.path.join(GOLD, name), allow_pickle=True)
+        params = U.closed_form_params(C)
+        row = []
+        for dtype, act in MODES:
+            net = SimpleUnet(C, 0.0, compute_dtype=dtype, act_dtype=act)
+            net.load_state_dict(params, strict=True)
+            net = net.cuda()
+            z, l, y = T(g["z"]).cuda(), T(g["logsnr"]).cuda(), T(g["guide"]).cuda()
+            with torch.no_grad():
+                e = errs(net(z, l, guide=y), T(g["v"]))
+            row.append(f"{mode_name(dtype, act)}: max {e[0]:.2e} L2 {e[1]:.2e}")
+        print(f"{name} (hidden_size {C}, closed-form fill) vs the reference | " + " | ".join(row), flush=True)
+
+
 if __name__ == "__main__":
     main()
     ragged()
+    widths()
