@@ -123,7 +123,10 @@ def args_type(default):
 
 
 def count_vars(module):
-    return sum(int(np.prod(p.shape)) for p in module.parameters())
+    """Parameter count as the reference reports it (gms/common.py:95-96); zero padding a module keeps around its parameters (the narrow
+    U-Net widths, `padding_numel`) is not counted."""
+    total = sum(int(np.prod(p.shape)) for p in module.parameters())
+    return total - sum(int(getattr(m, "padding_numel", 0)) for m in module.modules())
 
 
 class NullWriter:

@@ -167,6 +167,7 @@ class SimpleUnet(nn.Module):
             _attach(self, n, nn.Parameter(flat[self._offsets[n]:self._offsets[n] + math.prod(shp)].view(shp)))
         self._shapes = shapes
         self._real_shapes = dict(self._real_inventory)
+        self.padding_numel = sum(math.prod(s) for _, s in self._inventory) - sum(math.prod(s) for _, s in self._real_inventory)
         self._bind(flat)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_params_changed())
         if self._narrow:

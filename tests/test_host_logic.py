@@ -126,6 +126,8 @@ def test_param_inventory_and_arena():
         assert int((narrow.flat_params == 0.25).sum()) == sum(int(np.prod(s)) for _, s in spec)       # everything else is padding: zeros
         assert int((narrow.flat_params != 0).sum()) == int((narrow.flat_params == 0.25).sum())
         assert all(torch.equal(v, filled[k]) for k, v in narrow.state_dict().items())
+        from generative_models_amd import common
+        assert common.count_vars(narrow) == sum(int(np.prod(s)) for _, s in spec) == {32: 387137, 64: 1521793}[width]
     net3 = SimpleUnet(128, in_channels=3)
     assert sum(p.numel() for p in net3.parameters()) == 6038275
 
