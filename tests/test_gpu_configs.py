@@ -63,7 +63,7 @@ def test_whole_net_at_config_shapes(dtype, S, B, attention):
              "guide_embed.2.bias", "down.seq.2.in_layers.2.bias"]
     if attention:
         names += ["attn.qkv.weight", "attn.proj.weight", "attn.norm.bias"]
-    bad = [(n, rel_err(net.grad(n), p[n].grad)) for n in names if rel_err(net.grad(n), p[n].grad) >= 6 * tol]
+    bad = [(n, rel_err(net.grad(n), p[n].grad)) for n in names if rel_err(net.grad(n), p[n].grad) >= (1 if dtype == torch.float32 else 3 if attention else 2) * tol]      # (rounds 1-2: 6x)
     assert not bad, bad
 
 
@@ -284,7 +284,9 @@ def test_hidden_size_256_vs_oracle_and_through_the_plugin(dtype, C):
         if v.grad is None:
             continue
         err = float((net.grad(name).cpu() - v.grad).abs().max())
-        if err > (3 if dtype == torch.float32 else 6) * tol * max(float(v.grad.abs().max()), 1e-3 * gmax):
+        # fp32 at the bar of the outputs; 16-bit mode 2x at the native width, 4x for the zero-padded narrow nets (their gradients are small
+        # against the floor 1e-3 x the largest gradient entry of the net)
+        if err > (1 if dtype == torch.float32 else 2 if C >= 128 else 4) * tol * max(float(v.grad.abs().max()), 1e-3 * gmax):
             bad.append((name, err))
     assert not bad, bad[:8]
     for width in (96, 192, 512):

@@ -78,11 +78,12 @@ def test_default_init_goldens(golden, dtype, name, C):
     names = [str(n) for n in g["grad_names"]]
     norms = torch.stack([net.grad(n).norm() for n in names]).cpu()
     ref = T(g["grad_norms"])
-    ok = (norms - ref).abs() <= 3 * tol * ref.abs() + 1e-3 * tol * ref.abs().max()
+    # gradients at the bar of the outputs (round 3; rounds 1-2 allowed 3x): measured 4e-6 / 2.2e-3 on the norms, 9e-7 / 2.7e-3 on the full gradients
+    ok = (norms - ref).abs() <= tol * ref.abs() + 1e-3 * tol * ref.abs().max()
     assert bool(ok.all()), [(names[i], float(norms[i]), float(ref[i])) for i in (~ok).nonzero().flatten()[:8]]
     for k in g.files:
         if k.startswith("grad__"):
-            assert rel_err(net.grad(k[6:]), T(g[k])) < 3 * tol, k
+            assert rel_err(net.grad(k[6:]), T(g[k])) < tol, k
 
 
 def test_state_dict_roundtrip_and_arena():
@@ -126,8 +127,9 @@ def test_unet_forward_backward_vs_oracle(dtype, in_channels, S):
             continue
         err = float((net.grad(name).cpu() - v.grad).abs().max())
         scale = max(float(v.grad.abs().max()), 1e-3 * gmax)
-        # gradients compound the forward and the backward rounding: 3x the forward bar at fp32, 6x at bf16
-        if err > (3 if dtype == torch.float32 else 6) * TOL[dtype] * scale:
+        # fp32: the bar of the outputs.  16-bit mode: bf16 gradient storage compounds along the backward chain - 2x the bar (measured worst
+        # 1.1 - 1.3e-2 of the tensor's largest entry; rounds 1-2 allowed 3x / 6x)
+        if err > (1 if dtype == torch.float32 else 2) * TOL[dtype] * scale:
             bad.append((name, err, scale))
     assert not bad, bad[:8]
 
@@ -163,7 +165,7 @@ def test_training_step_vs_golden(golden, name, C, dtype):
             norms = torch.stack([net.grad(n).norm() for n in names]).cpu()
             ref = T(g["grad_norms"])
             if dtype == torch.float32:
-                ok = (norms - ref).abs() <= 3 * tol * ref.abs() + 1e-3 * tol * ref.abs().max()
+                ok = (norms - ref).abs() <= tol * ref.abs() + 1e-3 * tol * ref.abs().max()
             else:
                 # bf16 gradients on the cancellation-heavy closed-form net: single small-norm tensors deviate by up to 17 % (measured,
                 # round 3), the gradient as a whole by < 2 %; bounds: 30 % per tensor (+ 2 % of the largest norm), 5 % on the total norm
@@ -171,7 +173,7 @@ def test_training_step_vs_golden(golden, name, C, dtype):
                 assert abs(float(norms.norm() / ref.norm()) - 1.0) < 5e-2, float(norms.norm() / ref.norm())
             assert bool(ok.all()), [(names[i], float(norms[i]), float(ref[i])) for i in (~ok).nonzero().flatten()[:8]]
             live = {n: float(r) > 1e-4 * float(ref.max()) for n, r in zip(names, ref)}   # skip mathematically-zero grads
-            gtol = 3 * tol if dtype == torch.float32 else 0.3
+            gtol = tol if dtype == torch.float32 else 0.3
             for k in g.files:
                 if k.startswith("grad__") and live[k[6:]]:
                     assert rel_err(net.grad(k[6:]), T(g[k])) < gtol, k
@@ -226,7 +228,7 @@ def test_sampler_vs_oracle(dtype, sampler, guided):
     zs, xs, es = diff.sample(net=partial(net, guide=y.cuda()), init_x=init.cuda(), cond_w=0.5 if guided else None,
                              noises=noises.cuda(), net_cond_w=w.cuda() if guided else None)
     assert zs.shape == zs_ref.shape
-    tol = 5 * TOL[dtype]          # errors compound over the chain
+    tol = (1 if dtype == torch.float32 else 3) * TOL[dtype]          # 16-bit mode: errors compound over the chain (measured worst 2.1e-2, guided DDIM)
     assert rel_err(zs, zs_ref) < tol and rel_err(xs, xs_ref) < tol
     assert torch.equal(zs[-1], xs[-1])
     last = diff.sample(net=partial(net, guide=y.cuda()), init_x=init.cuda(), cond_w=0.5 if guided else None,
@@ -383,7 +385,7 @@ def test_odd_batches_and_sizes_bf16_vs_fp32_vs_oracle(B, S):
         for name in ("down.seq.1.in_layers.2.weight", "up.seq.3.1.conv.weight", "down.seq.6.conv.weight",
                      "up.seq.5.skip_connection.weight", "out.2.weight", "time_embed.0.weight", "turn.out_layers.0.bias"):
             gr = p[name].grad
-            assert rel_err(net.grad(name), gr) < 6 * tol, name
+            assert rel_err(net.grad(name), gr) < (1 if net is net32 else 2) * tol, name      # (rounds 1-2: 6x; measured worst 1.3e-2 in the 16-bit mode)
 
 
 @pytest.mark.parametrize("mt", ["eps", "x"])
@@ -451,7 +453,7 @@ def test_dropout_training_mode_vs_oracle(dtype):
     net.backward_hip(ctx, dout.cuda())
     for name in ("down.seq.1.out_layers.3.weight", "down.seq.1.out_layers.0.weight", "up.seq.5.in_layers.2.weight",
                  "turn.out_layers.0.bias", "time_embed.0.weight", "down.seq.0.conv.weight"):
-        assert rel_err(net.grad(name), pr[name].grad) < 6 * tol, name
+        assert rel_err(net.grad(name), pr[name].grad) < (1 if dtype == torch.float32 else 2) * tol, name
     # eval mode: no dropout, equals the oracle without masks
     net.eval()
     with torch.no_grad():
@@ -485,7 +487,8 @@ def test_attention_extension_vs_oracle(dtype):
     net.backward_hip(ctx, dout.cuda())
     for name in ("attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "attn.norm.weight", "attn.norm.bias",
                  "turn.out_layers.3.weight", "down.seq.1.in_layers.2.weight", "up.seq.0.0.in_layers.2.weight", "time_embed.0.weight"):
-        assert rel_err(net.grad(name), pr[name].grad) < 6 * tol, name
+        # (the extension's fp32 path at the bar of the outputs; bf16 internals of the block: measured 2.1e-2 on attn.qkv.weight)
+        assert rel_err(net.grad(name), pr[name].grad) < (1 if dtype == torch.float32 else 3) * tol, name
     # without the flag nothing changes: 160 tensors, reference names only
     assert len(SimpleUnet(128, 0.0).state_dict()) == 160
 
