@@ -6,6 +6,7 @@
 #   r03_traffic.json                          HBM bytes per launch of every kernel of the headline config, separate --pmc passes,
 #                                             stamped with the kernel-source hash (bench.py quotes it only for the same sources)
 #   r03_bench.json                            the bench line of the same build;  r03_parity_report.txt  tests/parity_report.py
+#   r03_trajectory_report.txt                 tests/trajectory_report.py: 150 Adam steps, CPU oracle vs HIP fp32 vs HIP 16-bit
 TAG=${1:-r03}
 OUT=/tmp/gmk_$TAG                 # raw traces are hundreds of MB: they stay on the box; only the summaries travel
 KEEP=gpurun_out/$TAG
@@ -43,6 +44,7 @@ echo "traffic done"
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 cp $OUT/bench.json profiles/r03_bench.json
 python tests/parity_report.py > profiles/r03_parity_report.txt 2>/dev/null || exit 1
+python tests/trajectory_report.py 150 2>/dev/null | grep -v "^oracle step" > profiles/r03_trajectory_report.txt || exit 1
 cp profiles/r03_* $KEEP/
 cp $OUT/*.log $OUT/bench.err $KEEP/ 2>/dev/null
 tail -c 300 $OUT/bench.json
