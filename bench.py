@@ -10,8 +10,10 @@ are cycled).  Workloads are BASELINE.json's configs (C=128, bf16 compute, fp32 m
 is fixed):
     N = 1   headline configs[2] (3x32x32, B=2048: the largest config that is quoted on one GPU), `other_configs` =
             configs[1] (1x28x28, B=1024) and the per-GPU shard of configs[3] (3x64x64, B=1024)
-    N > 1   headline = the per-GPU shard of configs[3] (3x64x64, 1024 images per GPU); `other_configs` = the shard of
-            configs[4] (3x64x64 + self-attention, 512 per GPU)
+    N > 1   headline = the SAME per-GPU workload (3x32x32, 2048 images per GPU: global batch N x 2048), so that value(N) / (N x value(1))
+            of the top-level lines is the weak-scaling efficiency of one workload; `other_configs` = the per-GPU shards of the two
+            configs BASELINE quotes on 8 GPUs: configs[3] (3x64x64, 1024 per GPU: its single-GPU reference is other_configs.cfg3 of the
+            N = 1 line) and configs[4] (3x64x64 + fp8 self-attention, 512 per GPU)
 Rank 0 prints ONE JSON line:
   value            whole-job train images/s over exactly K timed steps after W warm-up steps, max-over-ranks wall time
   steady_state     the same loop again for >= 50 more steps (SURVEY §8d M1 asks for >= 50 steps after >= 10 warm-up)
@@ -349,7 +351,7 @@ class Bench:
         elif self.world == 1:
             plan = [("cfg2", CONFIGS["cfg2"]), ("cfg1", CONFIGS["cfg1"]), ("cfg3", CONFIGS["cfg3"])]
         else:
-            plan = [("cfg3", CONFIGS["cfg3"]), ("cfg4", CONFIGS["cfg4"])]
+            plan = [("cfg2", CONFIGS["cfg2"]), ("cfg3", CONFIGS["cfg3"]), ("cfg4", CONFIGS["cfg4"])]
         if not a.others:
             plan = plan[:1]
         head = self.run_config(plan[0][0], plan[0][1], a.steps, a.warmup, True)
@@ -377,9 +379,9 @@ class Bench:
             if others:
                 line["other_configs"] = others
             if self.world > 1:
-                # the N = 1 line's headline is configs[2]; the single-GPU number of THIS workload is its other_configs entry
-                line["scaling_reference"] = ("weak scaling of the configs[3] per-GPU shard: divide by n_gpus x "
-                                             "other_configs.cfg3.value of the --gpus 1 line (same per-GPU batch and shape)")
+                line["scaling_reference"] = ("weak scaling, same per-GPU workload as the --gpus 1 line: efficiency = value / (n_gpus x value of the "
+                                             "--gpus 1 line); other_configs.cfg3 (BASELINE configs[3], 1024 images per GPU) compares with "
+                                             "other_configs.cfg3 of the --gpus 1 line the same way")
             print(json.dumps(line))
         if self.world > 1:
             dist.destroy_process_group()
