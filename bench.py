@@ -170,6 +170,8 @@ class Bench:
         torch.cuda.set_device(local)
         self.dev = torch.device("cuda", local)
         if self.world > 1:
+            from generative_models_amd.parallel import configure_rccl_env
+            configure_rccl_env()                     # RCCL's channel count = the CUs the persistent kernels leave free
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=self.dev)
             else:

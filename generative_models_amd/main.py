@@ -200,6 +200,8 @@ def init_distributed():
     """One process per GPU under torchrun: RCCL (backend "nccl") when GPUs are present, gloo otherwise."""
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ and not dist.is_initialized():
         if torch.cuda.is_available():
+            from .parallel import configure_rccl_env
+            configure_rccl_env()
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
             dist.init_process_group(backend="nccl")
         else:

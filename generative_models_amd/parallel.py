@@ -13,7 +13,11 @@ few, large buckets.  The 1/world scaling is folded into the fused Adam kernel (`
 CU carve-out: the convolution kernels are persistent grids of one 160 KiB-LDS workgroup per CU — they leave RCCL's reduction
 kernels nowhere to run until a whole kernel drains.  With world > 1 the persistent grids are therefore limited to
 256 - `GMK_RCCL_CUS` CUs (default 8: RCCL's ring kernels use a handful of workgroups per channel), costing the convolutions
-3 % of the chip and buying overlap of the exchange with the backward pass.
+3 % of the chip and buying overlap of the exchange with the backward pass.  `configure_rccl_env()` - called by the drivers BEFORE the
+process group exists - caps RCCL at that many channels (`NCCL_MAX_NCHANNELS`, one workgroup per channel) unless the user set the
+variable: a reduction kernel wider than the carve-out would take its extra CUs at the next kernel boundary, and the following
+persistent grid (sized for 248 CUs) would then run a straggler round on whatever is left.  24 MB per step needs no more: 8 channels
+over 7 xGMI links.  (By construction; no multi-GPU node was available to measure either setting.)
 """
 import os
 
@@ -55,6 +59,15 @@ def merge_buckets(natural, count):
             raise ValueError("merged gradient bucket is not contiguous")
         groups.append((start, end, g * per + per - 1))
     return groups
+
+
+def configure_rccl_env():
+    """Keep RCCL's reduction kernels inside the CUs `reserve_cus_for_rccl` leaves free.  Environment only: call before
+    `init_process_group` (RCCL reads it when the communicator is created); a value the user exported wins."""
+    keep = int(os.environ.get("GMK_RCCL_CUS", "8"))
+    if keep > 0 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(keep))
+    return os.environ.get("NCCL_MAX_NCHANNELS")
 
 
 def reserve_cus_for_rccl():
@@ -131,6 +144,7 @@ class GradSync:
         """What the exchange looks like from this rank (bench.py puts it beside the scaling numbers)."""
         info = {"world": world(), "backend": dist.get_backend() if world() > 1 else None,
                 "bucket_bytes": [4 * (e - s) for s, e, _ in self.buckets], "persistent_kernel_cus": self.cu_limit,
+                "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS"),
                 "exposed_ms": self.exposed_ms(),
                 "issue": "each bucket from a third stream behind the data-gradient and weight-gradient streams (no join on the main stream)"}
         if torch.cuda.is_available():

@@ -99,4 +99,5 @@ def test_bench_two_ranks_rehearsal():
     ex = d["exchange"]
     assert ex["world"] == 2 and ex["backend"] == "gloo" and len(ex["bucket_bytes"]) == 4 and ex["persistent_kernel_cus"] == 248
     assert ex["exposed_ms"] is not None and ex["exposed_ms"] >= 0.0
+    assert ex["rccl_max_channels"] == "8"        # RCCL capped at the CUs the persistent kernels leave free (set before the process group exists)
     assert d["steady_state"]["steps"] == 50 and d["sampler"]["timed_steps"] == 2
