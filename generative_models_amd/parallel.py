@@ -12,8 +12,9 @@ few, large buckets.  The 1/world scaling is folded into the fused Adam kernel (`
 
 CU carve-out: the convolution kernels are persistent grids of one 160 KiB-LDS workgroup per CU — they leave RCCL's reduction
 kernels nowhere to run until a whole kernel drains.  With world > 1 the persistent grids are therefore limited to
-256 - `GMK_RCCL_CUS` CUs (default 8: RCCL's ring kernels use a handful of workgroups per channel), costing the convolutions
-3 % of the chip and buying overlap of the exchange with the backward pass.  `configure_rccl_env()` - called by the drivers BEFORE the
+256 - `GMK_RCCL_CUS` CUs (default 8: RCCL's ring kernels use a handful of workgroups per channel) WHILE BUCKETS ARE IN FLIGHT - from the
+first all-reduce of a backward pass to `finish()`; the forward pass, the backward in front of the first bucket and the samplers keep all
+256 - costing the convolutions 3 % of the chip for about half of a step and buying overlap of the exchange with the backward pass.  `configure_rccl_env()` - called by the drivers BEFORE the
 process group exists - caps RCCL at that many channels (`NCCL_MAX_NCHANNELS`, one workgroup per channel) unless the user set the
 variable: a reduction kernel wider than the carve-out would take its extra CUs at the next kernel boundary, and the following
 persistent grid (sized for 248 CUs) would then run a straggler round on whatever is left.  24 MB per step needs no more: 8 channels
@@ -70,13 +71,16 @@ def configure_rccl_env():
     return os.environ.get("NCCL_MAX_NCHANNELS")
 
 
-def reserve_cus_for_rccl():
-    """Limit the persistent kernels to 256 - GMK_RCCL_CUS CUs when more than one rank runs (see the module docstring)."""
-    from ._lib import check, lib
+def carved_cu_limit():
+    """(full, carved): the CU count the persistent kernels normally use and the one that leaves GMK_RCCL_CUS CUs to RCCL while gradient
+    buckets are in flight (see the module docstring); carved is None when nothing is to be carved (one rank, GMK_RCCL_CUS=0, or a user-fixed
+    GMK_CU_LIMIT)."""
+    from ._lib import lib
+    full = lib.gmk_get_cu_limit()
     keep = int(os.environ.get("GMK_RCCL_CUS", "8"))
     if world() > 1 and keep > 0 and "GMK_CU_LIMIT" not in os.environ:
-        check(lib.gmk_set_cu_limit(256 - keep), "set_cu_limit")
-    return lib.gmk_get_cu_limit()
+        return full, full - keep
+    return full, None
 
 
 class GradSync:
@@ -92,7 +96,10 @@ class GradSync:
         self._fire = {last: (s, e) for s, e, last in self.buckets}
         self.works = []
         self.issued = []                      # (natural index, start, end) of every all-reduce issued this step (tests, bench)
-        self.cu_limit = reserve_cus_for_rccl() if net.flat_params.is_cuda else None
+        # the carve-out is applied only while buckets are in flight: from the first all-reduce of a backward pass to finish().  The forward
+        # pass, the part of the backward in front of the first bucket and the samplers (no collectives) keep the whole chip
+        self._cu_full, self.cu_limit = carved_cu_limit() if net.flat_params.is_cuda else (None, None)
+        self._carved = False
         self._comm = None                     # the exchange stream (GPU only)
         self._exposed = []                    # (event before, event after) around finish()'s waits: what the step still waits for
 
@@ -108,6 +115,10 @@ class GradSync:
         if self._comm is None:
             self._comm = torch.cuda.Stream(device=grads.device)
         comm = self._comm
+        if self.cu_limit is not None and not self._carved:    # every persistent kernel launched from here on leaves CUs to RCCL
+            from ._lib import check, lib
+            check(lib.gmk_set_cu_limit(self.cu_limit), "set_cu_limit")
+            self._carved = True
         comm.wait_stream(torch.cuda.current_stream())         # colsums, GroupNorm parameter gradients, embedding GEMMs
         if getattr(self.net, "_side", None) is not None:
             comm.wait_stream(self.net._side)                  # the bucket's weight gradients
@@ -123,6 +134,10 @@ class GradSync:
             w.wait()
         if self._comm is not None:
             torch.cuda.current_stream().wait_stream(self._comm)
+        if self._carved:                                      # what is launched from here on runs behind the exchange: the whole chip again
+            from ._lib import check, lib
+            check(lib.gmk_set_cu_limit(self._cu_full), "set_cu_limit")
+            self._carved = False
         if timed:
             e1 = torch.cuda.Event(enable_timing=True); e1.record()
             self._exposed.append((e0, e1))
