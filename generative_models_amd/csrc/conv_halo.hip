@@ -1408,9 +1408,11 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
         // not for variant 4 (its vmcnt waits count 4 weight DMAs per step); variant 6 is the A/B switch
         if (ntiles > G && rem > 0 && 2 * rem <= G && p.variant != 4 && p.variant != 6) { p.nfull = (int)ntiles - rem; p.nhalf = 2 * rem; }
     }
-    const bool use16 = p.variant != 32 && (p.variant == 16 || ((p.variant == 0 || p.variant == 7 || p.variant == 9) && (p.ktot >= 256 || W >= 32 || W <= 16)));
-    // MFMA shape of the consumers: bit-identical results either way; v_mfma_f32_16x16x32 measured +2 ... +4 % at K = 2304, at
-    // 64- / 32- / 14-pixel rows, and -2 % at 28 x 28 with K = 1152 (tools/halo_ab.py).  GMK_DEV_VARIANT 16 / 32 force one form.
+    const bool use16 = p.variant != 32 && p.variant != 1 && p.variant != 3;      // (variants 1 / 3: the 8-compute-wave kernel)
+    // MFMA shape of the consumers: bit-identical results either way; v_mfma_f32_16x16x32 measured +2 ... +4 % at K = 2304 and at
+    // 64- / 32- / 14-pixel rows in round 2.  At 28 x 28 with K = 1152 it had measured -2 % with bf16 operands and kept the 32 x 32 x 16 form
+    // there; re-measured in round 3 (fp16 forward operands, whole bench, same box): +1.2 ... 1.9 % train, +3.5 % sampler at 1x28x28 with
+    // the 16 x 16 x 32 form everywhere, so it is the form of every launch now.  GMK_DEV_VARIANT=32 forces the other.
     // kind: 0 the 8-compute-wave kernel (variants 1, 3, or statistics wanted), 1 fused GroupNorm-apply + SiLU in the producer waves
     // (tables from gmk_gn_stats), 2 variant 4 (no weight prefetch), 3 the wave-specialised kernel
     const int kind = gn_scale ? 1 : (p.variant == 4 && !p.stats) ? 2 : (!p.stats && (use16 || (p.variant != 1 && p.variant != 3))) ? 3 : 0;
