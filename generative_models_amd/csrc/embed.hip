@@ -55,8 +55,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                       const float* __restrict__ bias, const float* __restrict__ bias2,
                                                       const float* __restrict__ rowscale,
                                                       int silu, int accumulate, float* __restrict__ ws, int kchunk) {
-    __shared__ float As[TK][TM + 4];
-    __shared__ float Bs[TK][TN + 4];
+    // Two LDS stages: the next k-slab's 8 global values per thread are loaded into registers BEFORE the current slab's MFMAs and stored
+    // to the other stage behind them - one barrier per slab, the global-load latency (the whole cost of the single-stage loop: ~ 2 us per
+    // 16-k slab, 60 us for K = 256) hides under the matrix instructions.  Same MFMA sequence per accumulator: bit-identical results.
+    __shared__ float As[2][TK][TM + 4];
+    __shared__ float Bs[2][TK][TN + 4];
     const int tid = threadIdx.x;
     // wave (wm, wn) owns the 32 x 32 quarter of the 64 x 64 tile: one fp32 MFMA accumulator (v_mfma_f32_32x32x2_f32 - true fp32
     // multiply-adds, K = 2 per instruction: lane = (r, h) feeds A[row r][k + h] and B[k + h][col r])
@@ -70,36 +73,48 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     // raw partial sums to ws[z][M][N]; gemm_splitk_reduce_kernel then applies bias / rowscale / accumulate
     const int kbeg = blockIdx.z * kchunk;
     if (gridDim.z > 1) K = min(K, kbeg + kchunk);
-    for (int k0 = kbeg; k0 < K; k0 += TK) {
+    int ia[4], ka[4], jb[4], kb[4];              // this thread's 4 + 4 elements of a slab: A tile k fastest when sa1 == 1 (else i fastest), B alike
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = tid + e * 256;
+        if (sa1 == 1) { ka[e] = idx % TK; ia[e] = idx / TK; } else { ia[e] = idx % TM; ka[e] = idx / TM; }
+        if (sb0 == 1) { kb[e] = idx % TK; jb[e] = idx / TK; } else { jb[e] = idx % TN; kb[e] = idx / TN; }
+    }
+    float ra[4], rb[4];
+    auto gload = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int idx = tid + e * 256;              // 1024 elements per tile
-            {   // A tile: k fastest when sa1 == 1, else i fastest
-                int i, k;
-                if (sa1 == 1) { k = idx % TK; i = idx / TK; } else { i = idx % TM; k = idx / TM; }
-                float v = 0.f;
-                if (i0 + i < M && k0 + k < K) {
-                    v = A[(int64_t)(i0 + i) * sa0 + (int64_t)(k0 + k) * sa1];
-                    if (silu & 1) v = v / (1.0f + expf(-v));
-                }
-                As[k][i] = v;
+            float v = 0.f;
+            if (i0 + ia[e] < M && k0 + ka[e] < K) {
+                v = A[(int64_t)(i0 + ia[e]) * sa0 + (int64_t)(k0 + ka[e]) * sa1];
+                if (silu & 1) v = v / (1.0f + expf(-v));
             }
-            {
-                int j, k;
-                if (sb0 == 1) { k = idx % TK; j = idx / TK; } else { j = idx % TN; k = idx / TN; }
-                float v = 0.f;
-                if (j0 + j < N && k0 + k < K) {
-                    v = Bm[(int64_t)(k0 + k) * sb0 + (int64_t)(j0 + j) * sb1];
-                    if (silu & 2) v = v / (1.0f + expf(-v));
-                }
-                Bs[k][j] = v;
+            ra[e] = v;
+            float w = 0.f;
+            if (j0 + jb[e] < N && k0 + kb[e] < K) {
+                w = Bm[(int64_t)(k0 + kb[e]) * sb0 + (int64_t)(j0 + jb[e]) * sb1];
+                if (silu & 2) w = w / (1.0f + expf(-w));
             }
+            rb[e] = w;
         }
-        __syncthreads();
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { As[buf][ka[e]][ia[e]] = ra[e]; Bs[buf][kb[e]][jb[e]] = rb[e]; }
+    };
+    gload(kbeg);
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < K; k0 += TK) {
+        const bool more = k0 + TK < K;
+        if (more) gload(k0 + TK);
 #pragma unroll
         for (int k = 0; k < TK; k += 2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k + h][wm * 32 + r], Bs[k + h][wn * 32 + r], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][k + h][wm * 32 + r], Bs[buf][k + h][wn * 32 + r], acc, 0, 0, 0);
+        if (more) sstore(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
     }
     // accumulator element e of lane (r, h): row (e & 3) + 8 (e >> 2) + 4 h, column r of the wave's quarter
     const int j = j0 + wn * 32 + r;
@@ -229,6 +244,8 @@ static int gemm_ksplit(int M, int N, int K, int* kchunk) {
         if (nz > K / 64) nz = K / 64;
         if (nz > 32) nz = 32;
         if (nz < 1) nz = 1;
+    } else if (tiles < 256 && K >= 1024) {
+        nz = 2;                                   // half a chip of tiles and a long contraction (the 12 emb_layers' data gradient: 128 tiles, K = 1536)
     }
     int kc = (K + nz - 1) / nz;
     kc = (kc + TK - 1) / TK * TK;
