@@ -27,7 +27,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- p
 cp $(find $OUT/bench -name "*kernel_stats.csv" | head -1) profiles/r03_bench_kernel_stats.csv
 echo "bench stats done"
 fi
-[[ " $PARTS " == *" pmc "* ]] || { cp profiles/r03_* $KEEP/; exit 0; }
+[[ " $PARTS " == *" pmc "* ]] || { cp profiles/r03_*kernel_stats.csv $KEEP/; exit 0; }
 for cfg in cfg2 cfg1 cfg3; do      # every single-GPU configuration of the bench line gets its own counter passes
   i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
@@ -55,6 +55,6 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 cp $OUT/bench.json profiles/r03_bench.json
 python tests/parity_report.py > profiles/r03_parity_report.txt 2>/dev/null || exit 1
 python tests/trajectory_report.py 150 2>/dev/null | grep -v "^oracle step" > profiles/r03_trajectory_report.txt || exit 1
-cp profiles/r03_* $KEEP/
+if [[ " $PARTS " == *" stats "* ]]; then cp profiles/r03_* $KEEP/; else cp profiles/r03_traffic.json profiles/r03_bench.json profiles/r03_parity_report.txt profiles/r03_trajectory_report.txt $KEEP/; fi
 cp $OUT/*.log $OUT/bench.err $KEEP/ 2>/dev/null
 tail -c 300 $OUT/bench.json
