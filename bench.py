@@ -9,7 +9,7 @@ bucketed gradient all-reduce, fused Adam) on a batch of synthetic images already
 are cycled).  Workloads are BASELINE.json's configs (C=128, bf16 compute, fp32 master weights, weak scaling: the per-GPU batch
 is fixed):
     N = 1   headline configs[2] (3x32x32, B=2048: the largest config that is quoted on one GPU), `other_configs` =
-            configs[1] (1x28x28, B=1024) and the per-GPU shard of configs[3] (3x64x64, B=1024)
+            configs[1] (1x28x28, B=1024) and the per-GPU shards of configs[3] (3x64x64, B=1024) and configs[4] (+ fp8 self-attention, B=512)
     N > 1   headline = the SAME per-GPU workload (3x32x32, 2048 images per GPU: global batch N x 2048), so that value(N) / (N x value(1))
             of the top-level lines is the weak-scaling efficiency of one workload; `other_configs` = the per-GPU shards of the two
             configs BASELINE quotes on 8 GPUs: configs[3] (3x64x64, 1024 per GPU: its single-GPU reference is other_configs.cfg3 of the
@@ -351,7 +351,7 @@ class Bench:
         elif a.config != "auto":
             plan = [(a.config, CONFIGS[a.config])]
         elif self.world == 1:
-            plan = [("cfg2", CONFIGS["cfg2"]), ("cfg1", CONFIGS["cfg1"]), ("cfg3", CONFIGS["cfg3"])]
+            plan = [("cfg2", CONFIGS["cfg2"]), ("cfg1", CONFIGS["cfg1"]), ("cfg3", CONFIGS["cfg3"]), ("cfg4", CONFIGS["cfg4"])]
         else:
             plan = [("cfg2", CONFIGS["cfg2"]), ("cfg3", CONFIGS["cfg3"]), ("cfg4", CONFIGS["cfg4"])]
         if not a.others:
