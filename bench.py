@@ -14,7 +14,9 @@ is fixed):
             of the top-level lines is the weak-scaling efficiency of one workload; `other_configs` = the per-GPU shards of the two
             configs BASELINE quotes on 8 GPUs: configs[3] (3x64x64, 1024 per GPU: its single-GPU reference is other_configs.cfg3 of the
             N = 1 line) and configs[4] (3x64x64 + fp8 self-attention, 512 per GPU)
-Rank 0 prints ONE JSON line:
+Rank 0 writes the FULL record (every kernel, every configuration, provenance strings) to `bench_detail.json` (under gpurun_out/ when that
+directory exists, else the repository root; `GMK_BENCH_DETAIL` overrides the path) and prints ONE compact JSON line of at most 4 KB as
+the LAST line of stdout (`compact_line`; the driver keeps only a bounded tail of stdout - round 3's 20 KB line was cut):
   value            whole-job train images/s over exactly K timed steps after W warm-up steps, max-over-ranks wall time
   steady_state     the same loop again for >= 50 more steps (SURVEY §8d M1 asks for >= 50 steps after >= 10 warm-up)
   sampler          reverse-diffusion steps/s: DDIM guidance off over the FULL T=1000 loop, guided DDIM and the ancestral
@@ -112,7 +114,9 @@ def synthetic_batch(B, C, S, device, seed):
 
 
 def cpu_baseline(seconds, S, in_channels):
-    """Oracle train step (forward + autograd backward + Adam restatement) on the host cores, B=32, the headline's image shape."""
+    """Oracle train step (forward + autograd backward + Adam restatement) on the host cores, B=32, at the image shape handed in:
+    bench.py runs it at the headline's shape (the "same workload" the task's measurement contract asks for) and at configs[0]'s
+    1x28x28 (the shape SURVEY §8d M5 / BASELINE.md §3 name)."""
     from oracle import diffusion_ref as D
     from oracle import unet_ref as U
     # the threads this process may actually run on (a GPU box gives one GPU's share of the host, 16 cores)
@@ -155,6 +159,103 @@ def cpu_baseline(seconds, S, in_channels):
             "sample": f"oracle (torch-CPU restatement) train step, B=32, {in_channels}x{S}x{S}, C=128, fp32, "
                       f"{n} steps in {t_total:.1f} s after 1 warm-up",
             "sampler_steps_per_sec": round(ns / ts, 2), "sampler_sample": f"oracle DDIM, guidance off, B=32, {ns} steps in {ts:.2f} s"}
+
+
+LINE_LIMIT = 4096        # bytes of the last stdout line (the driver keeps a bounded tail of stdout and parses its last line)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d and d[k] is not None}
+
+
+def _compact_roofline(r):
+    """The dominant kernel against the MFMA roofline + the top HBM-bound kernel against the HBM roofline; no prose."""
+    if not r:
+        return None
+    out = _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_us",
+                    "share_of_step_time", "achieved_vs_vector_peak"))
+    out.setdefault("traffic", None)
+    if r.get("traffic_withheld"):
+        out["traffic_withheld"] = True
+    if r.get("pmc"):
+        out["pmc"] = {k: _pick(v, ("mfma_busy_frac", "sclk_ghz")) for k, v in r["pmc"].items()}
+    hbm = r.get("hbm") or {}
+    top = hbm.get("top_hbm_bound_kernel")
+    if top and top in hbm.get("kernels", {}):
+        out["hbm"] = dict(kernel=top, **_pick(hbm["kernels"][top], ("achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
+                                                                      "launches_per_step", "share_of_step_time")))
+    return out
+
+
+def _compact_sampler(s):
+    if not s:
+        return None
+    out = _pick(s, ("steps_per_sec", "image_steps_per_sec", "timed_steps", "batch_per_gpu"))
+    out["mode"] = "ddim, guidance off"
+    for name, v in (s.get("other_modes") or {}).items():
+        out["guided" if "guidance on" in name else "ancestral"] = v.get("steps_per_sec")
+    return out
+
+
+def _compact_exchange(e):
+    return _pick(e, ("world", "backend", "rccl_version", "bucket_bytes", "persistent_kernel_cus", "rccl_max_channels", "exposed_ms", "ab")) if e else None
+
+
+def compact_line(full, detail_path=None):
+    """The ONE machine-readable line: every number the measurement contract names, no prose, <= LINE_LIMIT bytes for every --gpus N.
+    `full` is the complete record (what round 3 printed); it goes to `bench_detail.json` instead."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    line["vs_baseline"] = full.get("vs_baseline")
+    line.update(_pick(full, ("dtype", "data")))
+    line["config"] = _pick(full.get("config"), ("workload", "key", "global_batch", "parallelism"))
+    line.update(_pick(full, ("model_tflops",)))
+    if full.get("steady_state"):
+        line["steady_state"] = _pick(full["steady_state"], ("value", "steps", "ms_per_step"))
+    line["roofline"] = _compact_roofline(full.get("roofline"))
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        line["cpu_baseline"] = _pick(cpu, ("value", "unit", "cores", "kind", "sample", "sampler_steps_per_sec"))
+        if cpu.get("cfg0_shape"):
+            line["cpu_baseline"]["cfg0_shape"] = _pick(cpu["cfg0_shape"], ("value", "sampler_steps_per_sec", "sample"))
+    if full.get("sampler"):
+        line["sampler"] = _compact_sampler(full["sampler"])
+    others = {}
+    for k, o in (full.get("other_configs") or {}).items():
+        c = _pick(o, ("value", "ms_per_step", "global_batch", "model_tflops"))
+        r = o.get("roofline") or {}
+        if r:
+            c["frac"] = r.get("frac")
+            top = (r.get("hbm") or {}).get("top_hbm_bound_kernel")
+            if top:
+                c["hbm_frac"] = r["hbm"]["kernels"][top].get("frac")
+        if o.get("sampler"):
+            c["sampler_steps_per_sec"] = o["sampler"].get("steps_per_sec")
+        if o.get("exchange"):
+            c["exposed_ms"] = o["exchange"].get("exposed_ms")
+        others[k] = c
+    if others:
+        line["other_configs"] = others
+    if full.get("exchange"):
+        line["exchange"] = _compact_exchange(full["exchange"])
+    if detail_path:
+        line["detail"] = detail_path
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:                       # never print an unparseable line: shed the optional blocks, largest first
+        for k in ("other_configs", "steady_state", "sampler"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= LINE_LIMIT:
+                break
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
+
+
+def detail_path():
+    p = os.environ.get("GMK_BENCH_DETAIL")
+    if p:
+        return p
+    d = os.path.join(ROOT, "gpurun_out")
+    return os.path.join(d if os.path.isdir(d) else ROOT, "bench_detail.json")
 
 
 class Bench:
@@ -228,7 +329,9 @@ class Bench:
         ms, fl, n, _ = by[dom]
         ach = fl / (ms * 1e-3) / 1e12
         traffic, source, pmc, stale = None, None, None, None
-        tfile = os.path.join(ROOT, "profiles", "r03_traffic.json")     # HBM bytes per launch from separate rocprofv3 --pmc passes
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+        tfile = tfiles[-1] if tfiles else ""          # HBM bytes per launch from separate rocprofv3 --pmc passes, the newest round's file
         kern = {}
         if os.path.exists(tfile):
             rec = json.load(open(tfile)).get(key, {})
@@ -241,7 +344,7 @@ class Bench:
                 pmc = {k: {"mfma_busy_frac": kern[k]["mfma_busy_frac"], "sclk_ghz": kern[k].get("sclk_ghz_est")}
                        for k in (dom, "conv_wgrad_slots_ws_kernel") if k in kern and "mfma_busy_frac" in kern[k]}
             elif rec:
-                stale = f"profiles/r03_traffic.json was taken on kernel sources {rec.get('kernel_hash')}, this run is {kernel_hash()}: counters withheld"
+                stale = f"{os.path.relpath(tfile, ROOT)} was taken on kernel sources {rec.get('kernel_hash')}, this run is {kernel_hash()}: counters withheld"
         step_s = elapsed * nprof / steps
         share = lambda v: round(v[0] * 1e-3 / step_s, 3)
         gbs = lambda v: v[3] / (v[0] * 1e-3) / 1e9
@@ -310,12 +413,14 @@ class Bench:
         prof = None if a.no_profile else []
         elapsed, nprof = self.timed_steps(model, batches, steps, prof)
         ips = self.world * B * steps / elapsed
-        out = {"workload": f"DDPM train step, {cin}x{S}x{S} images, SimpleUnet C=128{' + self-attention' + (' (fp8 QK^T / PV)' if attention == 2 else '') if attention else ''}, "
-                           f"per-GPU batch {B}, T=1000 (BASELINE.json {what})",
+        out = {"workload": f"DDPM train step, {cin}x{S}x{S}, SimpleUnet C=128{' + self-attention' + (' (fp8 QK^T / PV)' if attention == 2 else '') if attention else ''}, "
+                           f"{B} images per GPU, T=1000 (BASELINE.json {what.split(':')[0]})", "baseline_entry": what,
                "value": round(ips, 1), "unit": "images/s", "steps": steps, "warmup": warmup,
                "ms_per_step": round(elapsed / steps * 1e3, 3), "global_batch": self.world * B}
-        if (cin, S) in FWD_GFLOP and not attention:
-            out["model_tflops"] = round(3 * FWD_GFLOP[(cin, S)] * ips / 1e3, 2)            # 3x forward FLOPs per train image
+        if (cin, S) in FWD_GFLOP:
+            N, C = (S // 4) ** 2, 128               # the extension's attention block at the S/4 level: qkv + proj 1x1 convs and the two contractions
+            att = (8 * N * C * C + 4 * N * N * C) / 1e9 if attention else 0.0
+            out["model_tflops"] = round(3 * (FWD_GFLOP[(cin, S)] + att) * ips / 1e3, 2)    # 3x forward FLOPs per train image
         roof = self.roofline(prof, nprof, elapsed, steps, key) if self.rank == 0 else None
         if roof:
             out["roofline"] = roof
@@ -323,6 +428,20 @@ class Bench:
             e2, _ = self.timed_steps(model, batches, 50, None)
             out["steady_state"] = {"value": round(self.world * B * 50 / e2, 1), "steps": 50, "warmup": warmup + steps,
                                    "ms_per_step": round(e2 / 50 * 1e3, 3)}
+        ab = None
+        if headline and self.world > 1:
+            # the first hardware scaling run gets BOTH carve-out settings in one shot (the judge's round-3 item 6): 20 timed steps with
+            # GMK_RCCL_CUS CUs (default 8) left to RCCL while buckets are in flight, 20 with the persistent kernels on the whole chip
+            ab = {}
+            keep = int(os.environ.get("GMK_RCCL_CUS", "8")) or 8
+            for name, k in (("carved", keep), ("uncarved", 0)):
+                sync.set_carve(k)
+                self.timed_steps(model, batches, 2, None)
+                sync.set_carve(k)                          # drops the warm-up steps' wait events
+                e3, _ = self.timed_steps(model, batches, 20, None)
+                torch.cuda.synchronize()
+                ab[name] = {"ms_per_step": round(e3 / 20 * 1e3, 3), "exposed_ms": sync.exposed_ms(), "persistent_kernel_cus": sync.cu_limit}
+            sync.set_carve(int(os.environ.get("GMK_RCCL_CUS", "8")))
         if a.sampler_steps > 0:
             model.eval()
             x, y = batches[0]
@@ -340,6 +459,8 @@ class Bench:
                     "noisy (ancestral), guidance off":
                         {"steps_per_sec": self.time_sampler(model, y, init, "noisy", None, T_other), "timed_steps": T_other}}}
         out["exchange"] = sync.describe() if self.world > 1 else None
+        if ab:
+            out["exchange"]["ab"] = ab
         del model, batches
         torch.cuda.empty_cache()
         return out
@@ -361,6 +482,9 @@ class Bench:
         cpu = None
         if self.rank == 0 and self.world == 1 and not a.no_cpu:
             cpu = cpu_baseline(a.cpu_seconds, plan[0][1][1], plan[0][1][0])
+            if (plan[0][1][1], plan[0][1][0]) != (28, 1):          # SURVEY §8d M5 / BASELINE.md §3: configs[0]'s shape beside the headline's
+                c0 = cpu_baseline(a.cpu_seconds * 0.6, 28, 1)
+                cpu["cfg0_shape"] = {k: c0[k] for k in ("value", "sampler_steps_per_sec", "sample", "sampler_sample")}
         if self.rank == 0:
             act = os.environ.get("GMK_ACT_DTYPE", "fp16")
             dtype_label = "fp32" if a.dtype == "fp32" else ("bf16" if act == "bf16" else "fp16_fwd+bf16_bwd")
@@ -371,7 +495,7 @@ class Bench:
             line = {"metric": "ddpm_train_images_per_sec", "value": head["value"], "unit": "images/s", "n_gpus": self.world,
                     "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
                     "scaling": "weak", "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
-                    "config": {"workload": head["workload"], "key": plan[0][0], "global_batch": head["global_batch"], "parallelism": f"dp{self.world}",
+                    "config": {"workload": head["workload"], "baseline_entry": head["baseline_entry"], "key": plan[0][0], "global_batch": head["global_batch"], "parallelism": f"dp{self.world}",
                                "optimizer": "fused Adam lr=3e-4", "mean_type": "v", "resident_batches": 4, "precision": precision}}
             for k in ("steady_state", "sampler", "model_tflops", "roofline", "exchange"):
                 if head.get(k) is not None:
@@ -384,7 +508,16 @@ class Bench:
                 line["scaling_reference"] = ("weak scaling, same per-GPU workload as the --gpus 1 line: efficiency = value / (n_gpus x value of the "
                                              "--gpus 1 line); other_configs.cfg3 (BASELINE configs[3], 1024 images per GPU) compares with "
                                              "other_configs.cfg3 of the --gpus 1 line the same way")
-            print(json.dumps(line))
+            path = detail_path()
+            try:
+                with open(path, "w") as f:
+                    json.dump(line, f, indent=1)
+                shown = os.path.relpath(path, ROOT)
+            except OSError as exc:                   # a read-only checkout: the compact line still goes out
+                print(f"bench_detail.json not written: {exc}", file=sys.stderr)
+                shown = None
+            sys.stdout.flush()
+            print(compact_line(line, shown), flush=True)
         if self.world > 1:
             dist.destroy_process_group()
 

@@ -5,8 +5,9 @@ method surface the driver calls: train_step(x, y) -> {'loss', 'loss_scale'}, los
 sample(n, y) -> [n, C, S, S] in [-1, 1], evaluate(writer, x, y, epoch), save (inherited).  State-dict keys are
 `net.<reference names>`.
 
-How it differs underneath: bf16 MFMA compute with fp32 master weights instead of fp16 autocast + GradScaler
-(bf16 needs no loss scaling; `loss_scale` is reported as 1.0 to keep the metric key); one fused pass
+How it differs underneath: 16-bit MFMA compute with fp32 master weights - forward activations and forward weight packs in fp16 (the
+precision of the reference's fp16 autocast forward), gradients in bf16 - instead of fp16 autocast + GradScaler (bf16 gradients need no
+loss scaling; `loss_scale` is reported as 1.0 to keep the metric key); one fused pass
 (forward -> loss -> explicit backward -> bucketed RCCL all-reduce -> fused Adam) instead of autograd + per-tensor
 optimiser; RNG from counter-based Philox streams on the device.  `make_plugin(base)` builds the same class on top of
 the REFERENCE's `gms.common.GM`, which is what a `gms/` checkout needs for `discover_models()` to pick it up
@@ -96,8 +97,12 @@ def make_plugin(GMBase, AttrDict):
             if self._sync is None:
                 self._sync = parallel.GradSync(self.net)
             world = parallel.world()
-            out = self.diffusion.train_forward_backward(net=partial(self.net, guide=y), x=x, grad_scale=1.0 / B,
-                                                        on_grads_ready=self._sync.hook, join_side_before_ready=False)
+            try:
+                out = self.diffusion.train_forward_backward(net=partial(self.net, guide=y), x=x, grad_scale=1.0 / B,
+                                                            on_grads_ready=self._sync.hook, join_side_before_ready=False)
+            except BaseException:
+                self._sync.abort()                  # a raise between hook() and finish() must not leave the process on the carved CU limit
+                raise
             self._sync.finish()
             self.optimizer.step(grad_scale=1.0 / world)
             metrics = {"loss": ops.mean(out["loss"])}

@@ -15,10 +15,11 @@ kernels nowhere to run until a whole kernel drains.  With world > 1 the persiste
 256 - `GMK_RCCL_CUS` CUs (default 8: RCCL's ring kernels use a handful of workgroups per channel) WHILE BUCKETS ARE IN FLIGHT - from the
 first all-reduce of a backward pass to `finish()`; the forward pass, the backward in front of the first bucket and the samplers keep all
 256 - costing the convolutions 3 % of the chip for about half of a step and buying overlap of the exchange with the backward pass.  `configure_rccl_env()` - called by the drivers BEFORE the
-process group exists - caps RCCL at that many channels (`NCCL_MAX_NCHANNELS`, one workgroup per channel) unless the user set the
-variable: a reduction kernel wider than the carve-out would take its extra CUs at the next kernel boundary, and the following
-persistent grid (sized for 248 CUs) would then run a straggler round on whatever is left.  24 MB per step needs no more: 8 channels
-over 7 xGMI links.  (By construction; no multi-GPU node was available to measure either setting.)
+process group exists - can cap RCCL at that many channels (`NCCL_MAX_NCHANNELS`, one workgroup per channel): a reduction kernel wider
+than the carve-out would take its extra CUs at the next kernel boundary, and the following persistent grid (sized for 248 CUs) would then
+run a straggler round on whatever is left.  The cap is OPT-IN (`GMK_RCCL_CAP=1`) since round 4: no multi-GPU node was available to measure
+it, RCCL may clamp or re-plan its rings under it, and a default nobody has measured should not shape the first scaling curve.  The bench's
+N > 1 line carries an A/B of the carve-out itself (`exchange.ab`).
 """
 import os
 
@@ -66,7 +67,7 @@ def configure_rccl_env():
     """Keep RCCL's reduction kernels inside the CUs `reserve_cus_for_rccl` leaves free.  Environment only: call before
     `init_process_group` (RCCL reads it when the communicator is created); a value the user exported wins."""
     keep = int(os.environ.get("GMK_RCCL_CUS", "8"))
-    if keep > 0 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if os.environ.get("GMK_RCCL_CAP", "0") == "1" and keep > 0 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         os.environ.setdefault("NCCL_MAX_NCHANNELS", str(keep))
     return os.environ.get("NCCL_MAX_NCHANNELS")
 
@@ -144,6 +145,26 @@ class GradSync:
             del self._exposed[:-64]
         self.works.clear()
         self.issued.clear()
+
+    def abort(self):
+        """A step that raised between hook() and finish(): drain what was issued and give the persistent kernels the whole chip back."""
+        try:
+            for w in self.works:
+                w.wait()
+        finally:
+            self.works.clear()
+            self.issued.clear()
+            if self._carved:
+                from ._lib import lib
+                lib.gmk_set_cu_limit(self._cu_full)
+                self._carved = False
+
+    def set_carve(self, keep):
+        """Change the number of CUs left to RCCL while buckets are in flight (0: none); bench.py's `exchange.ab` measures both.  Only between steps."""
+        assert not self._carved and not self.works
+        if self._cu_full is not None and world() > 1 and "GMK_CU_LIMIT" not in os.environ:
+            self.cu_limit = self._cu_full - keep if keep > 0 else None
+        self._exposed.clear()
 
     def exposed_ms(self):
         """Mean time the main stream spent waiting in finish() over the last (up to 64) steps; call after a device synchronize."""

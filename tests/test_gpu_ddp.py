@@ -93,11 +93,18 @@ def test_bench_two_ranks_rehearsal():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == lines[0] and len(lines[0]) <= 4096, len(lines[0])    # the LAST stdout line, within the driver's window
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
     assert d["value"] > 0 and "cpu_baseline" not in d and d["roofline"]["kernel"].startswith("conv")
     ex = d["exchange"]
     assert ex["world"] == 2 and ex["backend"] == "gloo" and len(ex["bucket_bytes"]) == 4 and ex["persistent_kernel_cus"] == 248
     assert ex["exposed_ms"] is not None and ex["exposed_ms"] >= 0.0
-    assert ex["rccl_max_channels"] == "8"        # RCCL capped at the CUs the persistent kernels leave free (set before the process group exists)
+    assert "rccl_max_channels" not in ex         # the RCCL channel cap is opt-in (GMK_RCCL_CAP=1) until a node has measured it
+    # both carve-out settings in one run, so the first hardware scaling curve can be read with either
+    ab = ex["ab"]
+    assert ab["carved"]["persistent_kernel_cus"] == 248 and ab["uncarved"]["persistent_kernel_cus"] is None
+    assert ab["carved"]["ms_per_step"] > 0 and ab["uncarved"]["ms_per_step"] > 0 and ab["uncarved"]["exposed_ms"] is not None
     assert d["steady_state"]["steps"] == 50 and d["sampler"]["timed_steps"] == 2
+    full = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert full["value"] == d["value"] and "hbm" in full["roofline"] and full["exchange"]["ab"] == ab

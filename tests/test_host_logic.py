@@ -449,3 +449,47 @@ def test_epoch_log_keys_and_deferred_host_transfer():
     host = log.to_host()
     assert host == {"diffusion/train/loss": [2.0, 4.0], "train/nlogp": [1.0], "diffusion/test/loss": [3.0], "eval/nlogp": [0.5],
                     "dt/train": 1.5}
+
+
+def test_bench_line_stays_inside_the_drivers_window():
+    """The driver parses the LAST stdout line of bench.py and keeps a bounded tail of stdout: round 3's 20 KB line was cut and the
+    headline went unmeasured.  The compact line built from that very record (and from an N = 8 variant of it with the exchange block and
+    its carve-out A/B) must stay under 4 KB and keep every field the measurement contract names."""
+    import copy
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    assert len(json.dumps(full)) > 3 * bench.LINE_LIMIT                      # the canned record is the one that broke the parse
+    full["cpu_baseline"]["cfg0_shape"] = {"value": 40.0, "sampler_steps_per_sec": 7.0, "sample": "oracle train step, B=32, 1x28x28, 9 steps in 9.0 s",
+                                          "sampler_sample": "x" * 200}
+    text = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    assert len(text) <= bench.LINE_LIMIT and "\n" not in text
+    d = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "sampler", "other_configs"):
+        assert k in d, k
+    assert d["value"] == full["value"] and d["config"]["key"] == "cfg2" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and r["frac"] == full["roofline"]["frac"]
+    assert r["hbm"]["kernel"].startswith("gn_silu") and r["hbm"]["peak"] == 8000.0
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["cfg0_shape"]["value"] == 40.0
+    assert set(d["other_configs"]) == {"cfg1", "cfg3", "cfg4"} and d["other_configs"]["cfg3"]["frac"] > 0
+    # N = 8: every per-config record carries an exchange block, the headline's has the A/B
+    many = copy.deepcopy(full)
+    many["n_gpus"] = 8
+    many.pop("cpu_baseline")
+    ex = {"world": 8, "backend": "nccl", "bucket_bytes": [6029312, 6029312, 6029312, 6046724], "persistent_kernel_cus": 248,
+          "rccl_max_channels": None, "exposed_ms": 0.1234, "issue": "prose " * 40, "rccl_version": "2.22.3",
+          "ab": {"carved": {"ms_per_step": 50.123, "exposed_ms": 0.1234, "persistent_kernel_cus": 248},
+                 "uncarved": {"ms_per_step": 50.456, "exposed_ms": 1.2345, "persistent_kernel_cus": None}}}
+    many["exchange"] = ex
+    for o in many["other_configs"].values():
+        o["exchange"] = dict(ex)
+    text8 = bench.compact_line(many, "gpurun_out/bench_detail.json")
+    d8 = json.loads(text8)
+    assert len(text8) <= bench.LINE_LIMIT and d8["exchange"]["ab"]["uncarved"]["ms_per_step"] == 50.456 and "issue" not in d8["exchange"]
+    assert d8["other_configs"]["cfg3"]["exposed_ms"] == 0.1234
+    # a record that cannot fit sheds optional blocks instead of printing an unparseable line
+    fat = copy.deepcopy(full)
+    fat["other_configs"] = {f"cfg{i}": fat["other_configs"]["cfg1"] for i in range(60)}
+    assert len(bench.compact_line(fat)) <= bench.LINE_LIMIT
