@@ -428,6 +428,8 @@ class Bench:
             e2, _ = self.timed_steps(model, batches, 50, None)
             out["steady_state"] = {"value": round(self.world * B * 50 / e2, 1), "steps": 50, "warmup": warmup + steps,
                                    "ms_per_step": round(e2 / 50 * 1e3, 3)}
+        torch.cuda.synchronize()
+        exchange = sync.describe() if self.world > 1 else None      # exposed_ms of the timed loops above
         ab = None
         if headline and self.world > 1:
             # the first hardware scaling run gets BOTH carve-out settings in one shot (the judge's round-3 item 6): 20 timed steps with
@@ -458,7 +460,7 @@ class Bench:
                         {"steps_per_sec": self.time_sampler(model, y, init, "ddim", 0.5, T_other), "timed_steps": T_other},
                     "noisy (ancestral), guidance off":
                         {"steps_per_sec": self.time_sampler(model, y, init, "noisy", None, T_other), "timed_steps": T_other}}}
-        out["exchange"] = sync.describe() if self.world > 1 else None
+        out["exchange"] = exchange
         if ab:
             out["exchange"]["ab"] = ab
         del model, batches

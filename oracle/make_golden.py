@@ -327,6 +327,84 @@ def gen_metrics(name):
     save(name, **out)
 
 
+def ref_net_channels(C, cin, sd):
+    """The reference `SimpleUnet` for `cin` image channels.  The network is size-agnostic and hard-codes the image channel count in
+    exactly two layers (simple_unet.py:93 the stem `Downsample(1, channels, 1)`, :41 the head `Conv2d(channels, 1, 3)`): for cin != 1 those
+    two attributes of the IMPORTED module are re-assigned to the same layer types with cin channels - nothing else of the
+    reference is touched, its forward / ResBlocks / GroupNorms / Up / Down run as they stand."""
+    net = R_su.SimpleUnet(C, 0.0)
+    if cin != 1:
+        net.down.seq[0].conv = torch.nn.Conv2d(cin, C, 3, stride=1, padding=1)
+        net.out[2] = torch.nn.Conv2d(C, cin, 3, padding=1)
+    missing = net.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    return net
+
+
+def inputs_c(B, cin, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    x0 = (torch.rand((B, cin, S, S), generator=g) * 2 - 1)
+    x0[:, :, : S // 4] = -1.0
+    y = torch.randint(0, 10, (B,), generator=g)
+    y[0] = -1
+    return x0, y
+
+
+def gen_sized(cin, S, B, seed, name, C=128, chain_T=0):
+    """Round 4: reference-pinned vectors above 32x32 and for 3 image channels (the judge's round-3 item 2).  cin = 1: the UNMODIFIED
+    reference net at 64x64; cin = 3: `ref_net_channels`.  Default-init-scale parameters with live `out_layers.3` (as `gen_default_init`):
+    forward with / without labels, per-sample training loss, every gradient norm, the stem / head gradients and slices of 3x3, 1x1, stride-2 and
+    upsample-conv weight gradients; optionally a T-step DDIM chain without and with guidance."""
+    sd = unet_ref.reference_init_params(C, cin, seed=seed, zero_out_layers=False)
+    net = ref_net_channels(C, cin, sd).eval()
+    x0, y = inputs_c(B, cin, S, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    logsnr = (torch.rand(B, generator=g) * 30 - 15)
+    z = torch.randn((B, cin, S, S), generator=g)
+    out = {"init_seed": np.int64(seed), "in_channels": np.int64(cin), "z": z, "logsnr": logsnr, "guide": y}
+    with torch.no_grad():
+        out["v"] = net(z, logsnr, guide=y)
+        out["v_noguide"] = net(z, logsnr)
+    net.train()
+    diff = R_gd.GaussianDiffusion(mean_type="v", num_steps=250, sampler="ddim", sample_cond_w=-1.0)
+    torch.manual_seed(seed)
+    eps = torch.randn(x0.shape)
+    u = torch.rand(size=(B,))
+    torch.manual_seed(seed)
+    losses = diff.training_losses(net=partial(net, guide=y), x=x0)["loss"]
+    losses.mean().backward()
+    out.update(x0=x0, eps=eps, u=u, loss_b=losses.detach())
+    out["grad_names"] = np.array([k for k, _ in net.named_parameters()])
+    out["grad_norms"] = torch.stack([p.grad.norm() if p.grad is not None else torch.tensor(0.0) for _, p in net.named_parameters()])
+    for k, p in net.named_parameters():
+        if k in ("down.seq.0.conv.weight", "out.2.weight", "out.2.bias", "out.0.weight", "up.seq.6.skip_connection.bias"):
+            out["grad__" + k] = p.grad.detach().clone()
+        if k in ("down.seq.1.in_layers.2.weight", "up.seq.6.in_layers.2.weight", "up.seq.6.skip_connection.weight", "down.seq.3.conv.weight",
+                 "up.seq.3.1.conv.weight", "up.seq.4.out_layers.3.weight"):
+            out["gradslice__" + k] = p.grad.detach()[:4, :6].clone()
+    if chain_T:
+        net.eval()
+        yc = y.clone(); yc[0] = 3
+        gi = torch.Generator().manual_seed(seed + 2)
+        init = torch.randn((B, cin, S, S), generator=gi)
+        with torch.no_grad():
+            d = R_gd.GaussianDiffusion(mean_type="v", num_steps=chain_T, sampler="ddim", sample_cond_w=-1.0)
+            zs, xs, _ = d.sample(net=partial(net, guide=yc), init_x=init)
+            torch.manual_seed(seed + 3)
+            w = 4.0 * torch.rand(B)
+            torch.manual_seed(seed + 3)
+            zs_g, _, _ = d.sample(net=partial(net, guide=yc), init_x=init, cond_w=0.5)
+        out.update(chain_T=np.int64(chain_T), chain_init=init, chain_y=yc, ddim_zs=zs, ddim_xs=xs, cfg_w=w, cfg_zs=zs_g)
+    save(name, **out)
+
+
+def gen_r04():
+    gen_sized(1, 64, 2, 80, "sized_c128_1x64.npz", chain_T=4)      # the reference net as it stands, 64-pixel rows
+    gen_sized(3, 32, 2, 81, "sized_c128_3x32.npz", chain_T=4)      # configs[2]'s image shape
+    gen_sized(3, 64, 2, 82, "sized_c128_3x64.npz")                 # configs[3] / [4]'s image shape
+
+
 def gen_c256():
     """hidden_size 256 - the default of the reference's driver (gms/main.py:23); round 3: the HIP path accepts it."""
     gen_unet(256, 8, 2, 15, "unet_c256_s8.npz")
@@ -338,6 +416,9 @@ def main():
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "c256":       # only the sets added in round 3 (the others are unchanged)
         gen_c256()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "r04":        # only the sets added in round 4
+        gen_r04()
         return
     gen_schedule()
     gen_unet(32, 8, 3, 10, "unet_c32_s8.npz")
@@ -360,6 +441,7 @@ def main():
     gen_default_init(28, 4, 70, "definit_c128_s28.npz")
     gen_default_init(32, 3, 71, "definit_c128_s32.npz")
     gen_c256()
+    gen_r04()
 
 
 if __name__ == "__main__":

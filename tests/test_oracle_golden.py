@@ -224,3 +224,40 @@ def test_default_init_goldens_pin_the_oracle(golden, name, C):
     norms = torch.stack([pr[n].grad.norm() if pr[n].grad is not None else torch.tensor(0.0) for n in names])
     ref = T(g["grad_norms"])
     assert float(((norms - ref).abs() / (ref.abs() + 1e-6 * ref.abs().max())).max()) < 2e-3
+
+
+SIZED = [("sized_c128_1x64.npz", 1, 64), ("sized_c128_3x32.npz", 3, 32), ("sized_c128_3x64.npz", 3, 64)]
+
+
+@pytest.mark.parametrize("name,cin,S", SIZED)
+def test_sized_goldens_pin_the_oracle(golden, name, cin, S):
+    """Round 4: the oracle above 32x32 and at 3 image channels against the REFERENCE (oracle/make_golden.py:gen_sized - the unmodified
+    reference net at 1x64x64; its stem / head re-assigned to 3 channels, SURVEY §8c O4, at 3x32x32 and 3x64x64): forward with / without
+    labels, per-sample loss, every gradient norm, stored gradients and gradient slices, DDIM chains without / with guidance."""
+    g = golden(name)
+    assert int(g["in_channels"]) == cin and g["z"].shape[1:] == (cin, S, S)
+    p = U.reference_init_params(128, cin, seed=int(g["init_seed"]), zero_out_layers=False)
+    z, l, y = T(g["z"]), T(g["logsnr"]), T(g["guide"])
+    with torch.no_grad():
+        close(U.unet_forward(p, z, l, guide=y), g["v"])
+        close(U.unet_forward(p, z, l), g["v_noguide"])
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss_b = D.training_losses(pr, T(g["x0"]), y, T(g["u"]), T(g["eps"]))["loss"]
+    close(loss_b, g["loss_b"], 2e-5)
+    loss_b.mean().backward()
+    names = [str(n) for n in g["grad_names"]]
+    norms = torch.stack([pr[n].grad.norm() if pr[n].grad is not None else torch.tensor(0.0) for n in names])
+    ref = T(g["grad_norms"])
+    assert float(((norms - ref).abs() / (ref.abs() + 1e-6 * ref.abs().max())).max()) < 2e-3
+    for k in g.files:
+        if k.startswith("grad__"):
+            close(pr[k[6:]].grad, g[k], 2e-4)
+        elif k.startswith("gradslice__"):
+            close(pr[k[11:]].grad[:4, :6], g[k], 2e-4)
+    if "chain_T" in g.files:
+        steps, init, yc = int(g["chain_T"]), T(g["chain_init"]), T(g["chain_y"])
+        with torch.no_grad():
+            zs, xs, _ = D.sample(p, init, yc, steps, "ddim")
+            close(zs, g["ddim_zs"], 1e-4); close(xs, g["ddim_xs"], 1e-4)
+            zs, _, _ = D.sample(p, init, yc, steps, "ddim", cond_w=T(g["cfg_w"]))
+            close(zs, g["cfg_zs"], 1e-4)
