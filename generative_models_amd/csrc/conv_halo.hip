@@ -56,7 +56,15 @@ struct HaloParams {
     int stats_groups;                          // Cout/4
     int variant;                               // GMK_DEV_VARIANT (experiments)
     float inv_hp2, inv_h, inv_we, inv_w;       // reciprocals for exact small-integer division
+    // folded 1x1 skip convolution (kSkip kernels): out += wsk[n][:] . cat(sk0, sk1)[pixel][:] + bias2[n]
+    const void* sk0; const void* sk1; const void* wsk; const float* bias2;
+    int cs, sk_ktot, nsk0;                     // channels per skip source (128), total skip K (2 cs), first weight row
+    unsigned nbs, nbws;                        // bytes of one skip source / of the skip weight pack
 };
+
+// 8-KiB LDS slot (of the 14 the two halo half-buffers span) that holds half `hf` (pixels 128 hf .. 128 hf + 127) of dense sub-phase k
+// of the folded skip convolution: E0..E2 in buffer 0 (filled during the previous tile's last halo phase), E3..E5 and E6, E7 in buffer 1
+__host__ __device__ constexpr int skip_slot(int k, int hf) { return k < 3 ? 2 * k + hf : k < 6 ? 7 + 2 * (k - 3) + hf : 7 + 2 * (k - 6) + hf; }
 
 // sum over the 32 lanes of a half-wave with DPP; lanes 16..31 (and 48..63) end up holding the half's total
 __device__ __forceinline__ float half_wave_sum(float v) {
@@ -431,8 +439,22 @@ template <int N> struct IntTag { static constexpr int value = N; };
 // MFMA time, measured with per-tile s_memtime stamps in round 1).  Here a SIMD hosts one consumer (32 MFMAs + 24 ds_read_b128 per K-step: 0.75 reads
 // per MFMA instead of 1) and one producer, w and w+4 share a SIMD, and the consumer's epilogue stores no longer sit in the
 // same vmcnt queue as the DMA (no `fresh` bookkeeping).  One s_barrier per K-step, crossed by all 8 waves.
-template <typename T, bool kPrefetchW, int kShape = 32, bool kFuse = false>
+//
+// kSkip (round 4): `skip_connection(x) + h` of the up-path ResBlocks (reference simple_unet.py:174-186) as ONE launch.  conv2's K grows from
+// 9 x 128 to 9 x 128 + 256: in front of the two halo phases a tile contracts the 256 channels of torch.cat([x, skip]) (two 128-channel
+// sources, never concatenated) with the 1x1 skip weights, centre tap only.  Those K-steps have no tap reuse, so their pixel operand is laid
+// out DENSE (no halo), in sub-phases of 32 channels: 256 pixels x 64 B = 16 KiB = two 8-KiB slots (pixels 0..127 / 128..255) + an 8-KiB
+// weight tile [128 rows][32 k] - the DMA volume of an ordinary K-step at half its MFMA work, eight of them (E0..E7).  With 32-channel
+// sub-phases everything fits the 14 slots of the two halo half-buffers at an issue distance of two K-steps (64-channel sub-phases need 15):
+//   previous tile's last halo phase (reads buffer 1), taps 0..6:  E0, E1, E2 -> slots 0..5, H0 piece 6 -> slot 6
+//   e0: E3 -> 7, 8     e1: E4 -> 9, 10; H0[0] -> 0     e2: E5 -> 11, 12; H0[1] -> 1     e3: H0[2], H0[3] -> 2, 3
+//   e4: E6 -> 7, 8; H0[4] -> 4     e5: E7 -> 9, 10     e6: H0[5] -> 5     e7: -     then H0 (fills H1 into buffer 1) and H1 as before.
+// Every slot is re-used only behind the barrier that follows its last read.  64-byte rows: lane (row = lane >> 2, chunk = lane & 3) of a
+// DMA instruction writes 16 rows of 64 B; physical chunk c of row n holds logical chunk c ^ ((n >> 2) & 3), so the 16 rows a
+// ds_read_b128 lane group touches (consecutive n, one logical chunk) cover all 64 banks.  No residual, no half jobs in this form.
+template <typename T, bool kPrefetchW, int kShape = 32, bool kFuse = false, bool kSkip = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParams p) {
+    static_assert(!kSkip || (kPrefetchW && kShape == 16 && !kFuse), "the folded skip convolution is built on the plain 16x16x32 form");
     typedef typename Frag16<T>::type frag_t;
     typedef typename Frag16<T>::half_type half_t;
     constexpr int ES = 2;
@@ -719,6 +741,114 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             return;
         }
+        if constexpr (kSkip) {
+            // ---------------------------------------------------------------------------------------------------- folded skip convolution
+            const __amdgpu_buffer_rsrc_t rsk0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.sk0), 0, (int)p.nbs, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsk1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.sk1), 0, (int)p.nbs, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rswk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wsk), 0, (int)p.nbws, 0x00020000);
+            const int drow = lane >> 2;
+            const unsigned dchunk = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);      // logical chunk of this lane's physical chunk
+            const unsigned srow_b = (unsigned)p.cs * ES;
+            unsigned wdo[2];                    // dense weight tile: rows 32 pw + 16 u + drow of [cout][sk_ktot], 64 B of k per sub-phase (soffset)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                wdo[u] = (unsigned)(p.nsk0 + nblk + 32 * pw + 16 * u + drow) * (unsigned)p.sk_ktot * ES + dchunk;
+            // a tile's pixels are contiguous in memory (whole rows of the global row list): pixel px of tile tl is row tl * TP + px of the source
+            unsigned dv[2][2], dvn[2][2];       // [half][u]: this lane's pixel of its two instructions of a half-piece (current / next tile)
+            auto resolve_dense = [&](int tl, unsigned (&o)[2][2]) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int px = 128 * hf + 32 * pw + 16 * u + drow;
+                        const int m = tl * p.TP + px;
+                        o[hf][u] = (tl < p.ntiles && px < p.TP && m < p.M) ? (unsigned)m * srow_b + dchunk : kBadOff;
+                    }
+            };
+            auto issue_dense = [&](int k, int hf, const unsigned (&o)[2][2]) {      // half hf of sub-phase k (channels 32 k .. 32 k + 31 of the concatenation)
+                const unsigned koff_b = (unsigned)((32 * k) % p.cs) * ES;           // scalar: soffset
+                const bool second = 32 * k >= p.cs;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    GMK_LDS char* dst = (GMK_LDS char*)(smem + skip_slot(k, hf) * 8192 + (32 * pw + 16 * u) * 64);
+                    if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk1, (GMK_LDS void*)dst, 16, o[hf][u], koff_b, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk0, (GMK_LDS void*)dst, 16, o[hf][u], koff_b, 0, 0);
+                }
+            };
+            auto issue_wd = [&](int stage, int k) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + (32 * pw + 16 * u) * 64);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rswk, (GMK_LDS void*)dst, 16, wdo[u], (unsigned)k * 64u, 0, 0);
+                }
+            };
+            auto wait_vm = [&](int n) __attribute__((always_inline)) {      // n is a constant after unrolling
+                if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            };
+            int sq = 2;
+            int tile = job_tile(0);
+            // prologue: what the previous tile's last phase would have brought (E0..E2, H0 piece 6), then the first two dense weight tiles
+            resolve_dense(tile, dv);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) issue_dense(t >> 1, t & 1, dv);
+            resolve_piece(tile, 6); issue_fill(0, 0, 6);
+            issue_wd(0, 0);
+            issue_wd(1, 1);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // start-up barrier: weight tile 0 is in LDS
+            for (int k = 0; k < njobs; ++k) {
+                const int ntile = job_tile(k + 1);
+                // ---- dense sub-phases e0..e7: per step the weights of step e + 2 first, then the pixel pieces of the table above.
+                // At barrier e the weight tile of step e + 1 (first ops of step e - 1) must have landed; the pixel pieces issued behind it may fly.
+                auto pix_of = [](int e) { return e == 0 ? 4 : e == 1 ? 6 : e == 2 ? 6 : e == 3 ? 4 : e == 4 ? 6 : e == 5 ? 4 : e == 6 ? 2 : 0; };      // pixel-piece instructions this wave issues in step e
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    wait_vm(e == 0 ? 0 : pix_of(e - 1));
+                    __builtin_amdgcn_s_barrier();
+                    if (e + 2 < 8) issue_wd(sq, e + 2);
+                    else issue_w(sq, e + 2 - 8, 0, -1);
+                    if (e == 0) { issue_dense(3, 0, dv); issue_dense(3, 1, dv); }
+                    if (e == 1) { issue_dense(4, 0, dv); issue_dense(4, 1, dv); resolve_piece(tile, 0); issue_fill(0, 0, 0); }
+                    if (e == 2) { issue_dense(5, 0, dv); issue_dense(5, 1, dv); resolve_piece(tile, 1); issue_fill(0, 0, 1); }
+                    if (e == 3) { resolve_piece(tile, 2); issue_fill(0, 0, 2); resolve_piece(tile, 3); issue_fill(0, 0, 3); }
+                    if (e == 4) { issue_dense(6, 0, dv); issue_dense(6, 1, dv); resolve_piece(tile, 4); issue_fill(0, 0, 4); }
+                    if (e == 5) { issue_dense(7, 0, dv); issue_dense(7, 1, dv); }
+                    if (e == 6) { resolve_piece(tile, 5); issue_fill(0, 0, 5); }
+                    sq = sq == 2 ? 0 : sq + 1;
+                }
+                // ---- halo phase 0 (buffer 0), filling phase 1 into buffer 1
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    wait_vm(tap == 0 || tap == 8 ? 0 : 2);
+                    __builtin_amdgcn_s_barrier();
+                    if (tap < 7) { issue_w(sq, tap + 2, 0, -1); issue_fill(1, 1, tap); }
+                    else issue_w(sq, tap - 7, 1, -1);
+                    sq = sq == 2 ? 0 : sq + 1;
+                }
+                // ---- halo phase 1 (buffer 1), bringing the next tile's E0..E2 and H0 piece 6 into buffer 0
+                resolve_dense(ntile, dvn);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    wait_vm(tap == 0 || tap == 8 ? 0 : 2);
+                    __builtin_amdgcn_s_barrier();
+                    if (tap < 7) issue_w(sq, tap + 2, 1, -1);
+                    else issue_wd(sq, tap - 7);                                   // the next job's first two dense weight tiles
+                    if (tap < 6) issue_dense(tap >> 1, tap & 1, dvn);
+                    if (tap == 6) { resolve_piece(ntile, 6); issue_fill(0, 0, 6); }
+                    sq = sq == 2 ? 0 : sq + 1;
+                }
+                tile = ntile;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) dv[hf][u] = dvn[hf][u];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the speculative DMA before the LDS is released
+            return;
+        }
         const __amdgpu_buffer_rsrc_t rsr =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
         // Residual hand-over (whole jobs with a residual): the consumers have no registers to keep the residual tile's loads in flight under
@@ -854,6 +984,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             wt[set][0] = *reinterpret_cast<const frag_t*>(Wb + coff);
             wt[set][1] = *reinterpret_cast<const frag_t*>(Wb + 2048 + coff);
         };
+        // folded skip convolution: 64-byte rows (32 channels); this lane's byte offset inside a half-piece / a dense weight tile
+        const int hfs = __builtin_amdgcn_readfirstlane(wave) >> 1;                 // which 128-pixel half this wave's pixels are in
+        const int d_off = (((wave & 1) * 64 + r16) << 6) + ((q ^ ((r16 >> 2) & 3)) << 4);
+        const int dw_off = kWOFF + (r16 << 6) + ((q ^ ((r16 >> 2) & 3)) << 4);
+        auto load_wt_d = [&](int stg, int pair, int set) {                         // channel blocks 2 pair, 2 pair + 1 of a dense weight tile
+            int o = dw_off;
+            asm volatile("" : "+v"(o));
+            const char* Wb = smem + stg * kWST + pair * 2048 + o;
+            wt[set][0] = *reinterpret_cast<const frag_t*>(Wb);
+            wt[set][1] = *reinterpret_cast<const frag_t*>(Wb + 1024);
+        };
         auto run_job = [&](auto ncb_tag, int tile, int chalf, int next_boff) {
             constexpr int NCB = decltype(ncb_tag)::value;          // 8: whole job, 4: half job
             constexpr int NG = NCB / 2;                            // groups (channel-block pairs) per k2 half
@@ -904,7 +1045,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                             st = st == 2 ? 0 : st + 1;
                             if (tap < 8) { addr(tap + 1); load_px(hbuf, 0, 0, 0, 4); }
                             if (tap == 8 && ph + 1 == nph) b_off = next_boff;
-                            if (kPrefetchW) load_wt(st, 0, 0, 0);
+                            if (kSkip && tap == 8) {                   // a job's last halo step is followed by the next job's first DENSE step
+                                if (ph + 1 == nph) load_wt_d(st, 0, 0); else load_wt(st, 0, 0, 0);
+                            } else if (kPrefetchW) load_wt(st, 0, 0, 0);
                         }
                         if (kFirst && tap == 0 && k2 == 0) mfma_group(pair, g & 1, k2, IntTag<1>{}); else mfma_group(pair, g & 1, k2, IntTag<0>{});
                         // one read per MFMA where there are reads to hide; the address VALU of the tap's last group rides along
@@ -933,8 +1076,47 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 }
                 hbuf ^= 1;
             };
-            phase(IntTag<1>{}, 0);
-            for (int ph = 1; ph < nph; ++ph) phase(IntTag<0>{}, ph);
+            if constexpr (kSkip) {
+                // ---- the folded 1x1 skip convolution: eight dense K-steps of 32 channels in front of the halo phases (see the kernel's
+                // header).  Per step: 4 pixel fragments (this wave's 64 pixels, one k chunk per lane) after the barrier, then 4 groups of
+                // 8 MFMAs (2 channel blocks x 4 pixel blocks) with the next group's weight fragments read underneath.
+                if constexpr (NCB == 8) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        __builtin_amdgcn_s_barrier();
+                        {
+                            int o = d_off;
+                            asm volatile("" : "+v"(o));          // per-step addresses stay out of loop-invariant hoisting (registers)
+                            const char* Eb = smem + (skip_slot(e, 0) + hfs) * 8192 + o;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) px[0][i] = *reinterpret_cast<const frag_t*>(Eb + i * 1024);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const bool last = g == 3;
+                            if (!last) load_wt_d(st, g + 1, (g + 1) & 1);
+                            else {
+                                st = st == 2 ? 0 : st + 1;
+                                if (e < 7) load_wt_d(st, 0, 0);              // the next dense step's first weight fragments (landed at this barrier)
+                                else load_wt(st, 0, 0, 0);                   // ... or those of halo phase 0, tap 0
+                            }
+                            if (e == 0) mfma_group(g, g & 1, 0, IntTag<1>{}); else mfma_group(g, g & 1, 0, IntTag<0>{});
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                for (int ph = 0; ph < nph; ++ph) phase(IntTag<0>{}, ph);
+            } else {
+                phase(IntTag<1>{}, 0);
+                for (int ph = 1; ph < nph; ++ph) phase(IntTag<0>{}, ph);
+            }
             asm volatile("" ::: "memory");
             // residual hand-over (see the producers): units 0..6 of the tile's residual arrive in the halo buffer this job's last phase
             // just finished with; unit 7 (channels 112..127) is loaded from memory here, ahead of the two barriers that hide its latency
@@ -962,6 +1144,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             if (p.bias) {
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) load4(p.bias + cbase + cb * 16 + 4 * q, bz[cb]);
+            }
+            if constexpr (kSkip) {          // the skip convolution's own bias (simple_unet.py:177-179)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    float t2[4];
+                    load4(p.bias2 + cbase + cb * 16 + 4 * q, t2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bz[cb][e] += t2[e];
+                }
             }
 #pragma unroll
             for (int ip = 0; ip < 2; ++ip) {
@@ -1028,7 +1219,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         }
         resolve_centres(job_tile(0));
         __builtin_amdgcn_s_barrier();                          // start-up barrier: weight tile 0 is in LDS
-        if (kPrefetchW) load_wt(0, 0, 0, 0);
+        if (kSkip) load_wt_d(0, 0, 0);
+        else if (kPrefetchW) load_wt(0, 0, 0, 0);
         for (int k = 0; k < njobs; ++k) {
             const int tile = job_tile(k), hc = job_half(k), ntile = job_tile(k + 1), nhc = job_half(k + 1);
             const int next_boff = kWOFF + ((nhc >= 0 ? nhc * 64 : 0) + r16) * 128;
@@ -1430,4 +1622,51 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     if (dtype == GMK_F16) launch(f16_t{});
     else launch(bf16_t{});
     return kind == 0 ? 1 : 2;
+}
+
+// ---- conv2 + folded 1x1 skip convolution of an up-path ResBlock (reference simple_unet.py:172-186) --------------------------------
+static int skipfold_geometry(int B, int H, int W, int c0, int cs, int cout, int w_rows, int out_cstride, int min_tiles, HaloGeometry* g) {
+    if (c0 != 128 || cs != 128 || cout != 128) return 0;          // two halo phases + eight 32-channel sub-phases: the C = 128 nets
+    if (!gmk_halo_geometry(B, H, W, c0, 0, w_rows, cout, out_cstride, min_tiles, 0, 0, g)) return 0;
+    return (int64_t)g->M * cs * 2 < 0xFFFF0000ll;
+}
+
+extern "C" int gmk_conv3x3_skipfold_ok(int B, int H, int W, int c0, int cs, int cout) {
+    const int force = gmk_kernel_choice(0, "GMK_CONV_KERNEL");
+    if (force != 0 && force != 3) return 0;
+    HaloGeometry g;
+    return skipfold_geometry(B, H, W, c0, cs, cout, cout, cout, force == 3 ? 1 : 32, &g);
+}
+
+extern "C" int gmk_conv3x3_skipfold(const void* src, int c0, int B, int H, int W, const void* w, int w_rows, int n0, int cout,
+                                    const float* bias, const void* sk0, const void* sk1, int cs, const void* wsk, int wsk_rows, int nsk0,
+                                    const float* bias_sk, void* out, int out_cstride, int dtype, void* stream) {
+    GMK_REQUIRE(src && w && sk0 && sk1 && wsk && bias && bias_sk && out, "gmk_conv3x3_skipfold: null pointer");
+    GMK_REQUIRE(dtype == GMK_BF16 || dtype == GMK_F16, "gmk_conv3x3_skipfold: 16-bit types only (dtype %d)", dtype);
+    GMK_REQUIRE(n0 >= 0 && n0 + cout <= w_rows && nsk0 >= 0 && nsk0 + cout <= wsk_rows && out_cstride >= cout,
+                "gmk_conv3x3_skipfold: bad output channels n0=%d nsk0=%d cout=%d", n0, nsk0, cout);
+    const int force = gmk_kernel_choice(0, "GMK_CONV_KERNEL");
+    HaloGeometry g;
+    GMK_REQUIRE(skipfold_geometry(B, H, W, c0, cs, cout, w_rows, out_cstride, force == 3 ? 1 : 32, &g),
+                "gmk_conv3x3_skipfold: shape B=%d %dx%d c0=%d cs=%d cout=%d is not foldable (ask gmk_conv3x3_skipfold_ok first)", B, H, W, c0, cs, cout);
+    HaloParams p = {};
+    p.src0 = src; p.src1 = nullptr; p.c0 = c0; p.c1 = 0; p.ktot = c0;
+    p.shift = 0; p.pmask = 0;
+    p.B = B; p.H = H; p.W = W; p.WE = W + 2; p.R = g.R; p.TP = g.TP; p.ntiles = (int)g.ntiles; p.rows_total = (int)g.rows_total;
+    p.w = w; p.w_tap_stride_b = (unsigned)w_rows * (unsigned)c0 * 2u; p.n0 = n0;
+    p.bias = bias; p.emb = nullptr; p.emb_stride = 0; p.residual = nullptr; p.out = out; p.out_cstride = out_cstride;
+    p.M = (int)g.M;
+    p.nb0 = (unsigned)g.nb0; p.nb1 = 0; p.nbw = (unsigned)g.nbw; p.nbo = (unsigned)g.nbo;
+    p.stats = nullptr; p.stats_groups = out_cstride / 4;
+    p.variant = gmk_kernel_choice(3, "GMK_DEV_VARIANT") & 0xFF;
+    p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 2); p.inv_w = 1.0f / (float)W;
+    p.sk0 = sk0; p.sk1 = sk1; p.wsk = wsk; p.bias2 = bias_sk; p.cs = cs; p.sk_ktot = 2 * cs; p.nsk0 = nsk0;
+    p.nbs = (unsigned)((int64_t)g.M * cs * 2); p.nbws = (unsigned)((int64_t)wsk_rows * 2 * cs * 2);
+    const int ncu = gmk_cu_limit();
+    dim3 grid((unsigned)(g.ntiles < ncu ? g.ntiles : ncu), cout / 128);
+    p.nfull = (int)g.ntiles; p.nhalf = 0;                          // no half jobs in this form
+    if (dtype == GMK_F16) conv3x3_halo_ws_kernel<f16_t, true, 16, false, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+    else conv3x3_halo_ws_kernel<bf16_t, true, 16, false, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+    gmk_note_kernel(7);
+    return gmk_check_launch("gmk_conv3x3_skipfold");
 }

@@ -403,7 +403,11 @@ class SimpleUnet(nn.Module):
         gpc = self._g2 if len(srcs) == 2 else self._g1           # GroupNorm(32, cin): 16 groups per C-channel source
         skip = {}
         fwd_side = len(srcs) == 2 and ops.FWD_SIDE and ops.WGRAD_STREAM
-        if len(srcs) == 2:
+        # `skip_connection(x) + h` (simple_unet.py:174-186) as ONE launch where the kernel takes the shape: no 1x1 launch, no skip tensor in HBM
+        fold = len(srcs) == 2 and not self._narrow and ops.conv_skipfold_ok(srcs[0], srcs)
+        if fold:
+            fwd_side = False
+        elif len(srcs) == 2:
             # The 1x1 skip convolution (HBM-bound) only needs the block input.  With GMK_FWD_SIDE=1 it runs on the side stream beside
             # GroupNorm / conv1 / GroupNorm and is joined in front of conv2 (-1 % of a forward).  OFF by default: that co-residency
             # (conv_igemm_kernel's LDS staging next to the GroupNorm kernel) is where round 1's unexplained fault lived.
@@ -418,6 +422,9 @@ class SimpleUnet(nn.Module):
         wf1, _ = self._packs[f"{name}.in_layers.2"]
         wf2, _ = self._packs[f"{name}.out_layers.3"]
         dropping = self.dropout > 0.0 and self.training and name != "up.seq.3.0"
+        def conv2_folded(a2):
+            wfs, _ = self._packs[f"{name}.skip_connection"]
+            return ops.conv3x3_skipfold(a2, wf2, P[f"{name}.out_layers.3.bias"], srcs, wfs, P[f"{name}.skip_connection.bias"])
         if ctx is None and not dropping and ops.GN_FUSE and not self._narrow and ops.conv_gn_fusable(srcs):
             # Inference (nothing is kept for a backward pass): GroupNorm-apply + SiLU run inside the convolutions' producer waves.
             # A statistics-only launch reads the raw tensor once and leaves the per-(sample, channel) affine tables; the normalised
@@ -428,6 +435,13 @@ class SimpleUnet(nn.Module):
                 ops.gn_stats(s, P[f"{name}.in_layers.0.weight"][i * C:(i + 1) * C], P[f"{name}.in_layers.0.bias"][i * C:(i + 1) * C], gpc,
                              tsc[:, i * C:(i + 1) * C], tsh[:, i * C:(i + 1) * C])
             h = self._conv(srcs, wf1, C, 3, ops.NORMAL, (H, W), gn=(tsc, tsh))
+            if fold and ops.SKIP_FOLD_OVER_FUSE:      # the fold and the in-convolution GroupNorm do not combine (yet): conv2's input is materialised
+                a2, _, _ = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], self._g1, xadd=eadd)
+                return conv2_folded(a2)
+            if fold:
+                run_skip_now = self._conv(srcs, self._packs[f"{name}.skip_connection"][0], C, 1, ops.NORMAL, (H, W),
+                                          bias=P[f"{name}.skip_connection.bias"])
+                skip["res"] = run_skip_now
             t2c = torch.empty((B, C), device=h.device, dtype=torch.float32)
             t2h = torch.empty_like(t2c)
             ops.gn_stats(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], self._g1, t2c, t2h, xadd=eadd)
@@ -453,14 +467,17 @@ class SimpleUnet(nn.Module):
             self._drop_counter += (h.numel() + 3) // 4
         a2, mean2, rstd2 = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], self._g1, dropout=drop,
                                            xadd=eadd)
-        if len(srcs) == 2:
-            res = skip["res"]
-            if fwd_side:
-                self._join_side()
-                res.record_stream(torch.cuda.current_stream())      # allocated on the side stream, consumed here
+        if fold:
+            out = conv2_folded(a2)
         else:
-            res = srcs[0]
-        out = self._conv([a2], wf2, C, 3, ops.NORMAL, (H, W), bias=P[f"{name}.out_layers.3.bias"], residual=res,
+            if len(srcs) == 2:
+                res = skip["res"]
+                if fwd_side:
+                    self._join_side()
+                    res.record_stream(torch.cuda.current_stream())      # allocated on the side stream, consumed here
+            else:
+                res = srcs[0]
+            out = self._conv([a2], wf2, C, 3, ops.NORMAL, (H, W), bias=P[f"{name}.out_layers.3.bias"], residual=res,
                              gn_stats=True)
         if ctx is not None:
             ctx[name] = (srcs, a, stats1, h, a2, (mean2, rstd2))

@@ -27,6 +27,8 @@ KERNEL_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_dma_kernel", 3: "conv3x3_
                 # same binary as 4, launched on the zero-stuffed gradient of a stride-2 conv: 4x the algorithmic MFMA work by
                 # construction, so the profile keeps it apart from the plain 3x3 convolutions
                 5: "conv3x3_halo_ws_kernel[zero-stuffed transposed conv]",
+                # conv2 of an up-path ResBlock with its 1x1 skip convolution folded in (K = 9 x 128 + 256): its own line in the profile
+                7: "conv3x3_halo_ws_kernel[+1x1 skip]",
                 # stride-2 data gradient where the halo kernel declines (fp32, small problems): four output-parity phase launches of the LDS-DMA kernel
                 6: "conv_igemm_dma_kernel[stride-2 dgrad phases]",
                 21: "gn_silu_fwd_reg_kernel", 22: "gn_silu_fwd_kernel", 23: "gn_silu_bwd_hybrid_kernel", 24: "gn_silu_bwd_kernel"}
@@ -151,6 +153,11 @@ GN_FUSE = os.environ.get("GMK_GN_FUSE", "1") != "0"            # inference: Grou
 # against the ~190 the consumer's MFMA stream leaves free on the shared SIMD) costs what the normalised tensor's round trip saved
 # (758 vs 747 us, 351 vs 341 us), at 16 x 16 more.  GMK_GN_FUSE_MIN_HW overrides the threshold.
 GN_FUSE_MIN_HW = int(os.environ.get("GMK_GN_FUSE_MIN_HW", "2048"))
+# `skip_connection(x) + h` of the up-path ResBlocks as one launch (gmk_conv3x3_skipfold; GMK_SKIP_FOLD=0: the 1x1 convolution as its own
+# launch + residual epilogue, the path of rounds 1-3, kept for A/B).  GMK_SKIP_FOLD_FUSE=fuse: where inference could instead apply conv2's
+# GroupNorm inside the convolution (64-pixel rows), prefer that to the fold (the two do not combine yet)
+SKIP_FOLD = os.environ.get("GMK_SKIP_FOLD", "1") != "0"
+SKIP_FOLD_OVER_FUSE = os.environ.get("GMK_SKIP_FOLD_FUSE", "fold") != "fuse"
 FWD_SIDE = os.environ.get("GMK_FWD_SIDE", "0") == "1"          # forward 1x1 skip convolutions on the side stream (simple_unet._res_fwd)
 WGRAD_STREAM = os.environ.get("GMK_WGRAD_STREAM", "1") != "0"    # weight gradients on a side stream beside the data-gradient chain (simple_unet._wgrad)
 
@@ -354,6 +361,33 @@ def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, 
               "conv_igemm")
     if part is not None and lib.gmk_last_kernel() == 3 and ho * wo >= 32:      # only the 8-compute-wave halo kernel emits statistics
         out._gn_stats = (part, tp, nt)     # consumed by gn_silu_fwd(out, ...)
+    return out
+
+
+def conv_skipfold_ok(src, skips):
+    """True if conv3x3(src) + conv1x1(cat(skips)) of these shapes runs as one launch (gmk_conv3x3_skipfold)."""
+    if not SKIP_FOLD or len(skips) != 2 or src.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    B, H, W, c0 = src.shape
+    return skips[0].shape[3] == skips[1].shape[3] and bool(lib.gmk_conv3x3_skipfold_ok(B, H, W, c0, skips[0].shape[3], 128))
+
+
+def conv3x3_skipfold(src, w, bias, skips, wsk, bias_sk, cout=128):
+    """out = conv3x3(src; w) + bias + conv1x1(cat(skips); wsk) + bias_sk in one launch: the `skip_connection(x) + h` of the up-path
+    ResBlocks (reference simple_unet.py:174-186) without the skip output ever reaching HBM."""
+    s0 = _chk(src, name="src")
+    k0, k1 = _chk(skips[0], s0.dtype, "skip0"), _chk(skips[1], s0.dtype, "skip1")
+    B, H, W, c0 = s0.shape
+    cs = k0.shape[3]
+    assert k0.shape == k1.shape == (B, H, W, cs)
+    _chk(w, s0.dtype, "w"); _chk(wsk, s0.dtype, "wsk")
+    assert w.numel() == 9 * cout * c0 and wsk.numel() == cout * 2 * cs, (w.numel(), wsk.numel())
+    _f32(bias, "bias"); _f32(bias_sk, "bias_sk")
+    assert bias.numel() == cout and bias_sk.numel() == cout
+    out = torch.empty((B, H, W, cout), device=s0.device, dtype=s0.dtype)
+    with _Timed("conv_igemm", 2.0 * B * H * W * cout * (9 * c0 + 2 * cs), _nbytes(s0, k0, k1, out)):
+        check(lib.gmk_conv3x3_skipfold(_p(s0), c0, B, H, W, _p(w), cout, 0, cout, _p(bias), _p(k0), _p(k1), cs, _p(wsk), cout, 0,
+                                       _p(bias_sk), _p(out), cout, _DT[s0.dtype], _s()), "conv3x3_skipfold")
     return out
 
 

@@ -35,7 +35,7 @@ extern "C" {
 int gmk_version(void);
 const char* gmk_last_error(void);
 /* profiling aid: which kernel the calling thread's last gmk_conv_igemm / gmk_conv_wgrad / gmk_gn_* call launched
- * (1 conv_igemm_kernel, 2 conv_igemm_dma_kernel, 3 conv3x3_halo_kernel, 4 conv3x3_halo_ws_kernel, 5 a halo kernel on the zero-stuffed source of GMK_CONV_TRANSPOSED2 (GMK_CONV_KERNEL=3), 6 the four parity-phase launches of the LDS-DMA kernel for GMK_CONV_TRANSPOSED2, 11 conv_wgrad_kernel,
+ * (1 conv_igemm_kernel, 2 conv_igemm_dma_kernel, 3 conv3x3_halo_kernel, 4 conv3x3_halo_ws_kernel, 7 conv3x3_halo_ws_kernel with the folded 1x1 skip convolution, 5 a halo kernel on the zero-stuffed source of GMK_CONV_TRANSPOSED2 (GMK_CONV_KERNEL=3), 6 the four parity-phase launches of the LDS-DMA kernel for GMK_CONV_TRANSPOSED2, 11 conv_wgrad_kernel,
  * 12 conv_wgrad_slots_kernel, 13 conv_wgrad_slots_ws_kernel, 21 gn_silu_fwd_reg_kernel, 22 gn_silu_fwd_kernel, 23 gn_silu_bwd_hybrid_kernel, 24 gn_silu_bwd_kernel) */
 int gmk_last_kernel(void);
 /* development aid: force kernel variants (0 = automatic; see GMK_CONV_KERNEL / GMK_WGRAD_KERNEL / GMK_GN_KERNEL); -1 = unset */
@@ -133,6 +133,18 @@ int gmk_conv_gn_fusable(int B, int H, int W, int c0, int c1, int cout);
  * Two gmk_conv_igemm calls would read the output gradient twice. */
 int gmk_conv1x1_pair(const void* src, int c, int B, int H, int W, const void* w, int w_rows, int n0, void* out_a, void* out_b,
                      int dtype, void* stream);
+/* conv2 of an up-path ResBlock with its 1x1 skip convolution folded in - `skip_connection(x) + h` of simple_unet.py:174-186 as ONE launch
+ * (the reference evaluates Conv2d(2C, C, 1) on torch.cat([x, skip]) and adds the result to out_layers' 3x3 convolution, :177-186):
+ *   out[b][y][x][n] = bias[n] + bias_sk[n] + sum_{tap,k} src[b][y+dy][x+dx][k] * w[tap][n0+n][k]
+ *                                          + sum_k cat(sk0, sk1)[b][y][x][k] * wsk[nsk0+n][k]
+ * src: NHWC, c0 channels (the GroupNorm+SiLU output, simple_unet.py:169-172); sk0 / sk1: the two NHWC halves of the block input, cs
+ * channels each; w: packed `[9][w_rows][c0]`, wsk: packed `[wsk_rows][2 cs]` (a w_fwd pack of the 1x1 convolution).  The skip output is
+ * never written to or read back from HBM and is added in fp32 (the two-launch path rounds it to 16 bits in between).  Shapes: where
+ * gmk_conv3x3_skipfold_ok(...) returns 1 (c0 = cs = cout = 128, a problem the LDS-halo kernel takes); otherwise the call fails. */
+int gmk_conv3x3_skipfold_ok(int B, int H, int W, int c0, int cs, int cout);
+int gmk_conv3x3_skipfold(const void* src, int c0, int B, int H, int W, const void* w, int w_rows, int n0, int cout,
+                         const float* bias, const void* sk0, const void* sk1, int cs, const void* wsk, int wsk_rows, int nsk0,
+                         const float* bias_sk, void* out, int out_cstride, int dtype, void* stream);
 /* statistics-only GroupNorm for the above: mean / rstd [B][groups] and the affine tables (columns [0, C) of rows of tab_stride
  * floats: a concatenated input passes the same table with a column offset); xadd as in gmk_gn_silu_fwd */
 int gmk_gn_stats(const void* x, const float* gamma, const float* beta, float* mean, float* rstd, float* tab_scale,

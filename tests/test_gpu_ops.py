@@ -633,3 +633,40 @@ def test_conv_with_fused_groupnorm_is_bit_identical(ops, B, S, two, res):
     if resid is not None:
         t = t + resid.float()
     assert float((out.float() - t).abs().max() / t.abs().max()) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("S,B", [(32, 2), (28, 3), (14, 5), (7, 9), (64, 1), (16, 70), (8, 37), (32, 80)])
+def test_skip_convolution_folded_into_conv2(ops, dtype, S, B):
+    """`skip_connection(x) + h` of the up-path ResBlocks (reference simple_unet.py:174-186) as ONE launch: conv3x3(a2) + conv1x1(cat(x, skip)) + both
+    biases.  Against torch fp32 on the rounded operands (1e-2 bar of the 16-bit mode; measured far below: fp32 accumulation of 9 x 128 + 256
+    products and ONE rounding) and against the two-launch path it replaces (1x1 convolution -> 16-bit tensor -> residual of conv2), which
+    differs only by that intermediate rounding.  Shapes: tiles inside one image (32, 64), tiles spanning images with a ragged last tile
+    (28: 252 of 256 pixels per tile; 14, 7, 8), more tiles than CUs (several jobs per workgroup: 16 x 70, 32 x 80)."""
+    from generative_models_amd._lib import lib
+    C = 128
+    a2 = q(rnd(B, C, S, S, seed=210), dtype)
+    xs = [q(rnd(B, C, S, S, seed=211 + i) * (1.0 + i), dtype) for i in range(2)]
+    w = q(rnd(C, C, 3, 3, seed=220) / math.sqrt(C * 9), dtype)
+    wsk = q(rnd(C, 2 * C, 1, 1, seed=221) / math.sqrt(2 * C), dtype)
+    bias, bias_sk = rnd(C, seed=222) * 0.1, rnd(C, seed=223) * 0.1
+    ref = F.conv2d(a2, w, bias, padding=1) + F.conv2d(torch.cat(xs, 1), wsk, bias_sk)
+    ad, xd = nhwc(a2, dtype), [nhwc(t, dtype) for t in xs]
+    wf = torch.empty(w.numel(), device="cuda", dtype=dtype); wsf = torch.empty(wsk.numel(), device="cuda", dtype=dtype)
+    ops.pack_conv_weight(w.cuda(), wf, None)
+    ops.pack_conv_weight(wsk.cuda(), wsf, None)
+    try:
+        lib.gmk_set_kernel_choice(3, -1, -1)                      # small problems too (the dispatcher asks for 32 tiles)
+        assert ops.conv_skipfold_ok(ad, xd)
+        out = ops.conv3x3_skipfold(ad, wf, bias.cuda(), xd, wsf, bias_sk.cuda())
+        assert lib.gmk_last_kernel() == 7
+        res = ops.conv_igemm(xd, wsf, C, 1, ops.NORMAL, (S, S), bias=bias_sk.cuda())
+        two = ops.conv_igemm([ad], wf, C, 3, ops.NORMAL, (S, S), bias=bias.cuda(), residual=res)
+        out2 = ops.conv3x3_skipfold(ad, wf, bias.cuda(), xd, wsf, bias_sk.cuda())
+    finally:
+        lib.gmk_set_kernel_choice(-1, -1, -1)
+    e_ref, e_two = rel_err(nchw(out), ref), rel_err(nchw(out), nchw(two))
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)           # spacing of the 16-bit type at the output scale
+    assert e_ref < 0.75 * ulp and e_ref <= rel_err(nchw(two), ref) + 1e-6, (e_ref, rel_err(nchw(two), ref))
+    assert e_two < 1.5 * ulp, e_two
+    assert torch.equal(out, out2)                                   # bit-reproducible
