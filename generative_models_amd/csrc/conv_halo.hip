@@ -62,9 +62,9 @@ struct HaloParams {
     unsigned nbs, nbws;                        // bytes of one skip source / of the skip weight pack
 };
 
-// 8-KiB LDS slot (of the 14 the two halo half-buffers span) that holds half `hf` (pixels 128 hf .. 128 hf + 127) of dense sub-phase k
-// of the folded skip convolution: E0..E2 in buffer 0 (filled during the previous tile's last halo phase), E3..E5 and E6, E7 in buffer 1
-__host__ __device__ constexpr int skip_slot(int k, int hf) { return k < 3 ? 2 * k + hf : k < 6 ? 7 + 2 * (k - 3) + hf : 7 + 2 * (k - 6) + hf; }
+// first of the two 8-KiB LDS slots (pixels 0..127 / 128..255) that hold dense sub-phase m (0..3) of a halo phase's four: slots of the
+// half-buffer that is being FILLED during that phase (see the kSkip kernel's header)
+__host__ __device__ constexpr int skip_slot(int m) { return m == 3 ? 0 : 2 * m; }
 
 // sum over the 32 lanes of a half-wave with DPP; lanes 16..31 (and 48..63) end up holding the half's total
 __device__ __forceinline__ float half_wave_sum(float v) {
@@ -441,17 +441,23 @@ template <int N> struct IntTag { static constexpr int value = N; };
 // same vmcnt queue as the DMA (no `fresh` bookkeeping).  One s_barrier per K-step, crossed by all 8 waves.
 //
 // kSkip (round 4): `skip_connection(x) + h` of the up-path ResBlocks (reference simple_unet.py:174-186) as ONE launch.  conv2's K grows from
-// 9 x 128 to 9 x 128 + 256: in front of the two halo phases a tile contracts the 256 channels of torch.cat([x, skip]) (two 128-channel
-// sources, never concatenated) with the 1x1 skip weights, centre tap only.  Those K-steps have no tap reuse, so their pixel operand is laid
-// out DENSE (no halo), in sub-phases of 32 channels: 256 pixels x 64 B = 16 KiB = two 8-KiB slots (pixels 0..127 / 128..255) + an 8-KiB
-// weight tile [128 rows][32 k] - the DMA volume of an ordinary K-step at half its MFMA work, eight of them (E0..E7).  With 32-channel
-// sub-phases everything fits the 14 slots of the two halo half-buffers at an issue distance of two K-steps (64-channel sub-phases need 15):
-//   previous tile's last halo phase (reads buffer 1), taps 0..6:  E0, E1, E2 -> slots 0..5, H0 piece 6 -> slot 6
-//   e0: E3 -> 7, 8     e1: E4 -> 9, 10; H0[0] -> 0     e2: E5 -> 11, 12; H0[1] -> 1     e3: H0[2], H0[3] -> 2, 3
-//   e4: E6 -> 7, 8; H0[4] -> 4     e5: E7 -> 9, 10     e6: H0[5] -> 5     e7: -     then H0 (fills H1 into buffer 1) and H1 as before.
-// Every slot is re-used only behind the barrier that follows its last read.  64-byte rows: lane (row = lane >> 2, chunk = lane & 3) of a
-// DMA instruction writes 16 rows of 64 B; physical chunk c of row n holds logical chunk c ^ ((n >> 2) & 3), so the 16 rows a
-// ds_read_b128 lane group touches (consecutive n, one logical chunk) cover all 64 banks.  No residual, no half jobs in this form.
+// 9 x 128 to 9 x 128 + 256: a tile also contracts the 256 channels of torch.cat([x, skip]) (two 128-channel sources, never concatenated)
+// with the 1x1 skip weights, centre tap only.  Those K-steps have no tap reuse, so their pixel operand is laid out DENSE (no halo), in
+// sub-phases of 32 channels: 256 pixels x 64 B = 16 KiB = two 8-KiB slots + an 8-KiB weight tile [128 rows][32 k] - eight short K-steps
+// E0..E7 of half the MFMA work.  They are INTERLEAVED with the halo taps, four per halo phase, in the slots of the half-buffer that phase is
+// filling (which stay free until the next phase's pieces are issued - later than in the plain kernel, but still two K-steps ahead):
+//   K-steps of phase ph (reads buffer ph, fills buffer ph ^ 1):   t0 t1 t2 t3 e0 t4 e1 t5 e2 t6 e3 t7 t8      (e_m = sub-phase 4 ph + m)
+//   pixel pieces issued in:   t0: E(4ph+0) -> slots 0,1    t1: E(4ph+1) -> 2,3    t2: E(4ph+2) -> 4,5    t3: NEXT[6] -> 6
+//                             t4: E(4ph+3) -> 0,1 (e0 is done)    t5: NEXT[2,3] -> 2,3    t6: NEXT[4,5] -> 4,5    t7: NEXT[0,1] -> 0,1
+//   (NEXT = the next halo phase's pieces: phase 1 of this tile, or phase 0 of the next tile), weights of the step after next in every step.
+// Every dense piece is issued at least four K-steps before its step and every slot is re-used only behind the barrier that follows its last
+// read.  (The first form of the round put the eight dense steps in ONE block in front of the halo phases: 17 of a tile's 31 pieces then had
+// to arrive within eight 512-cycle steps, an issue distance of two short steps could not cover the HBM latency, and the block took 8.0 us
+// per tile for 2.0 us of MFMA work - 979 -> 796 us per launch at 32 x 32, B = 2048; DESIGN.md section 7b.2 has both measurements.)
+
+// 64-byte rows: lane (row = lane >> 2, chunk = lane & 3) of a DMA instruction writes 16 rows of 64 B; physical chunk c of row n holds logical
+// chunk c ^ ((n >> 2) & 3), so the 16 rows a ds_read_b128 lane group touches (consecutive n, one logical chunk) cover all 64 banks.
+// No residual, no half jobs in this form.
 template <typename T, bool kPrefetchW, int kShape = 32, bool kFuse = false, bool kSkip = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParams p) {
     static_assert(!kSkip || (kPrefetchW && kShape == 16 && !kFuse), "the folded skip convolution is built on the plain 16x16x32 form");
@@ -754,26 +760,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             for (int u = 0; u < 2; ++u)
                 wdo[u] = (unsigned)(p.nsk0 + nblk + 32 * pw + 16 * u + drow) * (unsigned)p.sk_ktot * ES + dchunk;
             // a tile's pixels are contiguous in memory (whole rows of the global row list): pixel px of tile tl is row tl * TP + px of the source
-            unsigned dv[2][2], dvn[2][2];       // [half][u]: this lane's pixel of its two instructions of a half-piece (current / next tile)
-            auto resolve_dense = [&](int tl, unsigned (&o)[2][2]) {
+            unsigned dv[2][2];                  // [half][u]: this lane's pixel of its two instructions of a half-piece
+            auto resolve_dense = [&](int tl) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int px = 128 * hf + 32 * pw + 16 * u + drow;
                         const int m = tl * p.TP + px;
-                        o[hf][u] = (tl < p.ntiles && px < p.TP && m < p.M) ? (unsigned)m * srow_b + dchunk : kBadOff;
+                        dv[hf][u] = (tl < p.ntiles && px < p.TP && m < p.M) ? (unsigned)m * srow_b + dchunk : kBadOff;
                     }
             };
-            auto issue_dense = [&](int k, int hf, const unsigned (&o)[2][2]) {      // half hf of sub-phase k (channels 32 k .. 32 k + 31 of the concatenation)
+            auto issue_dense = [&](int fb, int slot, int k) {      // sub-phase k (channels 32 k .. 32 k + 31 of the concatenation): both halves, 4 instructions
                 const unsigned koff_b = (unsigned)((32 * k) % p.cs) * ES;           // scalar: soffset
                 const bool second = 32 * k >= p.cs;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    GMK_LDS char* dst = (GMK_LDS char*)(smem + skip_slot(k, hf) * 8192 + (32 * pw + 16 * u) * 64);
-                    if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk1, (GMK_LDS void*)dst, 16, o[hf][u], koff_b, 0, 0);
-                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk0, (GMK_LDS void*)dst, 16, o[hf][u], koff_b, 0, 0);
-                }
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        GMK_LDS char* dst = (GMK_LDS char*)(smem + fb * kHB + (slot + hf) * 8192 + (32 * pw + 16 * u) * 64);
+                        if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk1, (GMK_LDS void*)dst, 16, dv[hf][u], koff_b, 0, 0);
+                        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk0, (GMK_LDS void*)dst, 16, dv[hf][u], koff_b, 0, 0);
+                    }
             };
             auto issue_wd = [&](int stage, int k) {
 #pragma unroll
@@ -782,69 +790,54 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rswk, (GMK_LDS void*)dst, 16, wdo[u], (unsigned)k * 64u, 0, 0);
                 }
             };
+            // weight tile of step i (0..12, or 13 / 14 = steps 0 / 1 of the following phase) of phase ph: steps 4, 6, 8, 10 are the dense ones
+            auto issue_weights = [&](int stage, int ph, int i) __attribute__((always_inline)) {
+                if (i >= 13) { i -= 13; ph ^= 1; }                               // (the next job runs the same convolution: same weights)
+                if (i == 4 || i == 6 || i == 8 || i == 10) issue_wd(stage, 4 * ph + (i - 4) / 2);
+                else issue_w(stage, i < 4 ? i : i == 5 ? 4 : i == 7 ? 5 : i == 9 ? 6 : i == 11 ? 7 : 8, ph, -1);
+            };
             auto wait_vm = [&](int n) __attribute__((always_inline)) {      // n is a constant after unrolling
                 if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             };
             int sq = 2;
             int tile = job_tile(0);
-            // prologue: what the previous tile's last phase would have brought (E0..E2, H0 piece 6), then the first two dense weight tiles
-            resolve_dense(tile, dv);
 #pragma unroll
-            for (int t = 0; t < 6; ++t) issue_dense(t >> 1, t & 1, dv);
-            resolve_piece(tile, 6); issue_fill(0, 0, 6);
-            issue_wd(0, 0);
-            issue_wd(1, 1);
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                      // start-up barrier: weight tile 0 is in LDS
+            for (int j = 0; j < 7; ++j) { resolve_piece(tile, j); issue_fill(0, 0, j); }
+            issue_w(0, 0, 0, -1);
+            issue_w(1, 1, 0, -1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // start-up barrier: weight tile 0 and the first halo half are in LDS
             for (int k = 0; k < njobs; ++k) {
                 const int ntile = job_tile(k + 1);
-                // ---- dense sub-phases e0..e7: per step the weights of step e + 2 first, then the pixel pieces of the table above.
-                // At barrier e the weight tile of step e + 1 (first ops of step e - 1) must have landed; the pixel pieces issued behind it may fly.
-                auto pix_of = [](int e) { return e == 0 ? 4 : e == 1 ? 6 : e == 2 ? 6 : e == 3 ? 4 : e == 4 ? 6 : e == 5 ? 4 : e == 6 ? 2 : 0; };      // pixel-piece instructions this wave issues in step e
+                resolve_dense(tile);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    wait_vm(e == 0 ? 0 : pix_of(e - 1));
-                    __builtin_amdgcn_s_barrier();
-                    if (e + 2 < 8) issue_wd(sq, e + 2);
-                    else issue_w(sq, e + 2 - 8, 0, -1);
-                    if (e == 0) { issue_dense(3, 0, dv); issue_dense(3, 1, dv); }
-                    if (e == 1) { issue_dense(4, 0, dv); issue_dense(4, 1, dv); resolve_piece(tile, 0); issue_fill(0, 0, 0); }
-                    if (e == 2) { issue_dense(5, 0, dv); issue_dense(5, 1, dv); resolve_piece(tile, 1); issue_fill(0, 0, 1); }
-                    if (e == 3) { resolve_piece(tile, 2); issue_fill(0, 0, 2); resolve_piece(tile, 3); issue_fill(0, 0, 3); }
-                    if (e == 4) { issue_dense(6, 0, dv); issue_dense(6, 1, dv); resolve_piece(tile, 4); issue_fill(0, 0, 4); }
-                    if (e == 5) { issue_dense(7, 0, dv); issue_dense(7, 1, dv); }
-                    if (e == 6) { resolve_piece(tile, 5); issue_fill(0, 0, 5); }
-                    sq = sq == 2 ? 0 : sq + 1;
-                }
-                // ---- halo phase 0 (buffer 0), filling phase 1 into buffer 1
+                for (int ph = 0; ph < 2; ++ph) {
+                    const int fb = ph ^ 1;                     // the half-buffer this phase fills
+                    // NEXT[j]: piece j of the next halo phase (phase 1 of this tile; in phase 1, phase 0 of the next job's tile)
+                    auto next_piece = [&](int j) __attribute__((always_inline)) {
+                        if (ph == 1) resolve_piece(ntile, j);
+                        issue_fill(fb, ph ^ 1, j);
+                    };
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    wait_vm(tap == 0 || tap == 8 ? 0 : 2);
-                    __builtin_amdgcn_s_barrier();
-                    if (tap < 7) { issue_w(sq, tap + 2, 0, -1); issue_fill(1, 1, tap); }
-                    else issue_w(sq, tap - 7, 1, -1);
-                    sq = sq == 2 ? 0 : sq + 1;
-                }
-                // ---- halo phase 1 (buffer 1), bringing the next tile's E0..E2 and H0 piece 6 into buffer 0
-                resolve_dense(ntile, dvn);
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    wait_vm(tap == 0 || tap == 8 ? 0 : 2);
-                    __builtin_amdgcn_s_barrier();
-                    if (tap < 7) issue_w(sq, tap + 2, 1, -1);
-                    else issue_wd(sq, tap - 7);                                   // the next job's first two dense weight tiles
-                    if (tap < 6) issue_dense(tap >> 1, tap & 1, dvn);
-                    if (tap == 6) { resolve_piece(ntile, 6); issue_fill(0, 0, 6); }
-                    sq = sq == 2 ? 0 : sq + 1;
+                    for (int i = 0; i < 13; ++i) {
+                        // pixel-piece instructions of the previous step may still fly; its weights (for step i + 1) and everything older have landed
+                        wait_vm(i == 0 ? 0 : i == 4 ? 2 : (i == 1 || i == 2 || i == 3 || i == 6 || i == 8 || i == 10 || i == 12) ? 4 : 0);
+                        __builtin_amdgcn_s_barrier();
+                        issue_weights(sq, ph, i + 2);
+                        if (i == 0) issue_dense(fb, skip_slot(0), 4 * ph + 0);
+                        if (i == 1) issue_dense(fb, skip_slot(1), 4 * ph + 1);
+                        if (i == 2) issue_dense(fb, skip_slot(2), 4 * ph + 2);
+                        if (i == 3) next_piece(6);
+                        if (i == 5) issue_dense(fb, skip_slot(3), 4 * ph + 3);
+                        if (i == 7) { next_piece(2); next_piece(3); }
+                        if (i == 9) { next_piece(4); next_piece(5); }
+                        if (i == 11) { next_piece(0); next_piece(1); }
+                        sq = sq == 2 ? 0 : sq + 1;
+                    }
                 }
                 tile = ntile;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) dv[hf][u] = dvn[hf][u];
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the speculative DMA before the LDS is released
             return;
@@ -1027,6 +1020,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 constexpr int kFirst = decltype(first_tag)::value;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
+                    const bool dense_after = kSkip && NCB == 8 && tap >= 3 && tap <= 6;      // a dense sub-phase of the folded skip convolution follows this tap
                     __builtin_amdgcn_s_barrier();
                     if (tap == 0) { addr(0); load_px(hbuf, 0, 0, 0, 4); }      // the phase's halo only became valid with this barrier
                     if (!kPrefetchW) load_wt(st, 0, 0, 0);
@@ -1043,15 +1037,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         if (k2 == 0 && pair == NG - 1) load_px(hbuf, 1, 1, 2, 4);
                         if (last) {
                             st = st == 2 ? 0 : st + 1;
-                            if (tap < 8) { addr(tap + 1); load_px(hbuf, 0, 0, 0, 4); }
+                            if (tap < 8 && !dense_after) { addr(tap + 1); load_px(hbuf, 0, 0, 0, 4); }
                             if (tap == 8 && ph + 1 == nph) b_off = next_boff;
-                            if (kSkip && tap == 8) {                   // a job's last halo step is followed by the next job's first DENSE step
-                                if (ph + 1 == nph) load_wt_d(st, 0, 0); else load_wt(st, 0, 0, 0);
-                            } else if (kPrefetchW) load_wt(st, 0, 0, 0);
+                            if (dense_after) load_wt_d(st, 0, 0);      // the dense step's first weight fragments (landed at this barrier)
+                            else if (kPrefetchW) load_wt(st, 0, 0, 0);
                         }
                         if (kFirst && tap == 0 && k2 == 0) mfma_group(pair, g & 1, k2, IntTag<1>{}); else mfma_group(pair, g & 1, k2, IntTag<0>{});
                         // one read per MFMA where there are reads to hide; the address VALU of the tap's last group rides along
-                        if (last && tap < 8) {
+                        if (last && tap < 8 && !dense_after) {
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1073,50 +1066,60 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                }
-                hbuf ^= 1;
-            };
-            if constexpr (kSkip) {
-                // ---- the folded 1x1 skip convolution: eight dense K-steps of 32 channels in front of the halo phases (see the kernel's
-                // header).  Per step: 4 pixel fragments (this wave's 64 pixels, one k chunk per lane) after the barrier, then 4 groups of
-                // 8 MFMAs (2 channel blocks x 4 pixel blocks) with the next group's weight fragments read underneath.
-                if constexpr (NCB == 8) {
+                    if constexpr (kSkip && NCB == 8) {
+                        if (dense_after) {
+                            // ---- dense sub-phase m = tap - 3 of this phase (32 channels of torch.cat([x, skip]) x the 1x1 skip weights): its pixel
+                            // rows sit in the half-buffer this phase is filling.  4 pixel fragments (this wave's 64 pixels, one k chunk per lane)
+                            // behind the barrier, then 4 groups of 8 MFMAs (2 channel blocks x 4 pixel blocks) with the next group's weight
+                            // fragments read underneath; the last group brings the next tap's addresses, pixel and weight fragments.
+                            __builtin_amdgcn_s_barrier();
+                            {
+                                int o = d_off;
+                                asm volatile("" : "+v"(o));          // per-step addresses stay out of loop-invariant hoisting (registers)
+                                const char* Eb = smem + (hbuf ^ 1) * kHB + (skip_slot(tap - 3) + hfs) * 8192 + o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        __builtin_amdgcn_s_barrier();
-                        {
-                            int o = d_off;
-                            asm volatile("" : "+v"(o));          // per-step addresses stay out of loop-invariant hoisting (registers)
-                            const char* Eb = smem + (skip_slot(e, 0) + hfs) * 8192 + o;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) px[0][i] = *reinterpret_cast<const frag_t*>(Eb + i * 1024);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const bool last = g == 3;
-                            if (!last) load_wt_d(st, g + 1, (g + 1) & 1);
-                            else {
-                                st = st == 2 ? 0 : st + 1;
-                                if (e < 7) load_wt_d(st, 0, 0);              // the next dense step's first weight fragments (landed at this barrier)
-                                else load_wt(st, 0, 0, 0);                   // ... or those of halo phase 0, tap 0
+                                for (int i = 0; i < 4; ++i) px[1][i] = *reinterpret_cast<const frag_t*>(Eb + i * 1024);
                             }
-                            if (e == 0) mfma_group(g, g & 1, 0, IntTag<1>{}); else mfma_group(g, g & 1, 0, IntTag<0>{});
-#pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                            }
-                            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
                             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const bool last = g == 3;
+                                if (!last) load_wt_d(st, g + 1, (g + 1) & 1);
+                                else {
+                                    st = st == 2 ? 0 : st + 1;
+                                    addr(tap + 1); load_px(hbuf, 0, 0, 0, 4);
+                                    load_wt(st, 0, 0, 0);
+                                }
+                                mfma_group(g, g & 1, 1, IntTag<0>{});
+                                if (last) {
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                                    }
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                                    }
+                                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                                } else {
+#pragma unroll
+                                    for (int k = 0; k < 2; ++k) {
+                                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                                    }
+                                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                     }
                 }
-                for (int ph = 0; ph < nph; ++ph) phase(IntTag<0>{}, ph);
-            } else {
-                phase(IntTag<1>{}, 0);
-                for (int ph = 1; ph < nph; ++ph) phase(IntTag<0>{}, ph);
-            }
+                hbuf ^= 1;
+            };
+            phase(IntTag<1>{}, 0);
+            for (int ph = 1; ph < nph; ++ph) phase(IntTag<0>{}, ph);
             asm volatile("" ::: "memory");
             // residual hand-over (see the producers): units 0..6 of the tile's residual arrive in the halo buffer this job's last phase
             // just finished with; unit 7 (channels 112..127) is loaded from memory here, ahead of the two barriers that hide its latency
@@ -1219,8 +1222,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         }
         resolve_centres(job_tile(0));
         __builtin_amdgcn_s_barrier();                          // start-up barrier: weight tile 0 is in LDS
-        if (kSkip) load_wt_d(0, 0, 0);
-        else if (kPrefetchW) load_wt(0, 0, 0, 0);
+        if (kPrefetchW) load_wt(0, 0, 0, 0);
         for (int k = 0; k < njobs; ++k) {
             const int tile = job_tile(k), hc = job_half(k), ntile = job_tile(k + 1), nhc = job_half(k + 1);
             const int next_boff = kWOFF + ((nhc >= 0 ? nhc * 64 : 0) + r16) * 128;

@@ -137,6 +137,9 @@ def test_unet_forward_backward_vs_oracle(dtype, in_channels, S):
 # the closed-form fill's head cancels to 1/10 of its operands, so a storage rounding shows ~10x larger on these vectors than on the
 # default-init ones: the 16-bit mode is held to 3x its bar here (measured with fp16 forward storage: see profiles/r03_parity_report.txt)
 CLOSED_FORM_SLACK = {torch.float32: 1.0, torch.bfloat16: 3.0}
+# what "16-bit gradient parity" means on that set (test_training_step_vs_golden; frozen from measurement, see the test): the flat gradient
+# against the reference-pinned oracle's - cosine, relative L2, tensors above 1 % of the norm, the total norm - and the stored full gradients
+GRAD16 = {"cosine": 0.999, "rel_l2": 4e-2, "per_tensor": 8e-2, "norm": 2e-2, "stored": 0.3}
 
 
 @pytest.mark.parametrize("name,C,dtype", [("train_c128_s28.npz", 128, torch.float32), ("train_c256_s8.npz", 256, torch.float32),
@@ -166,30 +169,49 @@ def test_training_step_vs_golden(golden, name, C, dtype):
             ref = T(g["grad_norms"])
             if dtype == torch.float32:
                 ok = (norms - ref).abs() <= tol * ref.abs() + 1e-3 * tol * ref.abs().max()
+                assert bool(ok.all()), [(names[i], float(norms[i]), float(ref[i])) for i in (~ok).nonzero().flatten()[:8]]
             else:
-                # bf16 gradients on the cancellation-heavy closed-form net: single small-norm tensors deviate by up to 17 % (measured,
-                # round 3), the gradient as a whole by < 2 %; bounds: 30 % per tensor (+ 2 % of the largest norm), 5 % on the total norm
-                ok = (norms - ref).abs() <= 0.3 * ref.abs() + 2e-2 * ref.abs().max()
-                assert abs(float(norms.norm() / ref.norm()) - 1.0) < 5e-2, float(norms.norm() / ref.norm())
-            assert bool(ok.all()), [(names[i], float(norms[i]), float(ref[i])) for i in (~ok).nonzero().flatten()[:8]]
+                # 16-bit mode (bf16 gradient storage) on the cancellation-heavy closed-form net - a statement that can fail meaningfully
+                # (round 3 accepted 30 % per tensor): the WHOLE gradient against the oracle's gradient of the same inputs (the oracle is pinned
+                # to the reference on these very vectors by tests/test_oracle_golden.py): cosine similarity and relative L2 of the flat
+                # gradient, the total norm against the reference's own norms, and per tensor only where a tensor carries >= 1 % of the norm
+                from oracle import diffusion_ref as D
+                pr = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+                D.training_losses(pr, x0.cpu(), y.cpu(), u.cpu(), eps.cpu())["loss"].mean().backward()
+                gn = [n for n in names if pr[n].grad is not None]
+                gh = torch.cat([net.grad(n).float().cpu().reshape(-1) for n in gn])
+                gr = torch.cat([pr[n].grad.reshape(-1) for n in gn])
+                cos, rl2 = float(F.cosine_similarity(gh, gr, dim=0)), float((gh - gr).norm() / gr.norm())
+                worst = max(((float((net.grad(n).float().cpu() - pr[n].grad).norm() / pr[n].grad.norm()), n) for n in gn
+                             if float(pr[n].grad.norm()) >= 1e-2 * float(gr.norm())))
+                print(f"16-bit gradient vs oracle [{name}]: cosine {cos:.6f}, relative L2 {rl2:.3e}, worst tensor above 1 % of the norm {worst[0]:.3e} ({worst[1]}), "
+                      f"total norm ratio {float(norms.norm() / ref.norm()):.4f}")
+                assert cos >= GRAD16["cosine"] and rl2 <= GRAD16["rel_l2"], (cos, rl2)
+                assert worst[0] <= GRAD16["per_tensor"], worst
+                assert abs(float(norms.norm() / ref.norm()) - 1.0) < GRAD16["norm"], float(norms.norm() / ref.norm())
             live = {n: float(r) > 1e-4 * float(ref.max()) for n, r in zip(names, ref)}   # skip mathematically-zero grads
-            gtol = tol if dtype == torch.float32 else 0.3
+            gtol = tol if dtype == torch.float32 else GRAD16["stored"]
+            stored = []
             for k in g.files:
                 if k.startswith("grad__") and live[k[6:]]:
-                    assert rel_err(net.grad(k[6:]), T(g[k])) < gtol, k
+                    stored.append((rel_err(net.grad(k[6:]), T(g[k])), k))
                 if k.startswith("gradslice__") and live[k[11:]]:
                     gs = T(g[k])
                     full = net.grad(k[11:]).cpu()
-                    assert float((full[:4, :6] - gs).abs().max()) < gtol * float(full.abs().max()), k
+                    stored.append((float((full[:4, :6] - gs).abs().max()) / float(full.abs().max()), k))
+            if dtype != torch.float32:
+                print(f"16-bit stored gradients [{name}]: worst max-norm error {max(stored)[0]:.3e} ({max(stored)[1]})")
+            assert max(stored)[0] < gtol, max(stored)
         assert rel_err(out["loss"].mean(), T(g[f"loss_step{step}"])) < tol
         opt.step()
         d = net.param("down.seq.0.conv.weight").cpu() - params["down.seq.0.conv.weight"]
         # Adam's first steps are ~ lr * sign(g): an element whose gradient is within the rounding noise of zero may flip
-        assert rel_err(d, T(g[f"delta_stem_step{step}"])) < (2e-2 if dtype == torch.float32 else 2.0)
-        if dtype != torch.float32:
+        if dtype == torch.float32:
+            assert rel_err(d, T(g[f"delta_stem_step{step}"])) < 2e-2
+        else:                                               # +-lr steps: the update DIRECTION has to agree almost everywhere
             ref_d = T(g[f"delta_stem_step{step}"])
             agree = float(((d * ref_d) > 0).float().mean())
-            assert agree > 0.97, agree                      # ... but the update direction agrees almost everywhere
+            assert agree > 0.97, agree
 
 
 def test_autograd_bridge_matches_fused_path(golden):
@@ -278,21 +300,27 @@ def test_diffusion_model_methods():
 @pytest.mark.parametrize("name,C,steps", [("sample_c32_s8_T4.npz", 32, 4), ("sample_c32_s12_T8.npz", 32, 8)])
 def test_sampler_chains_vs_golden_narrow(golden, name, C, steps):
     """The reference's own sampler chains (DDIM, classifier-free guided DDIM, ancestral with recorded noise) at hidden_size 32, on the HIP
-    path in fp32 mode: every intermediate z and x prediction (5 x 1e-3: errors compound over the chain, as in test_sampler_vs_oracle)."""
+    path in fp32 mode: every intermediate z and x prediction at the 1e-3 bar of the outputs (round 3 held them to 5e-3).  Only the GUIDED
+    chain keeps 5e-3, and the reason is the reference's own arithmetic: its first step (logsnr = -20) recovers the x prediction from the mixed
+    eps prediction as sqrt(1 + e^20) * (z - eps * rsqrt(1 + e^-20)) (gaussian_diffusion.py:181-186, diffusion_utils.py:76-82), where z and eps
+    agree to 4.5e-5 of their size - fp32 rounding of eps alone is 1.3e-3 of the prediction, in the reference's chain as in this one."""
     from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
     g = golden(name)
     net, _ = make_net(torch.float32, C=C)
     init, y = T(g["init"]).cuda(), T(g["y"]).cuda()
-    tol = 5e-3
+    tol, gtol = 1e-3, 5e-3
     ddim = GaussianDiffusion(mean_type="v", num_steps=steps, sampler="ddim", sample_cond_w=-1.0)
     zs, xs, es = ddim.sample(net=partial(net, guide=y), init_x=init)
-    assert rel_err(zs, T(g["ddim_zs"])) < tol and rel_err(xs, T(g["ddim_xs"])) < tol and rel_err(es, T(g["ddim_eps"])) < tol
+    e = (rel_err(zs, T(g["ddim_zs"])), rel_err(xs, T(g["ddim_xs"])), rel_err(es, T(g["ddim_eps"])))
+    assert max(e) < tol, e
     w = T(g["cfg_w"]).cuda()
     zs, xs, _ = ddim.sample(net=partial(net, guide=y), init_x=init, cond_w=0.5, net_cond_w=w)
-    assert rel_err(zs, T(g["cfg_zs"])) < tol and rel_err(xs, T(g["cfg_xs"])) < tol
+    e = (rel_err(zs, T(g["cfg_zs"])), rel_err(xs, T(g["cfg_xs"])))
+    assert max(e) < gtol, e
     anc = GaussianDiffusion(mean_type="v", num_steps=steps, sampler="noisy", sample_cond_w=-1.0)
     zs, xs, _ = anc.sample(net=partial(net, guide=y), init_x=init, noises=T(g["anc_noise"]).cuda())
-    assert rel_err(zs, T(g["anc_zs"])) < tol and rel_err(xs, T(g["anc_xs"])) < tol
+    e = (rel_err(zs, T(g["anc_zs"])), rel_err(xs, T(g["anc_xs"])))
+    assert max(e) < tol, e
     assert torch.equal(zs[-1], xs[-1])
 
 
