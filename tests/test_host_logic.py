@@ -555,16 +555,52 @@ def test_wgrad_register_loads_stay_untouched_while_in_flight():
         assert not any(t.startswith("scratch_") for t in ins), name
         labels = {t[:-1]: k for k, t in enumerate(ins) if t.endswith(":")}
 
-        def succ(k):
+        def sregs(op):
+            m = re.match(r"s\[(\d+):(\d+)\]$", op)
+            return {f"s{i}" for i in range(int(m.group(1)), int(m.group(2)) + 1)} if m else {op}
+
+        def succ(k, known):
+            """Successors of instruction k as (index, known) pairs.  The compiler emits the same scalar compare several times in a row in front
+            of the loop exits of the unrolled steps (also through `s_mov` copies of the loop counter); following both edges of the later
+            branches would walk paths no execution can take.  So the walk carries one fact: known = (compare opcode, registers equal to
+            its left operand, registers equal to its right operand, outcome or None, SCC-still-holds-it).  VALU / memory instructions keep
+            it, `s_mov_b32` extends the alias sets, any other scalar write drops its destination from them and (if it writes SCC) the link
+            between the fact and the SCC bit."""
             t = ins[k]
             if t.startswith("s_endpgm"):
                 return []
             if t.startswith("s_branch"):
-                return [labels[t.split()[-1]]]
-            out = [k + 1] if k + 1 < len(ins) else []
+                return [(labels[t.split()[-1]], known)]
+            m = re.match(r"s_cbranch_scc([01]) (\S+)", t)
+            if m:
+                want, tgt = int(m.group(1)), labels[m.group(2)]
+                if known and known[4] and known[3] is not None:
+                    return [(tgt, known)] if known[3] == want else [(k + 1, known)]
+                if known and known[4]:
+                    return [(tgt, known[:3] + (want, True)), (k + 1, known[:3] + (1 - want, True))]
+                return [(tgt, known), (k + 1, known)]
             if t.startswith("s_cbranch"):
-                out.append(labels[t.split()[-1]])
-            return out
+                return [(k + 1, known), (labels[t.split()[-1]], known)]
+            if t.startswith("s_cmp"):
+                op, rest = t.split(None, 1)
+                x, y = [o.strip() for o in rest.split(",")]
+                if known and known[0] == op and x in known[1] and y in known[2]:
+                    known = known[:4] + (True,)
+                else:
+                    known = (op, frozenset([x]), frozenset([y]), None, True)
+            elif t.startswith("s_") and not re.match(r"s_(waitcnt|barrier|nop|sleep|setprio)", t) and known:
+                op, rest = (t.split(None, 1) + [""])[:2]
+                ops = [o.strip() for o in rest.split(",")] if rest else []
+                dst = sregs(ops[0]) if ops else set()
+                lhs, rhs = set(known[1]) - dst, set(known[2]) - dst
+                if op == "s_mov_b32" and len(ops) == 2:
+                    if ops[1] in known[1]:
+                        lhs |= dst
+                    if ops[1] in known[2]:
+                        rhs |= dst
+                holds = known[4] and bool(re.match(r"s_(mov_b32|mov_b64|load|buffer_load|mul_i32|cselect)", op))
+                known = (known[0], frozenset(lhs), frozenset(rhs), known[3], holds) if lhs and rhs else None
+            return [(k + 1, known)] if k + 1 < len(ins) else []
 
         loads = [k for k, t in enumerate(ins) if is_reg_load(t)]
         assert len(loads) >= 8, (name, len(loads))
@@ -572,41 +608,55 @@ def test_wgrad_register_loads_stay_untouched_while_in_flight():
         for k0 in loads:
             dest = _regs(ins[k0].split(",")[0])
             assert len(dest) == 4, ins[k0]
-            seen, stack, hit = set(), [(n, 0, False) for n in succ(k0)], False
+            seen, stack, hit, parent = set(), [(n, 0, False, kn) for n, kn in succ(k0, None)], False, {}
+
+            def trace(st):           # the control-flow path that led here: branches, labels, waits, VMEM operations
+                out = []
+                while st is not None:
+                    t = ins[st[0]]
+                    if re.match(r"(buffer_|global_|s_waitcnt|s_barrier|s_c?branch|s_cmp)", t) or t.endswith(":"):
+                        out.append(f"{st[0]}:{t} [younger {st[1]}]")
+                    st = parent.get(st)
+                return " <- ".join(out[:60])
             while stack:
-                k, younger, retired = stack.pop()
-                if (k, younger, retired) in seen:
+                st = stack.pop()
+                if st in seen:
                     continue
-                seen.add((k, younger, retired))
+                seen.add(st)
+                k, younger, retired, known = st
                 t = ins[k]
                 w = re.match(r"s_waitcnt .*vmcnt\((\d+)\)", t)
                 if w and younger >= int(w.group(1)):
                     retired = True
                 ops = t.split(None, 1)[1] if " " in t and not t.endswith(":") else ""
                 if not t.endswith(":") and _regs(ops) & dest:
-                    assert retired, (name, ins[k0], "touched while possibly in flight by", t)
-                    if not is_vmem(t) or not is_reg_load(t):
-                        if t.startswith("v_cvt_f32_f16"):
-                            hit = True
+                    if not retired:
+                        open("/tmp/gmk_isa_trace.txt", "w").write(trace(st).replace(" <- ", "\n"))
+                    assert retired, (name, ins[k0], "touched while possibly in flight by", t, "path in /tmp/gmk_isa_trace.txt")
+                    hit = hit or t.startswith("v_cvt_f32_f16")
                     continue                                   # the value is consumed or dead behind this instruction
                 if is_vmem(t):
                     younger = min(younger + 1, 63)
-                stack.extend((n, younger, retired) for n in succ(k))
+                for n, kn in succ(k, known):
+                    nxt_st = (n, younger, retired, kn)
+                    parent.setdefault(nxt_st, st)
+                    stack.append(nxt_st)
             consumed += hit
         assert consumed >= 8, (name, consumed)                  # the steady-state loads all reach their conversion
         # four VMEM operations between two barriers of the steady-state loop, on every path
         bars = [k for k, t in enumerate(ins) if t == "s_barrier"]
 
         def to_next_barrier(b):
-            found, seen, stack = set(), set(), [(n, 0) for n in succ(b)]
+            found, seen, stack = set(), set(), [(n, 0, kn) for n, kn in succ(b, None)]
             while stack:
-                k, n = stack.pop()
-                if (k, n) in seen or n > 16:
+                st = stack.pop()
+                k, n, known = st
+                if st in seen or n > 16:
                     continue
-                seen.add((k, n))
+                seen.add(st)
                 if ins[k] == "s_barrier":
                     found.add((k, n)); continue
-                stack.extend((x, n + is_vmem(ins[k])) for x in succ(k))
+                stack.extend((x, n + is_vmem(ins[k]), kn) for x, kn in succ(k, known))
             return found
         nxt = {b: to_next_barrier(b) for b in bars}
         cyc = [b for b in bars if any(b in {k for k, _ in nxt[c]} for c in bars if c != b) and nxt[b]]      # barriers inside the loop
