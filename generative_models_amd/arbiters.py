@@ -18,6 +18,8 @@ from torch import nn
 
 
 class RandomFeatureEncoder(nn.Module):
+    stand_in = True          # metrics taken in this space are logged under their own keys (metrics.eval_heavy: `randfeat_*`)
+
     def __init__(self, z_size=64, width=32, seed=1234):
         super().__init__()
         g = torch.Generator().manual_seed(seed)
@@ -40,6 +42,7 @@ class RandomFeatureEncoder(nn.Module):
 
 class CentroidClassifier(nn.Module):
     """logits[n, c] = -|z_n - mu_c|^2 / (2 s^2): a Gaussian class model with shared isotropic variance on the encoder's features."""
+    stand_in = True
 
     def __init__(self, encoder, classes=10):
         super().__init__()
@@ -61,6 +64,14 @@ class CentroidClassifier(nn.Module):
             self._sum.index_add_(0, y[keep], z[keep])
             self.count.index_add_(0, y[keep], torch.ones_like(y[keep], dtype=torch.float32))
             self._sq += float((z[keep] ** 2).sum()); self._n += int(keep.sum())
+        # data parallel: every rank sees its own shard of the test stream - the class sums are all-reduced so that all ranks score
+        # samples with the SAME classifier (round 3 fitted one per rank: per-rank classifier_loss values were not comparable)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and self._sum is not None:
+            extra = torch.tensor([self._sq, float(self._n)], device=self._sum.device, dtype=torch.float64)
+            for t in (self._sum, self.count, extra):
+                dist.all_reduce(t)
+            self._sq, self._n = float(extra[0]), int(extra[1])
         self.mu = self._sum / self.count.clamp_min(1.0)[:, None]
         within = self._sq - float((self.mu ** 2 * self.count[:, None]).sum())
         self.var = torch.tensor(max(within / max(1, self._n * self.mu.shape[1]), 1e-6), device=self.mu.device)

@@ -79,6 +79,7 @@ class FlagSpace:
             with open(peek.weights_from.parent / "hps.yaml") as f:
                 layer = dict(yaml.load(f, Loader=yaml.Loader))
             layer.pop("full_cmd", None)                                   # the saved command line is a record, not a flag
+            layer.pop("arbiters", None)                                   # ... and so is the feature space of that run's eval/* numbers
             Model = registry[layer["model"]]
         else:
             Model = registry[peek.model]
@@ -238,6 +239,8 @@ def _feature_extractors(G, device, test_ds=None):
         import copy
         batches = ((b[0].to(device), b[1].to(device)) for b in copy.deepcopy(test_ds))      # a copy: the run's own test stream stays untouched
         classifier = arbiters.CentroidClassifier(arbiters.RandomFeatureEncoder().to(device)).to(device).fit(batches)
+    # recorded in hps.yaml next to the flags: which feature space the eval/* numbers of this run live in
+    G.arbiters = "stand-in" if (getattr(autoencoder, "stand_in", False) or getattr(classifier, "stand_in", False)) else "reference"
     return autoencoder, classifier
 
 

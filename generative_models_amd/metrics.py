@@ -95,10 +95,14 @@ def eval_heavy(logger, model, test_ds, autoencoder, classifier, G, total_samples
         scores["fid"] = compute_fid(gen.cpu().numpy(), real.cpu().numpy())
         return scores
 
-    results = against_real("gen")
+    # The reference's metric keys (`eval/fid`, `eval/precision` ...) are kept for values taken in the REFERENCE's feature space (its
+    # TorchScript arbiters).  With the stand-ins of arbiters.py the same quantities are logged as `eval/randfeat_*` /
+    # `eval/centroid_classifier_loss`, so that a log or hps file can never pass them off as reference-space numbers.
+    space = "randfeat_" if getattr(autoencoder, "stand_in", False) else ""
+    results = {space + key: val for key, val in against_real("gen").items()}
     if G.class_cond:
-        results["classifier_loss"] = clf_losses
-        results.update({"cond_" + key: val for key, val in against_real("cond").items()})
+        results[("centroid_" if getattr(classifier, "stand_in", False) else "") + "classifier_loss"] = clf_losses
+        results.update({space + "cond_" + key: val for key, val in against_real("cond").items()})
     for key, val in results.items():
         val = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else val
         logger[f"eval/{key}"] += [float(np.mean(val))]

@@ -321,10 +321,12 @@ def test_cli_at_config_1_flags(tmp_path):
     # DiffusionModel.DG.eval_heavy = 1 (diffusion_model.py:22): with the reference's TorchScript arbiters absent the built-in
     # stand-ins run the heavy eval on the HIP samples (N3): FID / precision / recall / classifier loss are logged
     assert "RUNNING HEAVY EVAL" in out and "DONE HEAVY EVAL" in out
-    for key in ("eval/fid", "eval/precision", "eval/recall", "eval/f1", "eval/cond_fid", "eval/classifier_loss"):
+    for key in ("eval/randfeat_fid", "eval/randfeat_precision", "eval/randfeat_recall", "eval/randfeat_f1", "eval/randfeat_cond_fid",
+                "eval/centroid_classifier_loss"):
         assert key in out, key
     with open(tmp_path / "cfg1" / "hps.yaml") as f:
         hps = yaml.load(f, Loader=yaml.Loader)
+    assert hps["arbiters"] == "stand-in"
     assert hps["bs"] == 32 and hps["timesteps"] == 200 and hps["hidden_size"] == 128 and hps["act_dtype"] in ("fp16", "bf16")
     assert len(torch.load(tmp_path / "cfg1" / "model.pt", map_location="cpu")) == 160
 

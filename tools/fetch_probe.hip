@@ -2,7 +2,9 @@
 // number of bytes of a 1-GiB buffer exactly once; the ratio counter / bytes is the correction factor for that kind of read.
 //   reg_full / dma_full   fully coalesced streaming reads, 16 B per lane: global loads to registers / buffer_load ... lds (LDS-DMA)
 //   reg_half / dma_half   the weight-gradient kernels' pattern: 128 B (one 64-channel half) of every 256-B pixel row, 8 lanes per row
-//   reg_half_twice        the same half rows read by TWO workgroups at about the same time (the two output-channel tiles of a split share X)
+//   reg_half_twice        the same half rows read by TWO workgroups on DIFFERENT XCDs at about the same time
+//   pair_half<reg | dma>  ... by two co-resident workgroups of the SAME XCD in step (the two output-channel tiles of a weight-gradient split
+//                         share the X operand this way), the second one started 0 / 2 / 4 us late
 // build + run on the GPU box:   hipcc -O3 --offload-arch=gfx950 tools/fetch_probe.hip -o /tmp/fetch_probe
 //                               rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/fp -o fp -- /tmp/fetch_probe
 // then tools/fetch_probe_parse.py /tmp/fp  (prints bytes read, counter x 1024, ratio per kernel)
@@ -54,6 +56,27 @@ __global__ void dma_half(const void* src, unsigned nbytes, int h) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Same-XCD sharing: 512 co-resident workgroups (2 per CU); blocks b and b + 256 (same XCD: ids 256 apart) walk the SAME half rows in step, like
+// the two output-channel tiles of a weight-gradient split that share the X operand.  delay: the second block of a pair starts ~`delay` us late.
+template <bool kDma>
+__global__ void pair_half(const void* src, unsigned* sink, unsigned nbytes, int delay) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * 1024];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, (int)nbytes, 0x00020000);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned b = blockIdx.x & 255;
+    if (blockIdx.x >= 256) for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(32);      // ~ 1 us per iteration
+    LDSP char* dst = (LDSP char*)(lds + wave * 1024);
+    u32x4 acc = {0, 0, 0, 0};
+    const unsigned waves = 256 * (blockDim.x >> 6);
+    for (unsigned k = b * (blockDim.x >> 6) + wave; k < nbytes / 256 / 8; k += waves) {
+        const unsigned off = (8 * k + (lane >> 3)) * 256u + (lane & 7) * 16u;
+        if (kDma) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDSP void*)dst, 16, off, 0, 0, 0);
+        else acc ^= __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
+
 __global__ void store_full(u32x4* dst, size_t nvec) {
     const u32x4 v = {1, 2, 3, 4};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;
@@ -72,6 +95,10 @@ int main() {
         flush(); reg_half<<<kGrid, kBlock>>>(a, sink, (unsigned)(kBytes / 256), 0, 0);
         flush(); dma_half<<<kGrid, kBlock>>>(a, lim, 0);
         flush(); reg_half<<<kGrid, kBlock>>>(a, sink, (unsigned)(kBytes / 256), 1, 1);
+        for (int delay = 0; delay <= 4; delay += 2) {
+            flush(); pair_half<false><<<512, kBlock>>>(a, sink, lim, delay);
+            flush(); pair_half<true><<<512, kBlock>>>(a, sink, lim, delay);
+        }
         flush(); store_full<<<kGrid, kBlock>>>((u32x4*)a, kBytes / 16);
     }
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }

@@ -3,9 +3,11 @@ import csv, glob, sys, collections
 GiB = 1 << 30
 known = {"reg_full": GiB, "dma_full": GiB - 65536, "reg_half": GiB // 2, "dma_half": (GiB - 65536) // 2, "store_full": GiB}
 rows = collections.defaultdict(list)
+r_names = {}
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0]
+        name = r["Kernel_Name"].split("(")[0].split("<")[0]
+        r_names[(name, int(r["Dispatch_Id"]))] = r["Kernel_Name"]
         rows[(name, r["Counter_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 for (name, counter), vals in sorted(rows.items()):
     vals.sort()
@@ -15,5 +17,7 @@ for (name, counter), vals in sorted(rows.items()):
         tag = name
         if name == "reg_half":
             tag = "reg_half" if i % 2 == 0 else "reg_half_twice"
-        b = known.get(name, 0)
+        if name.startswith("void pair_half") or name.startswith("pair_half"):
+            tag = "pair_same_xcd_dma" if "true" in r_names[(name, d)] else "pair_same_xcd_reg"      # (launched with start delays 0 / 2 / 4 us, in that order per kind)
+        b = known.get(name, 0) or (GiB - 65536) // 2
         print(f"{tag:16s} dispatch {d:3d} {counter:10s} = {v * 1024 / 1e6:10.1f} MB (counter x 1 KiB)   known bytes {b / 1e6:8.1f} MB   counter / known = {v * 1024 / b if b else 0:.3f}")
