@@ -83,16 +83,58 @@ def test_conv_forward_with_fp16_operands(ops, lib, B, S, two, up, force, variant
     assert rel_err(nchw(out), ref) < 2e-3
 
 
-def test_conv_output_saturates_instead_of_overflowing(ops):
-    """An fp16 convolution output beyond 65504 is stored as the largest finite value, not as inf (the residual stream is unbounded)."""
-    B, S, C = 2, 8, 128
+@pytest.mark.parametrize("residual", [False, True], ids=["plain", "residual-near-max"])
+@pytest.mark.parametrize("kernel", ["auto-small", "im2col-reg", "im2col-dma", "halo-ws", "halo-ws-32x32", "halo-8wave", "halo-fused-gn", "skipfold", "stem"])
+def test_conv_output_saturates_instead_of_overflowing(ops, lib, kernel, residual):
+    """An fp16 output beyond 65504 is stored as the largest finite value, not as inf (the residual stream is unbounded; the reference would
+    skip the step through its GradScaler, an unsaturated inf here would poison the next GroupNorm silently).  Saturation rests on
+    MODE.FP16_OVFL, set at the top of each kernel that stores fp16 activations (gmk_common.h fp16_saturating_stores): EVERY such kernel is
+    driven into overflow here - both im2col kernels, the LDS-halo kernel in its three consumer forms and with the fused GroupNorm producer,
+    the folded skip convolution, the stem - with >= 32 tiles where the dispatcher asks for them, with and without a residual near the
+    largest finite value (round 3 covered the small im2col path only: the advisor's finding)."""
+    C = 128
+    B, S = (2, 8) if kernel == "auto-small" else (2, 64)             # 64-pixel rows: 4 rows per tile, 32 tiles at B = 2
     x = torch.full((B, S, S, C), 60000.0, device="cuda", dtype=H)
     w = torch.zeros(C, C, 3, 3)
     w[:, :, 1, 1] = 1.0 / 64                                   # centre tap: every output = 128 * 60000 / 64 = 120000
     wf = torch.empty(w.numel(), device="cuda", dtype=H)
     ops.pack_conv_weight(w.cuda(), wf, None)
-    out = ops.conv_igemm([x], wf, C, 3, ops.NORMAL, (S, S))
-    assert bool(torch.isfinite(out).all()) and float(out.float().max()) == 65504.0
+    res = torch.full((B, S, S, C), 65000.0, device="cuda", dtype=H) if residual else None
+    force, variant = {"auto-small": (0, 0), "im2col-reg": (1, 0), "im2col-dma": (2, 0), "halo-ws": (3, 0), "halo-ws-32x32": (3, 32),
+                      "halo-8wave": (3, 3), "halo-fused-gn": (3, 0), "skipfold": (3, 0), "stem": (0, 0)}[kernel]
+    try:
+        lib.gmk_set_kernel_choice(force, -1, -1)
+        lib.gmk_set_dev_variant(variant)
+        if kernel == "stem":
+            if residual:
+                pytest.skip("the stem has no residual input")
+            img = torch.full((B, 3, S, S), 1.0, device="cuda")
+            ws = torch.full((C, 3, 3, 3), 10000.0, device="cuda")             # 270000 per interior output, 120000 in the corners (4 taps x 3 channels)
+            out = ops.stem_fwd(img, ws, torch.zeros(C, device="cuda"), C, H)
+        elif kernel == "skipfold":
+            if residual:
+                pytest.skip("the folded form has no residual input (the skip convolution is the residual)")
+            sk = [torch.full((B, S, S, C), 30000.0, device="cuda", dtype=H) for _ in range(2)]
+            wsk = torch.full((C, 2 * C, 1, 1), 1.0 / 128)                     # + 2 x 30000: 180000 in all
+            wsf = torch.empty(wsk.numel(), device="cuda", dtype=H)
+            ops.pack_conv_weight(wsk.cuda(), wsf, None)
+            out = ops.conv3x3_skipfold(x, wf, torch.zeros(C, device="cuda"), sk, wsf, torch.zeros(C, device="cuda"))
+            assert lib.gmk_last_kernel() == 7
+        elif kernel == "halo-fused-gn":
+            # raw source 1.0 with scale / shift tables that make silu(x * scale + shift) = silu(60000) = 60000: the producers' own fp16 store
+            xr = torch.ones((B, S, S, C), device="cuda", dtype=H)
+            tsc = torch.full((B, C), 60000.0, device="cuda"); tsh = torch.zeros((B, C), device="cuda")
+            assert ops.conv_gn_fusable([xr])
+            out = ops.conv_igemm([xr], wf, C, 3, ops.NORMAL, (S, S), residual=res, gn=(tsc, tsh))
+        else:
+            out = ops.conv_igemm([x], wf, C, 3, ops.NORMAL, (S, S), residual=res)
+            want = {"auto-small": 1, "im2col-reg": 1, "im2col-dma": 2, "halo-ws": 4, "halo-ws-32x32": 4, "halo-8wave": 3}[kernel]
+            assert lib.gmk_last_kernel() == want, lib.gmk_last_kernel()
+    finally:
+        lib.gmk_set_kernel_choice(-1, -1, -1)
+        lib.gmk_set_dev_variant(0)
+    assert out.dtype == H
+    assert bool(torch.isfinite(out).all()) and float(out.float().max()) == 65504.0 and float(out.float().min()) == 65504.0
 
 
 @pytest.mark.parametrize("B,S,two", [(40, 64, False), (33, 64, True)])
