@@ -982,12 +982,16 @@ static int conv_igemm_impl(const void* src0, const void* src1, int c0, int c1, i
     const int64_t lim = 0xFFFF0000ll;
     const int64_t nb0 = (int64_t)B * hs * ws * c0 * es, nb1 = (int64_t)B * hs * ws * c1 * es;
     const int64_t nbw = (int64_t)ksize * ksize * w_rows * (c0 + c1) * es;
+    // Tile-count floor of the halo kernel: NONE for the plain and the nearest-x2 forms since round 4 - the reference's own sampler sizes
+    // (25 images in `evaluate`, diffusion_model.py:98-104) put the 14 x 14 / 7 x 7 levels at 20 / 5 tiles, where the register-staged im2col
+    // kernel took 32 us a launch against the halo kernel's 19 (as half jobs on twice the CUs): B = 25 DDIM step 1.25 -> 1.15 ms, B = 8
+    // 1.46 -> 1.16 ms.  The zero-stuffed transposed form keeps 32 (below it the four parity phases win).
     // the transposed form (data gradient of the stride-2 conv) is the plain 3x3 conv of the zero-stuffed gradient: on the halo
     // kernel 3/4 of the resident pixels are zeros, but it still beats the im2col gather by 1.7x (215 vs 360 us at 28x28)
     const bool stuffed = mode == GMK_CONV_TRANSPOSED2 && !((ho | wo) & 1);
     if ((force == 0 || force == 3) && gmk_is16(dtype) && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2 || stuffed) && ksize == 3) {
         const int rc = gmk_conv3x3_halo_try(src0, src1, c0, c1, B, ho, wo, w, w_rows, n0, cout, bias, emb, emb_stride, residual,
-                                            out, out_cstride, force == 3 ? 1 : 32, stuffed ? 2 : mode == GMK_CONV_UPSAMPLE2, gn_stats,
+                                            out, out_cstride, (force == 3 || !stuffed) ? 1 : 32, stuffed ? 2 : mode == GMK_CONV_UPSAMPLE2, gn_stats,
                                             gn_stats_bytes, gn_scale, gn_shift, gn_stride, dtype, gmk_stream(stream));
         if (rc == 1 || rc == 2) {
             gmk_note_kernel(stuffed ? 5 : rc == 2 ? 4 : 3);       // 5: a halo kernel on the zero-stuffed source (transposed conv)
@@ -1074,7 +1078,7 @@ extern "C" int gmk_conv_gn_fusable(int B, int H, int W, int c0, int c1, int cout
     const int force = gmk_kernel_choice(0, "GMK_CONV_KERNEL");
     if (force != 0 && force != 3) return 0;
     // the same rule gmk_conv_igemm applies when it hands the launch to the halo kernel (weights [9][cout][c0 + c1], dense output)
-    return gmk_halo_geometry(B, H, W, c0, c1, cout, cout, cout, force == 3 ? 1 : 32, 0, 1, nullptr);
+    return gmk_halo_geometry(B, H, W, c0, c1, cout, cout, cout, 1, 0, 1, nullptr);
 }
 
 extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B,

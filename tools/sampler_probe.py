@@ -7,6 +7,8 @@ from functools import partial
 from generative_models_amd import common
 key, n = sys.argv[1], int(sys.argv[2])
 cin, S, B, attention, _ = bench.CONFIGS[key]
+if len(sys.argv) > 3:                      # batch override: python tools/sampler_probe.py cfg2 40 512
+    B = int(sys.argv[3])
 Model = common.discover_models()["diffusion"]
 G = common.AttrDict(dict(Model.DG)); G.update(lr=3e-4, pad32=0, device="cuda", timesteps=n, bs=B, in_channels=cin, attention=attention)
 m = Model(G).cuda().eval(); m.size = S
@@ -18,4 +20,4 @@ for r in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     m.diffusion.sample(net=partial(m.net, guide=y), init_x=init, record=False)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"{key}: {n / dt:.2f} steps/s  ({dt / n * 1e3:.3f} ms per step)")
+    print(f"{key} B={B}: {n / dt:.2f} steps/s  ({dt / n * 1e3:.3f} ms per step, {B * n / dt / 1e3:.1f} k image-steps/s)", flush=True)
