@@ -457,7 +457,7 @@ template <int N> struct IntTag { static constexpr int value = N; };
 
 // 64-byte rows: lane (row = lane >> 2, chunk = lane & 3) of a DMA instruction writes 16 rows of 64 B; physical chunk c of row n holds logical
 // chunk c ^ ((n >> 2) & 3), so the 16 rows a ds_read_b128 lane group touches (consecutive n, one logical chunk) cover all 64 banks.
-// No residual, no half jobs in this form.
+// No residual in this form (the skip convolution is the residual); half jobs as in the plain kernel (64 weight rows per step).
 template <typename T, bool kPrefetchW, int kShape = 32, bool kFuse = false, bool kSkip = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParams p) {
     static_assert(!kSkip || (kPrefetchW && kShape == 16 && !kFuse), "the folded skip convolution is built on the plain 16x16x32 form");
@@ -783,18 +783,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk0, (GMK_LDS void*)dst, 16, dv[hf][u], koff_b, 0, 0);
                     }
             };
-            auto issue_wd = [&](int stage, int k) {
+            unsigned wdh[2];                    // half jobs (channel half c): rows c * 64 + 16 pw + drow, one instruction
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + (32 * pw + 16 * u) * 64);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rswk, (GMK_LDS void*)dst, 16, wdo[u], (unsigned)k * 64u, 0, 0);
+            for (int c = 0; c < 2; ++c)
+                wdh[c] = (unsigned)(p.nsk0 + nblk + c * 64 + 16 * pw + drow) * (unsigned)p.sk_ktot * ES + dchunk;
+            auto issue_wd = [&](int stage, int k, int c) {      // c < 0: all 128 rows (2 instructions), else the 64 rows of channel half c (1)
+                if (c < 0) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + (32 * pw + 16 * u) * 64);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rswk, (GMK_LDS void*)dst, 16, wdo[u], (unsigned)k * 64u, 0, 0);
+                    }
+                } else {
+                    GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + (c * 64 + 16 * pw) * 64);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rswk, (GMK_LDS void*)dst, 16, c ? wdh[1] : wdh[0], (unsigned)k * 64u, 0, 0);
                 }
             };
-            // weight tile of step i (0..12, or 13 / 14 = steps 0 / 1 of the following phase) of phase ph: steps 4, 6, 8, 10 are the dense ones
-            auto issue_weights = [&](int stage, int ph, int i) __attribute__((always_inline)) {
-                if (i >= 13) { i -= 13; ph ^= 1; }                               // (the next job runs the same convolution: same weights)
-                if (i == 4 || i == 6 || i == 8 || i == 10) issue_wd(stage, 4 * ph + (i - 4) / 2);
-                else issue_w(stage, i < 4 ? i : i == 5 ? 4 : i == 7 ? 5 : i == 9 ? 6 : i == 11 ? 7 : 8, ph, -1);
+            // weight tile of step i (0..12, or 13 / 14 = steps 0 / 1 of the following phase) of phase ph: steps 4, 6, 8, 10 are the dense ones;
+            // c / cn: channel half of this job / of the job whose phase 0 follows this job's phase 1 (-1: whole job)
+            auto issue_weights = [&](int stage, int ph, int i, int c, int cn) __attribute__((always_inline)) {
+                if (i >= 13) { i -= 13; if (ph == 1) c = cn; ph ^= 1; }          // (the next job runs the same convolution: same weights)
+                if (i == 4 || i == 6 || i == 8 || i == 10) issue_wd(stage, 4 * ph + (i - 4) / 2, c);
+                else issue_w(stage, i < 4 ? i : i == 5 ? 4 : i == 7 ? 5 : i == 9 ? 6 : i == 11 ? 7 : 8, ph, c);
             };
             auto wait_vm = [&](int n) __attribute__((always_inline)) {      // n is a constant after unrolling
                 if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -802,15 +812,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             };
             int sq = 2;
-            int tile = job_tile(0);
+            int tile = job_tile(0), ch = job_half(0);
 #pragma unroll
             for (int j = 0; j < 7; ++j) { resolve_piece(tile, j); issue_fill(0, 0, j); }
-            issue_w(0, 0, 0, -1);
-            issue_w(1, 1, 0, -1);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            issue_w(0, 0, 0, ch);
+            issue_w(1, 1, 0, ch);
+            if (ch < 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __builtin_amdgcn_s_barrier();                      // start-up barrier: weight tile 0 and the first halo half are in LDS
             for (int k = 0; k < njobs; ++k) {
-                const int ntile = job_tile(k + 1);
+                const int ntile = job_tile(k + 1), nch = job_half(k + 1);
                 resolve_dense(tile);
 #pragma unroll
                 for (int ph = 0; ph < 2; ++ph) {
@@ -825,7 +836,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         // pixel-piece instructions of the previous step may still fly; its weights (for step i + 1) and everything older have landed
                         wait_vm(i == 0 ? 0 : i == 4 ? 2 : (i == 1 || i == 2 || i == 3 || i == 6 || i == 8 || i == 10 || i == 12) ? 4 : 0);
                         __builtin_amdgcn_s_barrier();
-                        issue_weights(sq, ph, i + 2);
+                        issue_weights(sq, ph, i + 2, ch, nch);
                         if (i == 0) issue_dense(fb, skip_slot(0), 4 * ph + 0);
                         if (i == 1) issue_dense(fb, skip_slot(1), 4 * ph + 1);
                         if (i == 2) issue_dense(fb, skip_slot(2), 4 * ph + 2);
@@ -837,7 +848,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         sq = sq == 2 ? 0 : sq + 1;
                     }
                 }
-                tile = ntile;
+                tile = ntile; ch = nch;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the speculative DMA before the LDS is released
             return;
@@ -981,10 +992,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         const int hfs = __builtin_amdgcn_readfirstlane(wave) >> 1;                 // which 128-pixel half this wave's pixels are in
         const int d_off = (((wave & 1) * 64 + r16) << 6) + ((q ^ ((r16 >> 2) & 3)) << 4);
         const int dw_off = kWOFF + (r16 << 6) + ((q ^ ((r16 >> 2) & 3)) << 4);
+        int dw_half = 0;                                                           // byte offset of the job's channel half in a dense weight tile
         auto load_wt_d = [&](int stg, int pair, int set) {                         // channel blocks 2 pair, 2 pair + 1 of a dense weight tile
             int o = dw_off;
             asm volatile("" : "+v"(o));
-            const char* Wb = smem + stg * kWST + pair * 2048 + o;
+            const char* Wb = smem + stg * kWST + dw_half + pair * 2048 + o;
             wt[set][0] = *reinterpret_cast<const frag_t*>(Wb);
             wt[set][1] = *reinterpret_cast<const frag_t*>(Wb + 1024);
         };
@@ -1020,7 +1032,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 constexpr int kFirst = decltype(first_tag)::value;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    const bool dense_after = kSkip && NCB == 8 && tap >= 3 && tap <= 6;      // a dense sub-phase of the folded skip convolution follows this tap
+                    const bool dense_after = kSkip && tap >= 3 && tap <= 6;      // a dense sub-phase of the folded skip convolution follows this tap
                     __builtin_amdgcn_s_barrier();
                     if (tap == 0) { addr(0); load_px(hbuf, 0, 0, 0, 4); }      // the phase's halo only became valid with this barrier
                     if (!kPrefetchW) load_wt(st, 0, 0, 0);
@@ -1066,7 +1078,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (kSkip && NCB == 8) {
+                    if constexpr (kSkip) {
                         if (dense_after) {
                             // ---- dense sub-phase m = tap - 3 of this phase (32 channels of torch.cat([x, skip]) x the 1x1 skip weights): its pixel
                             // rows sit in the half-buffer this phase is filling.  4 pixel fragments (this wave's 64 pixels, one k chunk per lane)
@@ -1082,8 +1094,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                             }
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const bool last = g == 3;
+                            for (int g = 0; g < NG; ++g) {                   // NG channel-block pairs: 4 (whole job) or 2 (half job)
+                                const bool last = g == NG - 1;
                                 if (!last) load_wt_d(st, g + 1, (g + 1) & 1);
                                 else {
                                     st = st == 2 ? 0 : st + 1;
@@ -1118,6 +1130,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 }
                 hbuf ^= 1;
             };
+            if constexpr (kSkip) dw_half = chalf > 0 ? 4096 : 0;          // dense weight rows c * 64 .. of a half job (64 B per row)
             phase(IntTag<1>{}, 0);
             for (int ph = 1; ph < nph; ++ph) phase(IntTag<0>{}, ph);
             asm volatile("" ::: "memory");
@@ -1669,7 +1682,12 @@ extern "C" int gmk_conv3x3_skipfold(const void* src, int c0, int B, int H, int W
     p.nbs = (unsigned)((int64_t)g.M * cs * 2); p.nbws = (unsigned)((int64_t)wsk_rows * 2 * cs * 2);
     const int ncu = gmk_cu_limit();
     dim3 grid((unsigned)(g.ntiles < ncu ? g.ntiles : ncu), cout / 128);
-    p.nfull = (int)g.ntiles; p.nhalf = 0;                          // no half jobs in this form
+    p.nfull = (int)g.ntiles; p.nhalf = 0;
+    {   // half jobs as in gmk_conv3x3_halo_try: the last partly filled round, or every tile of a small problem
+        const int G = (int)grid.x, rem = (int)(g.ntiles % G);
+        if (g.ntiles > G && rem > 0 && 2 * rem <= G && p.variant != 6) { p.nfull = (int)g.ntiles - rem; p.nhalf = 2 * rem; }
+        else if (2 * g.ntiles <= ncu && p.variant != 6 && p.variant != 8) { p.nfull = 0; p.nhalf = 2 * (int)g.ntiles; grid.x = (unsigned)p.nhalf; }
+    }
     if (dtype == GMK_F16) conv3x3_halo_ws_kernel<f16_t, true, 16, false, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
     else conv3x3_halo_ws_kernel<bf16_t, true, 16, false, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
     gmk_note_kernel(7);
