@@ -14,7 +14,7 @@ import torch  # noqa: F401  (FIRST: libgmk.so must bind to the HIP runtime torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "gmk.h")
-# GMK_LIBGMK: another build of the SAME library (diagnostic variants made by tools/build_variant.sh); still the HIP path
+# GMK_LIBGMK: another build of the SAME library (a diagnostic variant build); still the HIP path
 LIBPATH = os.environ.get("GMK_LIBGMK") or os.path.join(_PKG, "libgmk.so")
 
 _CTYPES = {

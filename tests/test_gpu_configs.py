@@ -386,7 +386,7 @@ def test_sized_goldens_vs_reference(golden, name, cin, S, dtype, forced):
     3x64x64).  `forced` runs the kernels the bench-size launches use - the LDS-halo convolution and the slot weight gradient, which the
     dispatcher only picks from 32 tiles up - on the same vectors, so the 64-pixel-row and 32-pixel-row instantiations of both and the
     64x64 resident GroupNorm kernels trace to the reference.  Bars: fp32 1e-3 / 16-bit 1e-2 max-norm on outputs, loss, every gradient norm
-    and the stored gradients; DDIM chains 1e-3 / 3e-2 on every intermediate z and x prediction (16-bit errors compound along the chain).
+    and the stored gradients; DDIM chains 1e-3 / 1e-2 on every intermediate z and x prediction (guided: 5e-3 / 2e-2).
     The GUIDED chain is held to 5e-3 in fp32: its first step (logsnr = -20) recovers the x prediction from the mixed eps prediction as
     sqrt(1 + e^20) * (z - eps * rsqrt(1 + e^-20)) (gaussian_diffusion.py:181-186, diffusion_utils.py:76-82) where z and eps agree to 4.5e-5 of
     their size: fp32 rounding of eps ALONE is 6e-8 / 4.5e-5 = 1.3e-3 of the prediction - the reference's own chain carries that noise (the fp32
@@ -432,7 +432,7 @@ def test_sized_goldens_vs_reference(golden, name, cin, S, dtype, forced):
                 assert rep[k] < tol, (k, rep[k])
         if "chain_T" in g.files:
             steps, init, yc = int(g["chain_T"]), T(g["chain_init"]).cuda(), T(g["chain_y"]).cuda()
-            ctol, gtol = (1e-3, 5e-3) if dtype == torch.float32 else (3e-2, 3e-2)
+            ctol, gtol = (1e-3, 5e-3) if dtype == torch.float32 else (1e-2, 2e-2)      # measured 16-bit: 1.5e-3 / 7.8e-3 (profiles/r04_sized_report.txt)
             ddim = GaussianDiffusion(mean_type="v", num_steps=steps, sampler="ddim", sample_cond_w=-1.0)
             zs, xs, _ = ddim.sample(net=partial(net, guide=yc), init_x=init)
             rep["ddim_zs"], rep["ddim_xs"] = rel_err(zs, T(g["ddim_zs"])), rel_err(xs, T(g["ddim_xs"]))

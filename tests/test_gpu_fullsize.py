@@ -88,7 +88,7 @@ def test_sampler_full_batch(net):
 
 
 def test_forward_is_bit_reproducible_with_the_skip_convs_on_the_side_stream(net):
-    """tools/side_stream_det.py as a test: repeated identical forwards with GMK_FWD_SIDE (1x1 skip convolutions beside the
+    """Side-stream determinism: repeated identical forwards with GMK_FWD_SIDE (1x1 skip convolutions beside the
     GroupNorm / conv1 chain) are bit-identical, and equal to the forward without the overlap.  A -DGMK_SHFL_BPERMUTE build fails
     this about every second forward; the shipped DPP / permlane reductions have never failed it."""
     from generative_models_amd import ops
