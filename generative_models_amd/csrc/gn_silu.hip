@@ -715,6 +715,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(XREG > 
 
 // pixels per thread of the register-resident kernels: the smallest of 1, 2, 4, 8 that fits the slab into <= 512 threads
 int gn_reg_iter(int HW, int nvec) {
+    // 28 x 28 (784 pixels; round 4): 16 pixels per thread leave 49 planes x 8 = 392 of 448 threads busy (4.05 TB/s against 4.65 at 32 x 32, same batch);
+    // 14 per thread make it 56 planes = 448 threads, all busy, on 8 fewer data registers (GMK_GN_KERNEL=6 keeps the power-of-two choice: A/B)
+    if (nvec == 8 && HW == 784 && gmk_kernel_choice(2, "GMK_GN_KERNEL") != 6) return 14;
     for (int it = 1; it <= 16; it <<= 1)
         if (((HW + it - 1) / it) * nvec <= 512) return it;
     return 0;
@@ -909,6 +912,7 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
             else if (it == 2) GMK_GN_FWD_REG(2, 8);
             else if (it == 4) GMK_GN_FWD_REG(4, 8);
             else if (it == 8) GMK_GN_FWD_REG(8, 8);
+            else if (it == 14) GMK_GN_FWD_REG(14, 8);
             else GMK_GN_FWD_REG(16, 8);
         }
 #undef GMK_GN_FWD_REG
@@ -969,6 +973,7 @@ extern "C" int gmk_gn_stats(const void* x, const float* gamma, const float* beta
         else if (it == 2) GMK_GN_STATS_REG(2);
         else if (it == 4) GMK_GN_STATS_REG(4);
         else if (it == 8) GMK_GN_STATS_REG(8);
+        else if (it == 14) GMK_GN_STATS_REG(14);
         else GMK_GN_STATS_REG(16);
 #undef GMK_GN_STATS_REG
     } else if (HW > 1024 && HW <= 4096 && HW % 16 == 0 && C % 32 == 0 && 32 % (C / groups) == 0) {
