@@ -16,6 +16,8 @@ steps run through gmk_ddim_step_vec / gmk_distill_target, the student is conditi
 """
 from functools import partial
 
+import os
+
 import numpy as np
 import torch
 
@@ -126,6 +128,59 @@ class GaussianDiffusion:
             if self.teacher_mode == "step1":
                 self.loss_weight_type = "snr"
         self.rng = PhiloxStream(seed)
+        self._graphs = {}                   # small-batch sampling: one captured U-Net forward per (net, shape, conditioning kind)
+
+    # ---- small-batch sampling: the forward as a replayed HIP graph ------------------------------------------------------------
+    # The reference's own use of the sampler is small: `evaluate` draws 25 images (diffusion_model.py:98-104), `eval_heavy` the test batch
+    # size.  Since round 4's dispatch changes a 25-image forward is 0.93 ms of kernels behind 1.1 ms of host launch work (~ 85 launches through
+    # ctypes): the host is the bound, and replaying the captured forward removes it.  (Round 3 had measured a graph at 1.34 = 1.34 ms and
+    # dropped it - the kernels, then 30 % longer, were the bound.)  Same kernels in the same order: bit-identical images.
+    GRAPH_MAX_PIXELS = int(os.environ.get("GMK_SAMPLER_GRAPH_PIXELS", str(64 * 1024)))       # images x H x W of one forward; 0 turns it off
+
+    def _forward_runner(self, module, z, guide, student_w):
+        """-> (run(z_t) -> v, lvec): the forward of `module` on a [nb, C, H, W] batch conditioned on `guide` / `student_w`, and the fp32 [nb]
+        log-SNR vector it reads (the caller fills it before the first step, the sampler-update kernel writes it afterwards)."""
+        nb = z.shape[0]
+        dev = z.device
+        # (a captured forward would replay ONE dropout mask: training-mode dropout keeps the kernel-by-kernel path)
+        small = 0 < nb * z.shape[2] * z.shape[3] <= self.GRAPH_MAX_PIXELS and self.num_steps >= 4 and not (module.training and module.dropout > 0.0)
+        if not small:
+            lvecs = [torch.empty((nb,), device=dev), torch.empty((nb,), device=dev)]      # two buffers alternate (see `sample`)
+            return None, lvecs
+        # the host-side freshness check of the packed convolution weights runs at capture time only: do it here, before every replay loop
+        # (the pack buffer keeps its address, so a re-pack is seen by the captured kernels)
+        if module._packs_stale or module._packed_version != module._version_sum():
+            module._repack()
+        key = (id(module), module.flat_params.data_ptr(), module._pack_buf.data_ptr(), tuple(z.shape), guide is not None, student_w is not None)
+        ent = self._graphs.get(key)
+        if ent is None:
+            zs, ls = torch.empty_like(z), torch.zeros((nb,), device=dev)
+            gs = guide.clone() if guide is not None else None
+            ws = student_w.clone() if student_w is not None else None
+            zs.copy_(z)
+            side = torch.cuda.Stream(device=dev)                  # warm-up off the capture: weight packs, workspaces, allocator pools
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    module.forward_hip(zs, ls, gs, ws)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = module.forward_hip(zs, ls, gs, ws)
+            ent = self._graphs[key] = (graph, zs, ls, gs, ws, out)
+            if len(self._graphs) > 8:                             # a handful of shapes at most: drop the oldest capture
+                self._graphs.pop(next(iter(self._graphs)))
+        graph, zs, ls, gs, ws, out = ent
+        if gs is not None:
+            gs.copy_(guide)
+        if ws is not None:
+            ws.copy_(student_w)
+
+        def run(z_t):
+            zs.copy_(z_t)
+            graph.replay()
+            return out
+        return run, [ls, ls]
 
     # ---- training ----------------------------------------------------------------------------------------
     def _teacher_eval(self, z, logsnr, guide, cond_w_net, guided):
@@ -235,16 +290,18 @@ class GaussianDiffusion:
         # the network's time vector: filled once here, then by the update kernel (the next logsnr_t is this step's logsnr_s);
         # two buffers alternate so that a forward still queued on the GPU never sees its input overwritten
         first = logsnr_schedule_cosine_host(sampler_times(self.num_steps - 1, self.num_steps)[0])
-        lvecs = [torch.full((nb,), float(first), device=dev), torch.empty((nb,), device=dev)]
+        # small batches replay a captured forward (one static log-SNR buffer, safe by stream order); large ones launch it kernel by kernel
+        graphed, lvecs = self._forward_runner(module, z2 if guided else z_t, guide2 if guided else guide, sw2 if guided else student_w)
+        lvecs[0].fill_(float(first))
         for it, i in enumerate(range(self.num_steps)[::-1]):
             u_t, u_s = sampler_times(i, self.num_steps)
             lt, ls = logsnr_schedule_cosine_host(u_t), logsnr_schedule_cosine_host(u_s)
             lvec, lnext = lvecs[it & 1], lvecs[(it + 1) & 1]
             if not guided:
-                v = module.forward_hip(z_t, lvec, guide, student_w)
+                v = graphed(z_t) if graphed else module.forward_hip(z_t, lvec, guide, student_w)
                 vu = None
             else:
-                v2 = module.forward_hip(z2, lvec, guide2, sw2)
+                v2 = graphed(z2) if graphed else module.forward_hip(z2, lvec, guide2, sw2)
                 v, vu = v2[:B], v2[B:]
             noise = None
             if self.sampler == "noisy":

@@ -554,3 +554,45 @@ def test_training_learns_class_conditional_templates(compute_dtype):
     assert int((d.argmin(1) == y).sum()) >= 19, d.argmin(1).tolist()
     assert float(own.mean()) < 0.15 and float(own.mean()) * 4 < float(d.mean()), (float(own.mean()), float(d.mean()))
 
+
+
+def test_small_batch_sampler_graph_replay_is_bit_identical():
+    """Small batches (the reference's `evaluate`: 25 images) replay the U-Net forward as a captured HIP graph (GaussianDiffusion._forward_runner).
+    Same kernels in the same order: every intermediate z / x / eps of a DDIM chain, a guided chain and an ancestral chain equals the
+    kernel-by-kernel path bit for bit - also after the weights changed between two sample() calls (the packed convolution weights are
+    refreshed outside the captured region)."""
+    from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    from generative_models_amd.diffusion.optim import FusedAdam
+    net, _ = make_net(torch.bfloat16, closed_form=False)
+    net.eval()
+    B, S, T = 5, 28, 6
+    g = torch.Generator().manual_seed(11)
+    init = torch.randn((B, 1, S, S), generator=g).cuda()
+    y = torch.tensor([1, 4, -1, 9, 0]).cuda()
+    noises = torch.randn((T, B, 1, S, S), generator=g).cuda()
+    w = (4 * torch.rand(B, generator=g)).cuda()
+
+    def chains(pixels):
+        out = []
+        for kind, kw in (("ddim", {}), ("ddim", {"cond_w": 0.5, "net_cond_w": w}), ("noisy", {"noises": noises})):
+            d = GaussianDiffusion(mean_type="v", num_steps=T, sampler=kind, sample_cond_w=-1.0)
+            d.GRAPH_MAX_PIXELS = pixels
+            zs, xs, es = d.sample(net=partial(net, guide=y), init_x=init, **kw)
+            assert (len(d._graphs) > 0) == (pixels > 0)
+            out += [zs, xs, es]
+            zs2, _, _ = d.sample(net=partial(net, guide=y), init_x=init, **kw)          # second call re-uses the capture
+            assert torch.equal(zs, zs2)
+        return out
+    a, b = chains(64 * 1024), chains(0)
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+    # train one step in between: the replayed graph has to see the new weights
+    d = GaussianDiffusion(mean_type="v", num_steps=T, sampler="ddim", sample_cond_w=-1.0)
+    z0 = d.sample(net=partial(net, guide=y), init_x=init, record=False)[0]
+    net.train()
+    d.train_forward_backward(net=partial(net, guide=y), x=init.clamp(-1, 1), grad_scale=1.0 / B)
+    FusedAdam(net, lr=1e-2).step()
+    net.eval()
+    z1 = d.sample(net=partial(net, guide=y), init_x=init, record=False)[0]
+    d2 = GaussianDiffusion(mean_type="v", num_steps=T, sampler="ddim", sample_cond_w=-1.0); d2.GRAPH_MAX_PIXELS = 0
+    z2 = d2.sample(net=partial(net, guide=y), init_x=init, record=False)[0]
+    assert not torch.equal(z0, z1) and torch.equal(z1, z2)

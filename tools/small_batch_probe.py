@@ -1,4 +1,5 @@
-"""Small-batch sampling latency - the reference's own use of the sampler (`evaluate`: 25 images, diffusion_model.py:98-104; `eval_heavy`: chunks
+"""(GMK_SAMPLER_GRAPH_PIXELS=0 in the environment: kernel-by-kernel launches instead of the replayed HIP graph.)
+Small-batch sampling latency - the reference's own use of the sampler (`evaluate`: 25 images, diffusion_model.py:98-104; `eval_heavy`: chunks
 of the test batch size): DDIM steps/s at B images of 1x28x28, interleaved over the variants given as GMK_DEV_VARIANT values.
     python tools/small_batch_probe.py [B=25] [steps=200] [variants=0,8]"""
 import sys, time
