@@ -143,7 +143,7 @@ class GaussianDiffusion:
         nb = z.shape[0]
         dev = z.device
         # (a captured forward would replay ONE dropout mask: training-mode dropout keeps the kernel-by-kernel path)
-        small = 0 < nb * z.shape[2] * z.shape[3] <= self.GRAPH_MAX_PIXELS and self.num_steps >= 4 and not (module.training and module.dropout > 0.0)
+        small = 0 < nb * z.shape[2] * z.shape[3] <= self.GRAPH_MAX_PIXELS and self.num_steps >= 16 and not (module.training and module.dropout > 0.0)
         if not small:
             lvecs = [torch.empty((nb,), device=dev), torch.empty((nb,), device=dev)]      # two buffers alternate (see `sample`)
             return None, lvecs
