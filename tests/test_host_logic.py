@@ -208,6 +208,19 @@ sync2.finish()
 assert torch.allclose(net.flat_grads, expect, rtol=1e-6, atol=0)
 d = sync2.describe()
 assert d["world"] == w and d["backend"] == "gloo" and sum(d["bucket_bytes"]) == 4 * net.flat_grads.numel() and len(d["bucket_bytes"]) == 2
+# a step that raises between hook() and finish(): abort() drains what was issued and leaves the exchange reusable (round 4)
+net.flat_grads.copy_(g_local)
+sync.hook(0); sync.hook(1)
+assert len(sync.works) == 2
+sync.abort()
+assert not sync.works and not sync.issued and not sync._carved
+net.flat_grads.copy_(g_local)
+for k in range(4):
+    sync.hook(k)
+sync.finish()
+assert torch.allclose(net.flat_grads, expect, rtol=1e-6, atol=0)
+sync.set_carve(0); sync.set_carve(8)          # no-ops on a CPU arena; must not raise between steps
+assert parallel.configure_rccl_env() is None or os.environ.get("GMK_RCCL_CAP") == "1"      # the RCCL channel cap is opt-in
 x = torch.arange(8.0)
 assert parallel.shard_batch(x).tolist() == x[r * 8 // w:(r + 1) * 8 // w].tolist()
 dist.destroy_process_group()
