@@ -35,6 +35,9 @@ KERNEL_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_dma_kernel", 3: "conv3x3_
 
 
 def _nbytes(*tensors):
+    """Algorithmic bytes of a launch - only evaluated when a profile is being collected (it sits on every launch's path)."""
+    if PROFILE is None:
+        return 0.0
     return float(sum(t.numel() * t.element_size() for t in tensors if t is not None))
 
 
@@ -82,7 +85,16 @@ def dt_code(dtype):
     return _DT[dtype]
 
 
+# The current HIP stream's raw handle.  torch.cuda.current_stream() builds a Stream object and walks torch's device-index helpers (an
+# os.environ lookup among them) on every call - a quarter of the host time of a small-batch step with ~ 350 launches (tools/host_profile.py);
+# the raw getter is the same value through one C call.
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _s():
+    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+        return _RAW_STREAM(_GET_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -409,7 +421,7 @@ _WS = {}
 
 
 def _workspace(nbytes, device, tag="conv"):
-    key = (tag, device.index, torch.cuda.current_stream().cuda_stream)
+    key = (tag, device.index, _s())
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
