@@ -62,7 +62,12 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
     slab_of_block(blockIdx.x, C / CS, B, b, slab);
     const int nvec = CS >> 3, planes = kThreads / nvec;
     const int vec = tid % nvec, pl = tid / nvec;
-    const int cpg = C / G, c0 = slab * CS, g0 = c0 / cpg, gps = CS / cpg;
+    // Gq < 0 (whole-sample launches only): -Gq channels per group, any size up to 16 (widths that are not a power of two times 32: GroupNorm(32, 96)
+    // has 3 channels per group), ceil(C / cpg) groups - the last one may be partial and lies in the zero padding
+    const int Gq = G;
+    const int cpg = Gq < 0 ? -Gq : C / Gq;
+    G = Gq < 0 ? (C + cpg - 1) / cpg : Gq;
+    const int c0 = slab * CS, g0 = c0 / cpg, gps = (CS + cpg - 1) / cpg;
     const T* xb = x + (size_t)b * HW * C + c0 + vec * 8;
     T* yb = y + (size_t)b * HW * C + c0 + vec * 8;
     float ea[8];           // per-(sample, channel) addend applied to x on load (conv bias + embedding broadcast of the producer)
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void gn_silu_fwd_kernel(const T* __restri
         __syncthreads();
         if (tid < gps) {
             float ss = 0.f, qq = 0.f;
-            for (int j = 0; j < cpg; ++j) { ss += red[tid * cpg + j]; qq += red[256 + tid * cpg + j]; }
+            for (int j = 0; j < cpg && tid * cpg + j < CS; ++j) { ss += red[tid * cpg + j]; qq += red[256 + tid * cpg + j]; }
             const float n = (float)cpg * (float)HW;
             const float m = ss / n;
             const float var = fmaxf(qq / n - m * m, 0.f);
@@ -200,7 +205,10 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
     slab_of_block(blockIdx.x, C / CS, B, b, slab);
     const int nvec = CS >> 3, planes = kThreads / nvec;
     const int vec = tid % nvec, pl = tid / nvec;
-    const int cpg = C / G, c0 = slab * CS, g0 = c0 / cpg, gps = CS / cpg;
+    const int Gq = G;                              // < 0: -Gq channels per group (see gn_silu_fwd_kernel)
+    const int cpg = Gq < 0 ? -Gq : C / Gq;
+    G = Gq < 0 ? (C + cpg - 1) / cpg : Gq;
+    const int c0 = slab * CS, g0 = c0 / cpg, gps = (CS + cpg - 1) / cpg;
     const size_t base = (size_t)b * HW * C + c0 + vec * 8;
 
     float gam[8], bet[8], mu[8], rs[8];
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void gn_silu_bwd_kernel(
     __syncthreads();
     if (tid < gps) {
         float A = 0.f, Bq = 0.f;
-        for (int j = 0; j < cpg; ++j) {
+        for (int j = 0; j < cpg && tid * cpg + j < CS; ++j) {
             const int cl = tid * cpg + j;
             A = fmaf(gamma[c0 + cl], chb[cl], A);
             Bq = fmaf(gamma[c0 + cl], chg[cl], Bq);
@@ -828,16 +836,19 @@ __global__ __launch_bounds__(256) void cast16_kernel(const TS* __restrict__ src,
 
 bool gn_shape_ok(int C, int G) {
     if (C <= 0 || C > 256 || (C & 7) || 256 % (C >> 3)) return false;
+    if (G < 0) return -G >= 1 && -G <= 16;        // -G channels per group, ceil(C / -G) groups (the last one may be partial: zero padding)
     if (G <= 0 || G > 256 || C % G) return false;
     const int cpg = C / G;
     return cpg == 1 || cpg == 2 || cpg == 4 || cpg == 8 || cpg == 16;
 }
-// groups of 1 or 2 channels: the whole-sample streaming kernels with per-channel sums only (no register-resident / hybrid / fused forms)
-static bool gn_narrow(int C, int G) { return C / G < 4; }
+// groups of 1 or 2 channels, and group sizes given explicitly (G < 0: 3, 5, 6, 7 ... channels - the zero-padded widths 96, 160, 192, 224): the
+// whole-sample streaming kernels with per-channel sums only (no register-resident / hybrid / fused forms)
+static bool gn_narrow(int C, int G) { return G < 0 || C / G < 4; }
 
 // Channel slab width of one workgroup: GMK_GN_KERNEL / gmk_set_kernel_choice(gn) 1 = whole sample, 3 = 32 channels,
 // 4 = 64 channels, otherwise automatic.
 int gn_slab_channels(int mode, int C, int G, int HW, int elem_bytes, bool backward) {
+    if (G < 0) return C;                           // explicit group sizes: whole sample
     const int cpg = C / G;
     int CS = C;
     if (mode == 3) CS = 32;
@@ -867,7 +878,7 @@ extern "C" int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const
     // 64 x 64 (HW up to 4096): a 32-channel slab of a sample is 256 KiB - the registers of ONE 1024-thread workgroup (16 pixels x 16 B per
     // thread); single read instead of the streaming kernel's two sweeps
     if (gn_narrow(C, groups)) {
-        GMK_REQUIRE(!stats_part, "gmk_gn_silu_fwd: producer statistics come in 4-channel units; groups of %d channels", C / groups);
+        GMK_REQUIRE(!stats_part, "gmk_gn_silu_fwd: producer statistics come in 4-channel units; groups of %d channels", groups < 0 ? -groups : C / groups);
         gmk_note_kernel(22);
         if (dtype == GMK_BF16)
             gn_silu_fwd_kernel<bf16_t, true><<<B, kThreads, 0, gmk_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, mean, rstd, HW, C, groups,
@@ -952,7 +963,7 @@ extern "C" int gmk_gn_stats(const void* x, const float* gamma, const float* beta
     GMK_REQUIRE(tab_stride >= C, "gmk_gn_stats: tab_stride %d < C %d", tab_stride, C);
     GMK_REQUIRE(B > 0 && HW > 0 && gn_shape_ok(C, groups), "gmk_gn_stats: unsupported shape B=%d HW=%d C=%d G=%d", B, HW, C, groups);
     GMK_REQUIRE(gmk_is16(dtype), "gmk_gn_stats: 16-bit tensors only (the fused apply lives in the halo convolution)");
-    GMK_REQUIRE(!gn_narrow(C, groups), "gmk_gn_stats: groups of %d channels run the unfused GroupNorm only", C / groups);
+    GMK_REQUIRE(!gn_narrow(C, groups), "gmk_gn_stats: groups of %d channels run the unfused GroupNorm only", groups < 0 ? -groups : C / groups);
     if (C % 64 == 0 && 32 % (C / groups) == 0 && HW > 64 && gn_reg_iter(HW, 8) > 0) {      // same choice as gmk_gn_silu_fwd: same statistics bits
         const int nvec = 8;
         const int it = gn_reg_iter(HW, nvec), planes = (HW + it - 1) / it, threads = (planes * nvec + 63) / 64 * 64;

@@ -14,11 +14,13 @@ checkpoints load; every arithmetic op runs in libgmk.so (include/gmk.h).  Differ
   exposes the pair to torch.autograd so `loss.backward()` style code keeps working.
 
 Extension over the reference: `in_channels` (the reference hard-codes 1, simple_unet.py:93,41).
-Widths: `channels` 128 and 256 are native (multiples of the 128-channel MFMA tile).  32 and 64 run ZERO-PADDED to 128 channels: every
+Widths: `channels` 128 and 256 are native (multiples of the 128-channel MFMA tile).  Every other multiple of 32 up to 256 (the reference takes
+any, simple_unet.py:17) runs ZERO-PADDED to 128 (32, 64, 96) or 256 (160, 192, 224) channels: every
 parameter lives in its padded shape in the arena (the padding stays exactly zero under Adam: its gradients are exactly zero),
 GroupNorm(32, C) over the real channels becomes GroupNorm(128 / (C / 32)) over the padded ones (all-zero groups normalise to zero), and
 state_dict() / load_state_dict() / param() / grad() translate to and from the reference's shapes.  A compatibility path (3/4 or 15/16 of
-the MFMA work multiplies zeros), there so that reference checkpoints and goldens of those widths run on the HIP kernels; other widths raise.
+the MFMA work multiplies zeros), there so that reference checkpoints and goldens of those widths run on the HIP kernels; widths above 256
+(320 ... 512) raise.  Widths whose GroupNorm groups have 3, 5, 6 or 7 channels use the whole-sample streaming GroupNorm kernels with an explicit group size.
 """
 import math
 import os
@@ -115,9 +117,9 @@ def _attach(root, dotted, param):
 class SimpleUnet(nn.Module):
     def __init__(self, channels, dropout=0.0, in_channels=1, compute_dtype=torch.bfloat16, attention=False, act_dtype=None):
         super().__init__()
-        if channels not in (32, 64, 128, 256):
+        if channels % 32 or not 32 <= channels <= 256:
             raise ValueError(f"the HIP path is built for hidden_size 128 (DiffusionModel's default, every BASELINE config) and 256 (the default of "
-                             f"gms/main.py:23); 32 and 64 run zero-padded to the 128-channel MFMA tiles; got {channels}")
+                             f"gms/main.py:23); every other multiple of 32 up to 256 runs zero-padded to 128 / 256 channels; got {channels}")
         if attention and channels != 128:
             raise ValueError("the self-attention extension is built for 128 channels (one head over C = 128)")
         if not 0.0 <= dropout < 1.0:
@@ -135,11 +137,16 @@ class SimpleUnet(nn.Module):
             raise ValueError("act_dtype must equal compute_dtype, or be torch.float16 next to compute_dtype=torch.bfloat16")
         # hidden_size: the reference's `channels`; self.channels: the width the kernels run at (narrow nets zero-padded to one 128-channel tile)
         self.hidden_size = channels
-        self._narrow = channels < 128
-        self._g1 = max(channels, 128) // (channels // 32)              # GroupNorm(32, C) in the padded layout: 32 unless narrow
-        self._g2 = max(channels, 128) // (2 * channels // 32)          # GroupNorm(32, 2C) of the up blocks, groups per C-channel source: 16
+        padded = 128 if channels <= 128 else 256                      # the width the kernels run at: whole 128-channel MFMA tiles
+        self._narrow = channels != padded                             # zero-padded (32 ... 224 except 128): a compatibility path
+        # GroupNorm(32, C) has C / 32 channels per group; in the padded layout that is `padded / cpg` groups where cpg divides it (32, 64:
+        # the all-zero groups normalise to zero), and an explicit group size otherwise (96, 160, 192, 224: 3, 5, 6, 7 channels - passed as a
+        # NEGATIVE group count, ops.gn_silu_fwd).  _g2: the up blocks' GroupNorm(32, 2C), per C-channel source (16 groups of 2C / 32 channels).
+        cpg1, cpg2 = channels // 32, 2 * channels // 32
+        self._g1 = padded // cpg1 if padded % cpg1 == 0 and cpg1 in (1, 2, 4, 8, 16) else -cpg1
+        self._g2 = padded // cpg2 if padded % cpg2 == 0 and cpg2 in (1, 2, 4, 8, 16) else -cpg2
         self._real_inventory = param_inventory(channels, in_channels, bool(attention))
-        channels = max(channels, 128)
+        channels = padded
         self.channels, self.in_channels, self.compute_dtype, self.act_dtype = channels, in_channels, compute_dtype, act_dtype
         self.dropout = float(dropout)      # nn.Dropout(p) of every ResBlock's out_layers (simple_unet.py:171); training mode only
         self.drop_seed, self._drop_counter = 0x5EEDD0, 0

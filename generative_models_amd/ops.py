@@ -190,8 +190,11 @@ def gn_silu_fwd(x, gamma, beta, groups, eps=1e-5, dropout=None, xadd=None):
     B, H, W, C = x.shape
     assert gamma.numel() == C and beta.numel() == C
     y = torch.empty_like(x)
-    mean = torch.empty((B, groups), device=x.device, dtype=torch.float32)
+    # groups < 0: -groups channels per group (any size up to 16: the zero-padded widths 96, 160, 192, 224), ceil(C / -groups) groups
+    ncol = groups if groups > 0 else (C - groups - 1) // -groups
+    mean = torch.empty((B, ncol), device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
+    mean._gn_groups = groups                    # gn_silu_bwd reads the group layout from the statistics it is handed
     st = getattr(x, "_gn_stats", None)
     part, tp, nt = st if st is not None else (None, 0, 0)
     dp, dseed, doff = dropout if dropout is not None else (0.0, 0, 0)
@@ -238,7 +241,7 @@ def gn_silu_bwd(dy, x, gamma, beta, mean, rstd, dadd1=None, dadd2=None, dxsum=No
         if t is not None:
             _chk(t, dy.dtype, "dadd"); assert t.shape == x.shape
     B, H, W, C = x.shape
-    G = mean.shape[1]
+    G = getattr(mean, "_gn_groups", mean.shape[1])
     dx = torch.empty_like(dy)
     dgp = torch.empty((B, C), device=x.device, dtype=torch.float32)
     dbp = torch.empty_like(dgp)

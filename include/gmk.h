@@ -67,7 +67,10 @@ int gmk_pack_conv_weights_multi(const float* arena, void* packs, int count, cons
 
 /* ---- GroupNorm + SiLU (simple_unet.py:39-40,161-162,169-170; always adjacent in the reference) ---------
  * x,y: NHWC [B][HW][C]; `groups` groups over these C channels (a 2C-channel concatenated input is handled as
- * two calls of 16 groups each, simple_unet.py:150,161); mean/rstd: fp32 [B][groups] (written). */
+ * two calls of 16 groups each, simple_unet.py:150,161); mean/rstd: fp32 [B][groups] (written).
+ * groups < 0: -groups channels per group (1..16, any size: nn.GroupNorm(32, 96) has 3), ceil(C / -groups) groups whose last one may be
+ * partial - for zero-padded widths, where it lies in the padding; mean/rstd then have ceil(C / -groups) columns.  Same convention in
+ * gmk_gn_silu_bwd. */
 int gmk_gn_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                     int B, int HW, int C, int groups, float eps, const float* stats_part, int tile_pixels, int ntiles,
                     float drop_p, uint64_t drop_seed, uint64_t drop_offset, const float* xadd, int xadd_stride, int dtype,

@@ -400,6 +400,10 @@ def gen_sized(cin, S, B, seed, name, C=128, chain_T=0):
 
 
 def gen_r04():
+    # widths whose GroupNorm groups are not a power of two wide (3 / 6 channels; the reference takes any width, simple_unet.py:17)
+    gen_unet(96, 8, 2, 16, "unet_c96_s8.npz")
+    gen_train(96, 8, 2, 26, "train_c96_s8.npz")
+    gen_unet(192, 8, 2, 17, "unet_c192_s8.npz")
     gen_sized(1, 64, 2, 80, "sized_c128_1x64.npz", chain_T=4)      # the reference net as it stands, 64-pixel rows
     gen_sized(3, 32, 2, 81, "sized_c128_3x32.npz", chain_T=4)      # configs[2]'s image shape
     gen_sized(3, 64, 2, 82, "sized_c128_3x64.npz")                 # configs[3] / [4]'s image shape

@@ -41,6 +41,7 @@ def make_net(dtype, C=128, in_channels=1, closed_form=True):
 
 
 @pytest.mark.parametrize("name,C", [("unet_c128_s28.npz", 128), ("unet_c256_s8.npz", 256), ("unet_c64_s8.npz", 64), ("unet_c32_s8.npz", 32),
+                                    ("unet_c96_s8.npz", 96), ("unet_c192_s8.npz", 192),
                                     ("unet_c32_s12.npz", 32), ("unet_c32_s16.npz", 32)])
 def test_unet_forward_vs_golden(golden, name, C):
     """Reference outputs (closed-form fill) at hidden_size 128 (DiffusionModel's default), 256 (the default of gms/main.py:23) and the
@@ -149,6 +150,7 @@ GRAD16 = {"cosine": 0.9999, "rel_l2": 1.5e-2, "per_tensor": {"train_c128_s28.npz
 
 @pytest.mark.parametrize("name,C,dtype", [("train_c128_s28.npz", 128, torch.float32), ("train_c256_s8.npz", 256, torch.float32),
                                           ("train_c128_s28.npz", 128, torch.bfloat16), ("train_c64_s8.npz", 64, torch.float32),
+                                          ("train_c96_s8.npz", 96, torch.float32),
                                           ("train_c32_s8.npz", 32, torch.float32), ("train_c32_s16.npz", 32, torch.float32),
                                           ("train_c64_s8.npz", 64, torch.bfloat16)])
 def test_training_step_vs_golden(golden, name, C, dtype):

@@ -111,13 +111,18 @@ def test_param_inventory_and_arena():
     sd = {k: torch.full_like(v, 0.5) for k, v in net.state_dict().items()}
     net.load_state_dict(sd)
     assert float(net.flat_params[net._offsets["turn.in_layers.2.weight"]]) == 0.5 and net._packs_stale
-    with pytest.raises(ValueError):
-        SimpleUnet(96)
-    # narrow widths live zero-padded in a 128-channel arena and speak the reference's shapes at the state-dict boundary
+    for bad in (48, 320, 512):                    # not a multiple of 32 / above 256
+        with pytest.raises(ValueError):
+            SimpleUnet(bad)
+    # every other multiple of 32 up to 256 lives zero-padded in a 128- or 256-channel arena and speaks the reference's shapes at the
+    # state-dict boundary (the reference takes any width, simple_unet.py:17)
     from oracle import unet_ref as U
-    for width in (32, 64):
+    wide = SimpleUnet(256)
+    for width in (32, 64, 96, 192):
         narrow = SimpleUnet(width)
-        assert narrow.hidden_size == width and narrow.channels == 128 and narrow.flat_params.numel() == net.flat_params.numel()
+        like = net if width <= 128 else wide
+        assert narrow.hidden_size == width and narrow.channels == like.channels and narrow.flat_params.numel() == like.flat_params.numel()
+        assert (narrow._g1, narrow._g2) == {32: (128, 64), 64: (64, 32), 96: (-3, -6), 192: (-6, -12)}[width]      # groups, or -(channels per group)
         spec = U.param_spec(width)
         sdn = narrow.state_dict()
         assert [(k, tuple(v.shape)) for k, v in sdn.items()] == [(k, tuple(s)) for k, s in spec]
@@ -127,7 +132,9 @@ def test_param_inventory_and_arena():
         assert int((narrow.flat_params != 0).sum()) == int((narrow.flat_params == 0.25).sum())
         assert all(torch.equal(v, filled[k]) for k, v in narrow.state_dict().items())
         from generative_models_amd import common
-        assert common.count_vars(narrow) == sum(int(np.prod(s)) for _, s in spec) == {32: 387137, 64: 1521793}[width]
+        assert common.count_vars(narrow) == sum(int(np.prod(s)) for _, s in spec)
+        if width in (32, 64):
+            assert common.count_vars(narrow) == {32: 387137, 64: 1521793}[width]
     net3 = SimpleUnet(128, in_channels=3)
     assert sum(p.numel() for p in net3.parameters()) == 6038275
 

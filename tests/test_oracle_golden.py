@@ -62,7 +62,8 @@ def test_embedding_and_algebra(golden):
 
 
 @pytest.mark.parametrize("name,C", [("unet_c32_s8.npz", 32), ("unet_c32_s12.npz", 32), ("unet_c32_s16.npz", 32),
-                                    ("unet_c128_s28.npz", 128), ("unet_c64_s8.npz", 64), ("unet_c256_s8.npz", 256)])
+                                    ("unet_c128_s28.npz", 128), ("unet_c64_s8.npz", 64), ("unet_c256_s8.npz", 256),
+                                    ("unet_c96_s8.npz", 96), ("unet_c192_s8.npz", 192)])
 def test_unet_forward(golden, name, C):
     g = golden(name)
     p = U.closed_form_params(C)
@@ -73,7 +74,7 @@ def test_unet_forward(golden, name, C):
         close(U.unet_forward(p, z, l, guide=y, cond_w=T(g["cond_w"])), g["v_condw"], 2e-5)
 
 
-@pytest.mark.parametrize("name,C", [("train_c32_s8.npz", 32), ("train_c32_s16.npz", 32), ("train_c128_s28.npz", 128), ("train_c64_s8.npz", 64),
+@pytest.mark.parametrize("name,C", [("train_c32_s8.npz", 32), ("train_c32_s16.npz", 32), ("train_c128_s28.npz", 128), ("train_c64_s8.npz", 64), ("train_c96_s8.npz", 96),
                                     ("train_c256_s8.npz", 256)])
 def test_training_loss_and_grads(golden, name, C):
     g = golden(name)
