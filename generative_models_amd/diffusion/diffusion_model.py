@@ -97,6 +97,8 @@ def make_plugin(GMBase, AttrDict):
             if self._sync is None:
                 self._sync = parallel.GradSync(self.net)
             world = parallel.world()
+            if self._graphable(x, world):
+                return self._train_step_graphed(x, y)
             try:
                 out = self.diffusion.train_forward_backward(net=partial(self.net, guide=y), x=x, grad_scale=1.0 / B,
                                                             on_grads_ready=self._sync.hook, join_side_before_ready=False)
@@ -108,6 +110,59 @@ def make_plugin(GMBase, AttrDict):
             metrics = {"loss": ops.mean(out["loss"])}
             ops.throttle()                          # at most two steps queued on the GPU (see ops.throttle)
             metrics["loss_scale"] = torch.tensor(1.0)
+            return metrics
+
+        # -- small batches: the step as a replayed HIP graph ------------------------------------------------------------------
+        # The reference's default invocation trains at bs = 32 (BASELINE configs[0]).  At that size a step is ~ 350 kernel launches whose host
+        # side (ctypes + torch allocations, 4.6 - 5.0 ms) exceeds the GPU's work (3.5 ms): forward, loss, backward and the loss mean are captured once
+        # per input shape and replayed; the random draws (same Philox streams, same order), the label drop on the CALLER's y, the copies into
+        # the static inputs and the fused Adam (its step count changes every step) stay outside.  Same kernels, same arguments: the
+        # parameters after k steps equal the kernel-by-kernel path's bit for bit (tests/test_gpu_unet.py).  The weight gradients run on the main
+        # stream inside the capture (the side stream pays at sizes that fill the chip).  Measured, same box: bs = 32 5.00 -> 3.46 ms per step,
+        # bs = 64 4.69 -> 4.14, bs = 128 5.11 -> 5.23 (hence the 64 Ki-pixel limit).  GMK_TRAIN_GRAPH_PIXELS=0 turns it off.
+        TRAIN_GRAPH_MAX_PIXELS = int(os.environ.get("GMK_TRAIN_GRAPH_PIXELS", str(64 * 1024)))
+
+        def _graphable(self, x, world):
+            return (world == 1 and self.teacher_net is None and self.net.dropout == 0.0 and x.is_cuda and x.dim() == 4 and
+                    0 < x.shape[0] * x.shape[2] * x.shape[3] <= self.TRAIN_GRAPH_MAX_PIXELS and ops.PROFILE is None)
+
+        def _train_step_graphed(self, x, y):
+            B, dev = x.shape[0], x.device
+            rng = self.diffusion.rng
+            eps = rng.normal(x.shape, dev)                      # the draw order of GaussianDiffusion._prepare: eps, then u
+            u = rng.uniform((B,), dev)
+            key = (tuple(x.shape), y.dtype)
+            graphs = self.__dict__.setdefault("_train_graphs", {})
+            ent = graphs.get(key)
+            if ent is None:
+                xs, ys, es, us = x.float().clone(), y.clone(), eps.clone(), u.clone()
+                side_was, side_stream = ops.WGRAD_STREAM, self.net._side
+                # nothing outside the capturing stream may be joined from inside the capture; the weight gradients stay on the main stream
+                # (GMK_TRAIN_GRAPH_SIDE=1 gives them a side stream of the capture's own: measured slower at these sizes, 3.68 vs 3.46 ms at bs = 32)
+                ops.WGRAD_STREAM, self.net._side = side_was and os.environ.get("GMK_TRAIN_GRAPH_SIDE", "0") == "1", None
+                try:
+                    run = lambda: self.diffusion.train_forward_backward(net=partial(self.net, guide=ys), x=xs, grad_scale=1.0 / B, u=us, eps=es,
+                                                                        on_grads_ready=self._sync.hook, join_side_before_ready=False)
+                    warm = torch.cuda.Stream(device=dev)        # warm-up off the capture: packs, workspaces, allocator pools (gradients only)
+                    warm.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(warm):
+                        run()
+                    torch.cuda.current_stream().wait_stream(warm)
+                    self.net.mark_params_changed()              # the captured forward has to contain the weight re-pack every step needs
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        loss = ops.mean(run()["loss"])
+                finally:
+                    ops.WGRAD_STREAM, self.net._side = side_was, side_stream
+                ent = graphs[key] = (graph, xs, ys, es, us, loss)
+                if len(graphs) > 4:
+                    graphs.pop(next(iter(graphs)))
+            graph, xs, ys, es, us, loss = ent
+            xs.copy_(x); ys.copy_(y); es.copy_(eps); us.copy_(u)
+            graph.replay()
+            self.optimizer.step(grad_scale=1.0)
+            metrics = {"loss": loss.clone(), "loss_scale": torch.tensor(1.0)}
+            ops.throttle()
             return metrics
 
         # -- loss (:76-80): differentiable through torch.autograd; used by the driver's test-set pass
