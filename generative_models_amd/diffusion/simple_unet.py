@@ -445,10 +445,9 @@ class SimpleUnet(nn.Module):
             if fold and ops.SKIP_FOLD_OVER_FUSE:      # the fold and the in-convolution GroupNorm do not combine (yet): conv2's input is materialised
                 a2, _, _ = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], self._g1, xadd=eadd)
                 return conv2_folded(a2)
-            if fold:
-                run_skip_now = self._conv(srcs, self._packs[f"{name}.skip_connection"][0], C, 1, ops.NORMAL, (H, W),
-                                          bias=P[f"{name}.skip_connection.bias"])
-                skip["res"] = run_skip_now
+            if fold:          # GMK_SKIP_FOLD_FUSE=fuse: conv2 keeps its in-convolution GroupNorm, the skip convolution its own launch
+                skip["res"] = self._conv(srcs, self._packs[f"{name}.skip_connection"][0], C, 1, ops.NORMAL, (H, W),
+                                         bias=P[f"{name}.skip_connection.bias"])
             t2c = torch.empty((B, C), device=h.device, dtype=torch.float32)
             t2h = torch.empty_like(t2c)
             ops.gn_stats(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], self._g1, t2c, t2h, xadd=eadd)
