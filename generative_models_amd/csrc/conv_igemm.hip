@@ -1023,8 +1023,8 @@ static int conv_igemm_impl(const void* src0, const void* src1, int c0, int c1, i
             return gmk_check_launch("gmk_conv_igemm(stride-2 dgrad phases)");
         }
     }
-    GMK_REQUIRE(!gn_scale, "gmk_conv_igemm: the fused GroupNorm-apply needs the 3x3 halo kernel (bf16, plain 3x3, a tile within two samples, "
-                           ">= 32 tiles): ask gmk_conv_gn_fusable first");
+    GMK_REQUIRE(!gn_scale, "gmk_conv_igemm: the fused GroupNorm-apply needs the 3x3 halo kernel (16-bit, plain 3x3, a tile within two samples): "
+                           "ask gmk_conv_gn_fusable first");
     // LDS-DMA kernel: problems with at least ~2 tiles of 256 pixels per CU, buffers addressable with 32-bit offsets
     const int64_t nbo = (int64_t)p.M * out_cstride * es;
     const bool fits = nb0 < lim && nb1 < lim && nbw < lim && nbo < lim && (int64_t)B * hs * ws < 0x00FFFFFF &&

@@ -47,6 +47,7 @@ struct SlotParams {
     float* slab;                 // [nsplit][9][cout][ktot]
     int nchunks, chunks_per_split;
     unsigned nbdy, nb0, nb1;
+    int variant;                 // GMK_DEV_VARIANT (experiments)
 };
 
 struct SlotPos { int b, ye, xe; };
@@ -333,9 +334,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
             }
             return 2;
         };
-        auto issue_y = [&]() {
-            unsigned p0, p1;
-            if constexpr (kShare) {        // dY chunk yc = the X chunk decoded LOOK issues ago (every issue_y follows an X issue: hist[0])
+        auto y_pixels = [&](unsigned& p0, unsigned& p1) {
+            if constexpr (kShare) {        // dY chunk yc = the X chunk decoded LOOK issues ago (every dY issue follows an X issue: hist[0])
                 p0 = hist[0][0]; p1 = hist[0][1];
             } else {
                 int r1 = yrow, x1 = yxe;
@@ -343,6 +343,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
                 p0 = pixel(yrow, yxe, 0); p1 = pixel(r1, x1, 0);
                 advance(yrow, yxe, d64r, d64x);
             }
+        };
+        auto issue_y = [&]() {
+            unsigned p0, p1;
+            y_pixels(p0, p1);
             GMK_LDS char* dst = (GMK_LDS char*)(smem + kWsDyBase + (yc & 7) * 8192 + pw * 2048);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (GMK_LDS void*)dst, 16, __umul24(p0, ys_b) + yoff_b + lc, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (GMK_LDS void*)(dst + 1024), 16, __umul24(p1, ys_b) + yoff_b + lc, 0, 0, 0);
@@ -367,6 +371,32 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
                 asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[1]) : "v"(v1), "s"(xdesc) : "memory");
                 rp = xc & 7;
                 ++xc;
+            };
+            // dY through registers too (round 4).  The two ci-tiles of a split read the same dY half rows in step, on one XCD; LDS-DMA reads of one
+            // line by two workgroups both reach the memory side, register loads are merged by the L2 (tools/fetch_probe.hip: counter / bytes 1.0
+            // against 0.5).  With dY by `buffer_load ... lds` the kernel fetched X + 2 dY = 1.5 x its algorithmic bytes; through the same
+            // register pipeline as X (loaded five blocks ahead, written to the dY ring two blocks ahead, no conversion) the corrected FETCH_SIZE of
+            // the large launches drops by 37 % (2,092 -> 1,323 MB on tools/wgrad_y_ab.py's mix) and the kernel runs 0.5 - 2.8 % faster, the
+            // same bits in LDS (the DMA form was A/B'd behind a runtime switch and then removed: one more compare in the step loop for nothing).
+            const unsigned long long ybase = (unsigned long long)p.dy;
+            const i32x4 ydesc = {(int)(unsigned)ybase, (int)((unsigned)(ybase >> 32) & 0xFFFFu), (int)p.nbdy, 0x00020000};
+            u32x4 yr[NSET][2];
+            int yrp[NSET];
+            auto load_y = [&](u32x4 (&r)[2], int& rp) {
+                unsigned p0, p1;
+                y_pixels(p0, p1);
+                const unsigned v0 = __umul24(p0, ys_b) + yoff_b + lc, v1 = __umul24(p1, ys_b) + yoff_b + lc;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[0]) : "v"(v0), "s"(ydesc) : "memory");
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[1]) : "v"(v1), "s"(ydesc) : "memory");
+                rp = yc & 7;
+                ++yc;
+            };
+            auto store_y = [&](u32x4 (&r)[2], int rp) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    asm volatile("" : "+v"(r[u]));
+                    *reinterpret_cast<u32x4*>(smem + kWsDyBase + rp * 8192 + pw * 2048 + u * 1024 + lane * 16) = r[u];
+                }
             };
             auto store_x = [&](u32x4 (&r)[2], int rp) {       // fp16 -> bf16, ds_write_b128 (+ mirror)
 #pragma unroll
@@ -397,7 +427,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
                 for (int k = 0; k < 2 * LOOK + 2; ++k) store_x(t[k], tp[k]);
             }
 #pragma unroll
-            for (int k = 2; k < FA; ++k) { load_x(xr[k % NSET], xrp[k % NSET]); issue_y(); }
+            for (int k = 2; k < FA; ++k) {
+                load_x(xr[k % NSET], xrp[k % NSET]);
+                load_y(yr[k % NSET], yrp[k % NSET]);
+            }
+
             // Step s.  Block k (X chunk c + k + LOOK, dY chunk c + k) has to be in LDS at barrier k - 1.  Its ds_writes are issued during step
             // k - 2 and only awaited at the top of step k - 1: a whole step for them to drain through an LDS queue the consumers keep full
             // (waiting for them in front of the same step's barrier put that latency on the barrier: +7 ... 10 %).
@@ -408,10 +442,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 load_x(xr[LSET], xrp[LSET]);
-                issue_y();
+                load_y(yr[LSET], yrp[LSET]);
                 static_assert(FA == 5, "the literal below is 4 x (FA - 2)");
                 asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 store_x(xr[SSET], xrp[SSET]);
+                store_y(yr[SSET], yrp[SSET]);
             };
             for (int s = 0; s < nsteps;) {        // load set (s + FA) % NSET = (s + 1) % 4, store set (s + 2) % 4: statically indexed
                 step(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}); ++s;
@@ -557,6 +592,7 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
     p.xshift = upsample ? 1 : 0;
     p.B = B; p.H = H; p.W = W; p.WE = WE; p.RE = RE; p.slab = slab; p.nchunks = nchunks; p.chunks_per_split = cps;
     p.nbdy = (unsigned)nbdy; p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1;
+    p.variant = gmk_kernel_choice(3, "GMK_DEV_VARIANT") & 0xFF;
     dim3 grid(ns, ktot / 64, cout / 128);
     // forced: 0 automatic = 3 the wave-specialised kernel (1.37 - 1.58 x the 8-compute-wave kernel at every shape of the train step:
     // tools/wgrad_bench.py); 2 the 8-compute-wave kernel (A/B)

@@ -556,7 +556,8 @@ def test_wgrad_register_loads_stay_untouched_while_in_flight():
       * no scratch memory, no VGPR / SGPR spills;
       * on EVERY path from a register load, no instruction reads or writes its destination registers while the load may still be in flight
         (in-order vmcnt: it has retired once a `vmcnt(N)` is crossed with at least N younger VMEM operations issued), and the first
-        instruction that does read them is the fp16 -> fp32 conversion that consumes the chunk;
+        instruction that does read them is their consumer - the fp16 -> fp32 conversion of an activation chunk, the `ds_write_b128` of a dY
+        chunk (round 4: dY takes the same register pipeline);
       * between two barriers of the steady-state loop exactly four VMEM operations are issued on every path (the literal 12 = 4 x 3 steps)."""
     L = _device_asm("conv_wgrad_slots.hip")
     text = "\n".join(L)
@@ -655,7 +656,8 @@ def test_wgrad_register_loads_stay_untouched_while_in_flight():
                     if not retired:
                         open("/tmp/gmk_isa_trace.txt", "w").write(trace(st).replace(" <- ", "\n"))
                     assert retired, (name, ins[k0], "touched while possibly in flight by", t, "path in /tmp/gmk_isa_trace.txt")
-                    hit = hit or t.startswith("v_cvt_f32_f16")
+                    # the consumers: the fp16 -> fp32 conversion of an activation chunk, the LDS write of a dY chunk (no conversion)
+                    hit = hit or t.startswith("v_cvt_f32_f16") or t.startswith("ds_write_b128")
                     continue                                   # the value is consumed or dead behind this instruction
                 if is_vmem(t):
                     younger = min(younger + 1, 63)
@@ -664,7 +666,7 @@ def test_wgrad_register_loads_stay_untouched_while_in_flight():
                     parent.setdefault(nxt_st, st)
                     stack.append(nxt_st)
             consumed += hit
-        assert consumed >= 8, (name, consumed)                  # the steady-state loads all reach their conversion
+        assert consumed >= 16, (name, consumed)                 # the steady-state loads (8 activation + 8 dY per 4 unrolled steps) all reach their consumer
         # four VMEM operations between two barriers of the steady-state loop, on every path
         bars = [k for k, t in enumerate(ins) if t == "s_barrier"]
 
