@@ -23,6 +23,8 @@
 //   reference's [Cout][Cin][k][k] layout.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gmk_common.h"
 
 namespace {
@@ -617,6 +619,8 @@ struct WgradParams {
     GatherParams g;
     float* slab;        // [nsplit][taps][cout][ktot]
     int M, chunk;       // pixels, pixels per split (multiple of 64)
+    int ns, taps;       // splits, filter taps (the grid is 1-D: see the block decode)
+    int order;          // 1: the (split, tap, block) order of rounds 1 - 3 (GMK_DEV_VARIANT=61, A/B)
 };
 
 // T: type of dy (and of the MFMA operands); TX: storage type of the activation operand.  TX = f16_t with T = bf16_t is the train
@@ -639,17 +643,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int wm = wave >> 1, wn = wave & 1;
     const GatherParams g = p.g;
     const int hw_o = g.ho * g.wo;
-    const int tap = blockIdx.y;
-    const int ky = tap / g.ksize, kx = tap - ky * g.ksize;
+    // 1-D grid, decoded so that the workgroups of ONE pixel range - its taps, its ci blocks, its co blocks: they all read the same dY rows,
+    // the taps overlapping X rows too - sit 8 block ids apart: on one XCD (block id mod 8) and next to each other in its dispatch order.  Then
+    // the first of them pulls a line into that XCD's L2 and the others find it there, and because a workgroup that hits runs ahead until it
+    // misses, they fall into step.  (As a (split, tap, block) grid they were `nsplit` ids apart: same XCD, but out of step by more than the
+    // L2 holds - the K = 256 skip convolution fetched dY twice, the stride-2 im2col form most lines several times: FETCH_SIZE of
+    // tools/wgrad_im2col_ab.py's mix 1,997 -> 1,348 MB per launch, 3 - 8 % of the time at 64 x 64 / 28 x 28 and of the stride-2 launches.)
+    // (One workgroup for BOTH input blocks of the skip convolution, dY staged once - 96 KiB of LDS, one workgroup per CU - was built and
+    // measured 3 - 5 % slower than two workgroups that meet in L2.)
     const int ncib = p.ktot / 128;
-    const int cib = blockIdx.z % ncib, cob = blockIdx.z / ncib;
+    const int ntile = p.taps * ncib * (p.cout / 128);
+    const int bj = blockIdx.x >> 3;
+    const int split = p.order ? (int)(blockIdx.x % p.ns) : (bj / ntile) * 8 + (blockIdx.x & 7);
+    const int tl = p.order ? (int)(blockIdx.x / p.ns) : bj % ntile;
+    if (split >= p.ns || tl >= ntile) return;
+    const int tap = tl % p.taps, bz = tl / p.taps;
+    const int ky = tap / g.ksize, kx = tap - ky * g.ksize;
+    const int cib = bz % ncib, cob = bz / ncib;
     const int kelem0 = cib * 128;
     const TX* src; int cs, ci_off;
     if (kelem0 < p.c0) { src = (const TX*)p.src0; cs = p.c0; ci_off = kelem0; }
     else { src = (const TX*)p.src1; cs = p.c1; ci_off = kelem0 - p.c0; }
     const T* dy = (const T*)p.dy + cob * 128;
 
-    const int pix_begin = blockIdx.x * p.chunk;
+    const int pix_begin = split * p.chunk;
     const int pix_end = min(pix_begin + p.chunk, p.M);
     const int nk = pix_end > pix_begin ? (pix_end - pix_begin + KP - 1) / KP : 0;
 
@@ -663,8 +680,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         if constexpr (ES == 2) lds_w[i] = row * 256 + ((((sc >> 2) ^ (row & 3)) << 2 | (sc & 3)) << 4);
         else lds_w[i] = row * 512 + sc * 16;
     }
-    u32x4 ry[4], rx[4];
-    auto load_step = [&](int ks) {
+    // two K-steps of operands in flight per thread (register sets ks & 1; one step ahead: 2 - 3 % slower on the 1x1 launches)
+    u32x4 ryy[2][4], rxx[2][4];
+    auto load_step = [&](int ks, u32x4 (&ry)[4], u32x4 (&rx)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = pix_begin + ks * KP + srow + RSTEP * i;
@@ -684,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             ry[i] = vy; rx[i] = vx;
         }
     };
-    auto write_step = [&](int buf) {
+    auto write_step = [&](int buf, u32x4 (&ry)[4], u32x4 (&rx)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<u32x4*>(Ys + buf * 16384 + lds_w[i]) = ry[i];
@@ -715,13 +733,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int r = lane & 31, h = lane >> 5;
 
     if (nk > 0) {
-        load_step(0);
-        write_step(0);
+        load_step(0, ryy[0], rxx[0]);
+        if (nk > 1) load_step(1, ryy[1], rxx[1]);
+        write_step(0, ryy[0], rxx[0]);
     }
     __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nk) load_step(ks + 1);
+    auto k_step = [&](int ks, auto par) {
+        constexpr int PAR = decltype(par)::value;          // ks & 1: LDS buffer of this step, register set of step ks + 2
+        const int buf = PAR;
+        if (ks + 2 < nk) load_step(ks + 2, ryy[PAR], rxx[PAR]);
         const char* Yb = Ys + buf * 16384;
         const char* Xb = Xs + buf * 16384;
         if constexpr (ES == 2) {
@@ -767,12 +787,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (ks + 1 < nk) write_step(buf ^ 1);
+        if (ks + 1 < nk) write_step(buf ^ 1, ryy[PAR ^ 1], rxx[PAR ^ 1]);
         __syncthreads();
+    };
+    for (int ks = 0; ks < nk; ks += 2) {
+        k_step(ks, std::integral_constant<int, 0>{});
+        if (ks + 1 < nk) k_step(ks + 1, std::integral_constant<int, 1>{});
     }
 
     // slab[split][tap][co][ci]
-    float* slab = p.slab + (((int64_t)blockIdx.x * gridDim.y + tap) * p.cout + cob * 128) * p.ktot + kelem0;
+    float* slab = p.slab + (((int64_t)split * p.taps + tap) * p.cout + cob * 128) * p.ktot + kelem0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1120,7 +1144,8 @@ extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, 
                 (long long)need);
     p.slab = (float*)workspace;
     gmk_note_kernel(11);
-    dim3 grid(ns, taps, (cout / 128) * (p.ktot / 128));
+    p.ns = ns; p.taps = taps; p.order = (gmk_kernel_choice(3, "GMK_DEV_VARIANT") & 0xFF) == 61;
+    dim3 grid((ns + 7) / 8 * 8 * taps * (cout / 128) * (p.ktot / 128));
     if (dtype == GMK_BF16 && xf16) conv_wgrad_kernel<bf16_t, f16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
     else if (dtype == GMK_BF16) conv_wgrad_kernel<bf16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
     else conv_wgrad_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(p);

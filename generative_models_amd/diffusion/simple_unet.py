@@ -251,6 +251,7 @@ class SimpleUnet(nn.Module):
         self._plist = [named[n] for n, _ in self._inventory]
         self._packed_version = -1
         self._side = None          # side stream of the weight gradients (backward_hip)
+        self._cu_part = None       # (CUs of the chip, CUs of the side stream) while a partitioned backward pass is being enqueued
         self._packs_stale = True
         self._freqs = {}
 
@@ -560,8 +561,15 @@ class SimpleUnet(nn.Module):
             self._side = torch.cuda.Stream(device=tensors[0].device)
         side = self._side
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fn()
+        part = self._cu_part
+        if part is not None:               # the side stream's persistent grids take `part[1]` CUs, the chain's the rest (backward_hip)
+            ops.set_cu_limit(part[1])
+        try:
+            with torch.cuda.stream(side):
+                fn()
+        finally:
+            if part is not None:
+                ops.set_cu_limit(part[0] - part[1])
         for t in tensors:
             t.record_stream(side)
 
@@ -684,6 +692,16 @@ class SimpleUnet(nn.Module):
         joins the side stream in front of every callback (a callback may then read the bucket in current-stream order); a consumer
         that orders its own stream behind BOTH streams (parallel.GradSync: the all-reduce runs on a third stream) passes False, and
         the data-gradient chain on the current stream never waits for the weight gradients."""
+        if ops.WGRAD_CUS > 0 and ops.WGRAD_STREAM and dout.is_cuda and self._cu_part is None and not (
+                torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
+            full = ops.get_cu_limit()
+            self._cu_part = (full, min(ops.WGRAD_CUS, full - 8))
+            ops.set_cu_limit(full - self._cu_part[1])
+            try:
+                return self.backward_hip(ctx, dout, on_grads_ready, join_side_before_ready)
+            finally:
+                ops.set_cu_limit(full)
+                self._cu_part = None
         ready = on_grads_ready if on_grads_ready is not None else (lambda k: None)
         join = self._join_side if (on_grads_ready is not None and join_side_before_ready) else (lambda: None)
         P, G, C, T = self._pv, self._gv, self.channels, self.compute_dtype

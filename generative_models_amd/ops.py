@@ -114,6 +114,15 @@ def _chk(t, dtype=None, name="tensor"):
     return t
 
 
+def get_cu_limit():
+    return lib.gmk_get_cu_limit()
+
+
+def set_cu_limit(n):
+    """CUs the persistent grids launched from here on may occupy (read by the host at launch time)."""
+    check(lib.gmk_set_cu_limit(int(n)), "set_cu_limit")
+
+
 def aligned(t):
     """Contiguous, 16-byte aligned version of a caller-supplied tensor (a slice of a batch may start anywhere)."""
     if t is None:
@@ -171,6 +180,7 @@ GN_FUSE_MIN_HW = int(os.environ.get("GMK_GN_FUSE_MIN_HW", "2048"))
 SKIP_FOLD = os.environ.get("GMK_SKIP_FOLD", "1") != "0"
 SKIP_FOLD_OVER_FUSE = os.environ.get("GMK_SKIP_FOLD_FUSE", "fold") != "fuse"
 FWD_SIDE = os.environ.get("GMK_FWD_SIDE", "0") == "1"          # forward 1x1 skip convolutions on the side stream (simple_unet._res_fwd)
+WGRAD_CUS = int(os.environ.get("GMK_WGRAD_CUS", "0"))           # > 0: the side stream's persistent grids take this many CUs, the data-gradient chain's the rest
 WGRAD_STREAM = os.environ.get("GMK_WGRAD_STREAM", "1") != "0"    # weight gradients on a side stream beside the data-gradient chain (simple_unet._wgrad)
 
 

@@ -61,6 +61,6 @@ cp $OUT/bench.json profiles/r04_bench.json                     # the compact lin
 cp gpurun_out/bench_detail.json profiles/r04_bench_detail.json   # the full record of the same run
 python tests/parity_report.py > profiles/r04_parity_report.txt 2>/dev/null || exit 1
 python tests/trajectory_report.py 150 2>/dev/null | grep -v "^oracle step" > profiles/r04_trajectory_report.txt || exit 1
-if [[ " $PARTS " == *" stats "* ]]; then cp profiles/r04_* $KEEP/; else cp profiles/r04_traffic.json profiles/r04_bench.json profiles/r04_parity_report.txt profiles/r04_trajectory_report.txt $KEEP/; fi
+if [[ " $PARTS " == *" stats "* ]]; then cp profiles/r04_* $KEEP/; else cp profiles/r04_traffic.json profiles/r04_bench.json profiles/r04_bench_detail.json profiles/r04_parity_report.txt profiles/r04_trajectory_report.txt $KEEP/; fi
 cp $OUT/*.log $OUT/bench.err $KEEP/ 2>/dev/null
 tail -c 300 $OUT/bench.json
