@@ -58,7 +58,8 @@ __global__ void dma_half(const void* src, unsigned nbytes, int h) {
 
 // Same-XCD sharing: 512 co-resident workgroups (2 per CU); blocks b and b + 256 (same XCD: ids 256 apart) walk the SAME half rows in step, like
 // the two output-channel tiles of a weight-gradient split that share the X operand.  delay: the second block of a pair starts ~`delay` us late.
-template <bool kDma>
+// kAux: cache-policy bits of the LDS-DMA load (gfx950: 1 = sc0, 2 = nt, 16 = sc1) - does any of them make the L2 serve the second reader?
+template <bool kDma, int kAux = 0>
 __global__ void pair_half(const void* src, unsigned* sink, unsigned nbytes, int delay) {
     __shared__ __attribute__((aligned(16))) char lds[4 * 1024];
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, (int)nbytes, 0x00020000);
@@ -70,7 +71,7 @@ __global__ void pair_half(const void* src, unsigned* sink, unsigned nbytes, int 
     const unsigned waves = 256 * (blockDim.x >> 6);
     for (unsigned k = b * (blockDim.x >> 6) + wave; k < nbytes / 256 / 8; k += waves) {
         const unsigned off = (8 * k + (lane >> 3)) * 256u + (lane & 7) * 16u;
-        if (kDma) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDSP void*)dst, 16, off, 0, 0, 0);
+        if (kDma) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDSP void*)dst, 16, off, 0, 0, kAux);
         else acc ^= __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -99,6 +100,11 @@ int main() {
             flush(); pair_half<false><<<512, kBlock>>>(a, sink, lim, delay);
             flush(); pair_half<true><<<512, kBlock>>>(a, sink, lim, delay);
         }
+        flush(); pair_half<true, 1><<<512, kBlock>>>(a, sink, lim, 0);
+        flush(); pair_half<true, 2><<<512, kBlock>>>(a, sink, lim, 0);
+        flush(); pair_half<true, 16><<<512, kBlock>>>(a, sink, lim, 0);
+        flush(); pair_half<true, 17><<<512, kBlock>>>(a, sink, lim, 0);
+        flush(); pair_half<true, 3><<<512, kBlock>>>(a, sink, lim, 0);
         flush(); store_full<<<kGrid, kBlock>>>((u32x4*)a, kBytes / 16);
     }
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }

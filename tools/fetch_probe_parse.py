@@ -18,6 +18,7 @@ for (name, counter), vals in sorted(rows.items()):
         if name == "reg_half":
             tag = "reg_half" if i % 2 == 0 else "reg_half_twice"
         if name.startswith("void pair_half") or name.startswith("pair_half"):
-            tag = "pair_same_xcd_dma" if "true" in r_names[(name, d)] else "pair_same_xcd_reg"      # (launched with start delays 0 / 2 / 4 us, in that order per kind)
+            full = r_names[(name, d)]
+            tag = ("pair_same_xcd_dma aux " + full.split("<")[1].split(">")[0].split(",")[-1].strip() if "true" in full else "pair_same_xcd_reg")      # (launched with start delays 0 / 2 / 4 us, in that order per kind)
         b = known.get(name, 0) or (GiB - 65536) // 2
-        print(f"{tag:16s} dispatch {d:3d} {counter:10s} = {v * 1024 / 1e6:10.1f} MB (counter x 1 KiB)   known bytes {b / 1e6:8.1f} MB   counter / known = {v * 1024 / b if b else 0:.3f}")
+        print(f"{tag:26s} dispatch {d:3d} {counter:10s} = {v * 1024 / 1e6:10.1f} MB (counter x 1 KiB)   known bytes {b / 1e6:8.1f} MB   counter / known = {v * 1024 / b if b else 0:.3f}")
