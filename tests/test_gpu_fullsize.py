@@ -105,6 +105,34 @@ def test_forward_is_bit_reproducible_with_the_skip_convs_on_the_side_stream(net)
     assert all(torch.equal(outs[0], o) for o in outs[1:]) and torch.equal(outs[0], plain)
 
 
+def test_backward_is_bit_reproducible_with_the_weight_gradients_on_the_side_stream(net):
+    """The backward analogue of the test above, for the overlap that is ON by default (ops.WGRAD_STREAM: every weight gradient beside the
+    data-gradient chain, the same co-residency pattern): eight identical train passes at the full batch give the same gradient arena bit for
+    bit, equal to the arena of a pass with every kernel on ONE stream; and with the chip partitioned between the two streams
+    (ops.WGRAD_CUS: other split counts, i.e. another fp32 summation order of the weight-gradient slabs) the same values to rounding."""
+    from generative_models_amd import ops
+    from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    d = GaussianDiffusion(mean_type="v", num_steps=1000)
+    x, y, u, eps = data(7)
+    run = lambda: (d.train_forward_backward(net=partial(net, guide=y), x=x, grad_scale=1.0 / B, u=u, eps=eps)["loss"].clone(), net.flat_grads.clone())
+    keep, keep_cus = ops.WGRAD_STREAM, ops.WGRAD_CUS
+    try:
+        ops.WGRAD_STREAM, ops.WGRAD_CUS = True, 0
+        runs = [run() for _ in range(8)]
+        ops.WGRAD_STREAM = False
+        loss1, grads1 = run()
+        ops.WGRAD_STREAM, ops.WGRAD_CUS = True, 96
+        loss_p, grads_p = run()
+        assert ops.get_cu_limit() == 256                         # the partition is undone behind the pass
+    finally:
+        ops.WGRAD_STREAM, ops.WGRAD_CUS = keep, keep_cus
+    assert all(torch.equal(runs[0][0], l) and torch.equal(runs[0][1], g) for l, g in runs[1:])
+    assert torch.equal(runs[0][0], loss1) and torch.equal(runs[0][1], grads1)
+    assert torch.equal(loss_p, loss1)
+    rel = float((grads_p - grads1).abs().max() / grads1.abs().max())
+    assert rel < 1e-4, rel
+
+
 def test_fused_groupnorm_forward_equals_materialised_forward(net):
     """Inference forward with GroupNorm-apply + SiLU inside the convolutions (ops.GN_FUSE, the default) against the forward that
     materialises the normalised tensors (the training path's forward): the same bits, at the full batch."""
