@@ -93,6 +93,7 @@ def parse():
     ap.add_argument("--size", type=int, default=28)
     ap.add_argument("--in_channels", type=int, default=1)
     ap.add_argument("--attention", type=int, default=0)
+    ap.add_argument("--hidden", type=int, default=128, help="hidden_size of a custom config (the reference's gms/main.py default is 256)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--sampler_steps", type=int, default=1000, help="T of the headline's guidance-off DDIM loop (0: skip the samplers)")
     ap.add_argument("--sampler_steps_other", type=int, default=100, help="loop length of the other sampler modes / configs")
@@ -398,6 +399,8 @@ class Bench:
         G = common.AttrDict(dict(Model.DG))
         G.update(lr=3e-4, pad32=0, device=str(self.dev), timesteps=1000, bs=B, compute_dtype=a.dtype, in_channels=cin, seed=0,
                  attention=attention)
+        hidden = a.hidden if key == "custom" else 128
+        G.hidden_size = hidden
         model = Model(G).to(self.dev)
         model.size = S
         from generative_models_amd import parallel
@@ -413,11 +416,11 @@ class Bench:
         prof = None if a.no_profile else []
         elapsed, nprof = self.timed_steps(model, batches, steps, prof)
         ips = self.world * B * steps / elapsed
-        out = {"workload": f"DDPM train step, {cin}x{S}x{S}, SimpleUnet C=128{' + self-attention' + (' (fp8 QK^T / PV)' if attention == 2 else '') if attention else ''}, "
+        out = {"workload": f"DDPM train step, {cin}x{S}x{S}, SimpleUnet C={hidden}{' + self-attention' + (' (fp8 QK^T / PV)' if attention == 2 else '') if attention else ''}, "
                            f"{B} images per GPU, T=1000 (BASELINE.json {what.split(':')[0]})", "baseline_entry": what,
                "value": round(ips, 1), "unit": "images/s", "steps": steps, "warmup": warmup,
                "ms_per_step": round(elapsed / steps * 1e3, 3), "global_batch": self.world * B}
-        if (cin, S) in FWD_GFLOP:
+        if (cin, S) in FWD_GFLOP and hidden == 128:      # SURVEY M4's FLOP table is the C = 128 net's
             N, C = (S // 4) ** 2, 128               # the extension's attention block at the S/4 level: qkv + proj 1x1 convs and the two contractions
             att = (8 * N * C * C + 4 * N * N * C) / 1e9 if attention else 0.0
             out["model_tflops"] = round(3 * (FWD_GFLOP[(cin, S)] + att) * ips / 1e3, 2)    # 3x forward FLOPs per train image
