@@ -67,6 +67,36 @@ def test_whole_net_at_config_shapes(dtype, S, B, attention):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,H,W,B", [(1, 12, 12, 5), (1, 20, 20, 3), (3, 36, 36, 2), (1, 44, 44, 2), (3, 24, 40, 3), (1, 52, 28, 2)],
+                         ids=["1x12x12", "1x20x20", "3x36x36", "1x44x44", "3x24x40", "1x52x28"])
+def test_whole_net_at_sizes_no_config_names(dtype, cin, H, W, B):
+    """The reference net is size-agnostic (any H, W divisible by 4: two stride-2 levels, `simple_unet.py:44-72`): sizes that are no power of two,
+    rows that fill neither a 64-slot chunk nor a 256-pixel tile, and non-square images - forward and a spread of gradients against the oracle,
+    with whatever kernels the dispatch picks at these shapes."""
+    from oracle import unet_ref as U
+    net, params = live_net(dtype, in_channels=cin)
+    g = torch.Generator().manual_seed(7 * H + W + B)
+    z = torch.randn((B, cin, H, W), generator=g)
+    l = torch.tensor([-6.0, 0.7, 5.0, -1.5, 9.0][:B])
+    y = torch.tensor([2, -1, 9, 0, 5][:B])
+    dout = torch.randn((B, cin, H, W), generator=g)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = U.unet_forward(p, z, l, guide=y)
+    ref.backward(dout)
+    ctx = {}
+    out = net.forward_hip(z.cuda(), l.cuda(), y.cuda(), None, ctx=ctx)
+    tol = TOL[dtype]
+    assert rel_err(out, ref) < tol, rel_err(out, ref)
+    net.backward_hip(ctx, dout.cuda())
+    names = ["down.seq.0.conv.weight", "down.seq.1.in_layers.2.weight", "down.seq.3.conv.weight", "down.seq.6.conv.weight",
+             "turn.out_layers.3.weight", "up.seq.0.1.conv.weight", "up.seq.3.1.conv.weight", "up.seq.5.skip_connection.weight",
+             "up.seq.6.in_layers.2.weight", "up.seq.6.out_layers.0.weight", "out.2.weight", "time_embed.0.weight",
+             "guide_embed.2.bias", "down.seq.2.in_layers.2.bias"]
+    bad = [(n, rel_err(net.grad(n), p[n].grad)) for n in names if rel_err(net.grad(n), p[n].grad) >= (1 if dtype == torch.float32 else 2) * tol]
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("B,S,attention", [(2048, 32, False), (1024, 64, False), (512, 64, 1), (512, 64, 2)],
                          ids=["cfg2-B2048-3x32x32", "cfg3-shard-B1024-3x64x64", "cfg4-shard-B512-3x64x64-attn-bf16",
                               "cfg4-shard-B512-3x64x64-attn-fp8"])
