@@ -206,6 +206,142 @@ __global__ __launch_bounds__(256) void expand3x3_mfma_kernel(const float* __rest
     }
 }
 
+// ---- the "expand" convolution for 16-bit outputs, round 4: tiles of 128 pixels, image window in LDS, bf16 hi + lo operands ----------------
+// What binds the exact-fp32 kernel above is not one thing (timing-only builds): with a ninth of the MFMA cycles it is
+// 9 % faster, with half of its gathers no faster, with dense stores no faster, with neither gathers nor MFMAs it writes at 5.2 TB/s - the
+// per-lane image gathers (16 four-byte loads per 32 pixels through the texture path) and the fp32 MFMA chain (56 x 64 cycles per block) each
+// cap it near 2.7 / 4.8 TB/s.  This form removes both: a workgroup owns 128 consecutive pixels of ONE sample, the window of image values they
+// touch (128 + 2 W + 2 per image channel) is loaded with coalesced loads one tile ahead and parked in LDS, the patch values are LDS reads;
+// both operands are split x = hi + lo into bf16 (2^-17) and multiplied as hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_bf16 (results equal to
+// the exact chain to the last 16-bit ulp); the results leave through a per-wave LDS tile so that a store instruction writes 1 KiB of contiguous
+// memory.  k = 16 ks + 8 h + e as in the MFMA's operand layout.
+constexpr int kTileWin = 128 + 2 * 128 + 2;            // window floats per image channel at W <= 128
+template <typename T, int CSN, bool FLIP>
+__global__ __launch_bounds__(256, 2) void expand3x3_tile16_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, T* __restrict__ out, int H, int W, int C,
+                                                                 int tiles_per_sample, unsigned ntiles, unsigned in_bytes, unsigned out_bytes) {
+    static_assert(sizeof(T) == 2, "16-bit outputs only");
+    fp16_saturating_stores<T>();
+    constexpr int K = 9 * CSN, KB = K + (FLIP ? 0 : 1), NKS = (KB + 15) / 16, NE = NKS * 8;
+    constexpr int kTrRow = 272;
+    __shared__ float win[2][CSN][kTileWin];
+    __shared__ __attribute__((aligned(16))) char trans[4 * 32 * kTrRow];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int HW = H * W, WIN = 128 + 2 * W + 2;
+    bf16x8 whi[4][NKS], wlo[4][NKS];
+    int kinfo[NE];              // per k entry of this lane: window offset << 6 | (dy + 1) | (dx + 1) << 2 | inside K << 4 | the bias entry << 5
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * ks + 8 * h + e;
+            const bool kin = k < K;
+            const int s_ = kin ? k / 9 : 0, t = kin ? k % 9 : 4;
+            const int dy = FLIP ? 1 - t / 3 : t / 3 - 1, dx = FLIP ? 1 - t % 3 : t % 3 - 1;
+            kinfo[ks * 8 + e] = ((s_ * kTileWin + dy * W + dx) * 64) | (dy + 1) | ((dx + 1) << 2) | ((int)kin << 4) | ((int)(!FLIP && k == K) << 5);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int c = cb * 32 + r;
+                const float wv = kin ? w[FLIP ? (s_ * C + c) * 9 + t : (c * CSN + s_) * 9 + t] : (!FLIP && k == K && bias) ? bias[c] : 0.f;
+                const bf16_t hi = (bf16_t)wv;
+                whi[cb][ks][e] = hi;
+                wlo[cb][ks][e] = (bf16_t)(wv - (float)hi);
+            }
+        }
+    constexpr unsigned kBadOff = 0xFFFFFF00u;
+    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)out_bytes, 0x00020000);
+    // window element i of tile (b, pp0): plane pixel pp0 - (W + 1) + i, zero outside the plane (those taps are masked anyway)
+    auto load_window = [&](unsigned tile, float (&wr)[CSN][2]) {
+        const int b = (int)(tile / (unsigned)tiles_per_sample), pp0 = ((int)tile - b * tiles_per_sample) * 128;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j, flat = pp0 - (W + 1) + i;
+            const bool ok = tile < ntiles && i < WIN && flat >= 0 && flat < HW;
+#pragma unroll
+            for (int s_ = 0; s_ < CSN; ++s_)
+                wr[s_][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsi, ok ? (unsigned)((b * CSN + s_) * HW + flat) * 4u : kBadOff, 0, 0));
+        }
+    };
+    auto park_window = [&](int buf, const float (&wr)[CSN][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j;
+            if (i < WIN) {
+#pragma unroll
+                for (int s_ = 0; s_ < CSN; ++s_) win[buf][s_][i] = wr[s_][j];
+            }
+        }
+    };
+    float wr[CSN][2];
+    load_window(blockIdx.x, wr);
+    park_window(0, wr);
+    __syncthreads();
+    int buf = 0;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        load_window(tile + gridDim.x, wr);               // in flight under this tile's work
+        const int b = (int)(tile / (unsigned)tiles_per_sample), pp0 = ((int)tile - b * tiles_per_sample) * 128;
+        const int pl = wave * 32 + r, pp = pp0 + pl;
+        const bool live = pp < HW;
+        const int y = pp / W, x = pp - y * W;
+        const float* wb = &win[buf][0][0] + pl + (W + 1);
+        bf16x8 phi[NKS], plo[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = kinfo[ks * 8 + e];
+                const int ok = (int)live & (m >> 4) & (int)((unsigned)(y + (m & 3) - 1) < (unsigned)H) & (int)((unsigned)(x + ((m >> 2) & 3) - 1) < (unsigned)W);
+                float v = wb[m >> 6];
+                v = (ok & 1) ? v : 0.f;
+                v = (m & 32) ? 1.f : v;                  // the bias entry multiplies a patch value of 1
+                const bf16_t hi = (bf16_t)v;
+                phi[ks][e] = hi;
+                plo[ks][e] = (bf16_t)(v - (float)hi);
+            }
+        char* tr = trans + wave * (32 * kTrRow);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {           // small terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[cb][ks], phi[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[cb][ks], plo[ks], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[cb][ks], phi[ks], acc, 0, 0, 0);
+            // lane (pixel r, half h) holds channels 32 cb + 8 q4 + 4 h + (0..3), q4 = 0..3
+            unsigned pk[4][2];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                pk[q4][0] = pack_pair<T>(sat16<T>(acc[4 * q4]), sat16<T>(acc[4 * q4 + 1]));
+                pk[q4][1] = pack_pair<T>(sat16<T>(acc[4 * q4 + 2]), sat16<T>(acc[4 * q4 + 3]));
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4 += 2) {       // after the swap: lanes < 32 hold channels 8 q4 .. 8 q4 + 7, lanes >= 32 the next 8
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[q4][0], pk[q4 + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q4][1], pk[q4 + 1][1], false, false);
+                const u32x4s o = {s0[0], s1[0], s0[1], s1[1]};
+                *reinterpret_cast<u32x4s*>(tr + r * kTrRow + (cb * 4 + q4 + h) * 16) = o;
+            }
+        }
+        // the wave's own tile, LDS operations of one wave complete in order: no barrier.  Lane -> (row 4 i + lane / 16, 16-byte chunk lane % 16)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + (lane >> 4);
+            const u32x4s v = *reinterpret_cast<const u32x4s*>(tr + row * kTrRow + (lane & 15) * 16);
+            const int ppr = pp0 + wave * 32 + row;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rso, ppr < HW ? ((unsigned)(b * HW + ppr) * 256u + (unsigned)(lane & 15) * 16u) : kBadOff, 0, 0);
+        }
+        park_window(buf ^ 1, wr);
+        __syncthreads();
+    }
+}
+
 // ---- weight gradients of both: the C-channel tensor is read ONCE (all image channels accumulate together), the image
 // through L1 -----------------------------------------------------------------------------------------------------------
 //   stem (FLIP = false): dw[c][s][t] = sum_{b,p} x[b,s,p + off(t)]    * dy[b,p,c]
@@ -591,6 +727,19 @@ static void launch_expand(const float* in, const float* w, const float* bias, T*
         // persistent: exactly the resident set (2 workgroups per CU at <= 256 registers), so the per-wave operand setup runs once
         const unsigned resident = 2u * (unsigned)gmk_cu_limit();
         const unsigned grid = (nblocks + 3) / 4 < resident ? (nblocks + 3) / 4 : resident;
+        if constexpr (sizeof(T) == 2) {          // 16-bit results: tiles with the image window in LDS and bf16 hi / lo operands (GMK_DEV_VARIANT 42 keeps the exact-fp32 chain: A/B)
+            if (W <= 128 && cs <= 3 && gmk_kernel_choice(3, "GMK_DEV_VARIANT") != 42) {
+                const int tps = (H * W + 127) / 128;
+                const unsigned ntiles = (unsigned)B * (unsigned)tps;
+                const unsigned grid16 = ntiles < resident ? ntiles : resident;
+#define GMK_EXPAND_T16(CSN) expand3x3_tile16_kernel<T, CSN, FLIP><<<grid16, 256, 0, stream>>>(in, w, bias, out, H, W, C, tps, ntiles, (unsigned)in_bytes, (unsigned)out_bytes)
+                if (cs == 1) GMK_EXPAND_T16(1);
+                else if (cs == 2) GMK_EXPAND_T16(2);
+                else GMK_EXPAND_T16(3);
+#undef GMK_EXPAND_T16
+                return;
+            }
+        }
 #define GMK_EXPAND_M(CSN) expand3x3_mfma_kernel<T, CSN, FLIP><<<grid, 256, 0, stream>>>(in, w, bias, out, H, W, C, (unsigned)npix, nblocks, (unsigned)in_bytes, (unsigned)out_bytes)
         if (cs == 1) GMK_EXPAND_M(1);
         else if (cs == 2) GMK_EXPAND_M(2);

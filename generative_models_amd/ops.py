@@ -462,12 +462,17 @@ def conv_wgrad(dy, srcs, ksize, mode, dw):
     return dw
 
 
+def _expand_name(dtype, cs, W):
+    """Profile label of the stem forward / head data gradient launch (smallconv.hip launch_expand: 16-bit results of <= 3 image channels run tiled)."""
+    return "expand3x3_tile16_kernel" if dtype in (torch.float16, torch.bfloat16) and cs <= 3 and W <= 128 else "expand3x3_mfma_kernel"
+
+
 def stem_fwd(x, w, bias, C, dtype):
     _f32(x, "x"); _f32(w, "w"); _f32(bias, "bias")
     B, cin, H, W = x.shape
     assert w.shape == (C, cin, 3, 3)
     y = torch.empty((B, H, W, C), device=x.device, dtype=dtype)
-    with _Timed("expand3x3_mfma_kernel", 2.0 * B * H * W * C * cin * 9, _nbytes(x, y), fixed=True):
+    with _Timed(_expand_name(dtype, cin, W), 2.0 * B * H * W * C * cin * 9, _nbytes(x, y), fixed=True):
         check(lib.gmk_stem_fwd(_p(x), _p(w), _p(bias), _p(y), B, cin, H, W, C, _DT[dtype], _s()), "stem_fwd")
     return y
 
@@ -499,7 +504,7 @@ def head_dgrad(dout, w, dtype):
     B, cout, H, W = dout.shape
     C = w.shape[1]
     da = torch.empty((B, H, W, C), device=dout.device, dtype=dtype)
-    with _Timed("expand3x3_mfma_kernel", 2.0 * B * H * W * C * cout * 9, _nbytes(dout, da), fixed=True):
+    with _Timed(_expand_name(dtype, cout, W), 2.0 * B * H * W * C * cout * 9, _nbytes(dout, da), fixed=True):
         check(lib.gmk_head_dgrad(_p(dout), _p(w), _p(da), B, cout, H, W, C, _DT[dtype], _s()), "head_dgrad")
     return da
 
