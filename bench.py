@@ -69,7 +69,7 @@ KERNEL_DESC = {
     "gn_silu_bwd_kernel": "GroupNorm+SiLU backward, two-sweep streaming",
     "expand3x3_mfma_kernel": "stem forward / head data gradient (<= 4 image channels <-> 128), fp32 MFMA",
     "expand3x3_tile16_kernel": "stem forward / head data gradient, 16-bit results: 128-pixel tiles, image window in LDS, bf16 hi + lo MFMA",
-    "wgrad3x3_mfma_kernel": "stem / head weight gradients, fp32 MFMA", "head_fwd_mfma_kernel": "head forward (128 -> <= 3 image channels)",
+    "wgrad3x3_mfma_kernel": "stem / head weight gradients, fp32 MFMA", "wgrad3x3_tile16_kernel": "stem / head weight gradients of 16-bit tensors: 128-pixel tiles through LDS, bf16 hi + lo MFMA", "head_fwd_mfma_kernel": "head forward (128 -> <= 3 image channels)",
     "sumpool2x2_kernel": "backward of the nearest x2 upsample", "chansum_kernel": "per-sample channel sums (bias / embedding gradients)"}
 
 

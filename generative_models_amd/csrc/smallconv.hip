@@ -531,6 +531,153 @@ __global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(const float* __restr
     }
 }
 
+// ---- the same weight gradients for 16-bit tensors, round 4: 128-pixel tiles through LDS, 16-bit matrix cores -------------------------------
+// The fp32 form above walks pixel PAIRS with one 2-byte load per lane and channel block (80 load instructions per 32 pixels) and four fp32 MFMAs
+// per pair: 2.4 TB/s of the one tensor it reads.  Here a workgroup stages 128 consecutive pixels of one sample - the 32 KiB of the 16-bit tensor
+// with dense 16-byte loads, the image window as in expand3x3_tile16_kernel - one tile ahead in registers, parks them in LDS, and every wave
+// contracts its 32 pixels with v_mfma_f32_32x32x16_bf16 (A: the tensor transposed by 2-byte LDS reads - rows = channels, k = pixels; B: the image
+// patch of tap entry j = lane % 32).  The fp32 patch is split hi + lo into bf16 (2^-17, and bf16's range: gradients of any scale); a bf16 tensor is
+// exact as it is, an fp16 one (the saved activations of the 16-bit mode) is split into bf16 hi + lo too - 8 + 3 significant bits: exact - so
+// the products are hi hi + hi lo + lo hi as in the expand kernel.  Accumulators, the reduction over the four waves and the partial-row layout
+// are those of the kernel above.
+template <typename T, int CSN, bool FLIP>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_tile16_kernel(const float* __restrict__ small, const T* __restrict__ big,
+                                                                float* __restrict__ part, int H, int W, int C, int tiles_per_sample,
+                                                                unsigned ntiles, unsigned small_bytes, unsigned big_bytes) {
+    static_assert(sizeof(T) == 2, "16-bit tensors only");
+    constexpr int K = 9 * CSN, kRow = 272;                 // LDS row of a pixel: 256 B + 16 B of padding
+    constexpr unsigned kBadOff = 0xFFFFFF00u;
+    typedef bf16x8 frag_t;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
+    __shared__ __attribute__((aligned(16))) char smem[4 * 128 * 32 * 4];     // tiles while streaming (128 x 272 B + window), then red[4][128 * 32]
+    __shared__ float bred[4][4][2];
+    char* bigt = smem;                                       // [128 pixels][272 B]
+    float* win = reinterpret_cast<float*>(smem + 128 * kRow);     // [CSN][kTileWin]
+    static_assert(128 * kRow + 3 * kTileWin * 4 <= (int)sizeof(smem), "tile + window fit the reduction buffer");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int HW = H * W, WIN = 128 + 2 * W + 2;
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(small), 0, (int)small_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(big), 0, (int)big_bytes, 0x00020000);
+    const bool kin = r < K;
+    const int s_ = kin ? r / 9 : 0, t = kin ? r % 9 : 4;
+    const int dy = FLIP ? 1 - t / 3 : t / 3 - 1, dx = FLIP ? 1 - t % 3 : t % 3 - 1;
+    const int woff = s_ * kTileWin + dy * W + dx + (W + 1);       // window index of this lane's tap relative to the pixel's tile position
+    float bsum = 0.f;
+    f32x16 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
+
+    auto load_tile = [&](unsigned tile, u32x4s (&br)[8], float (&wr)[CSN][2]) {
+        const bool on = tile < ntiles;
+        const int b = on ? (int)(tile / (unsigned)tiles_per_sample) : 0, pp0 = on ? ((int)tile - b * tiles_per_sample) * 128 : 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {          // chunk c = tid + 256 i of the tile's 128 x 16 sixteen-byte chunks: pixel row c / 16
+            const int c = tid + 256 * i, row = c >> 4;
+            br[i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, on && pp0 + row < HW ? (unsigned)(b * HW + pp0) * 256u + (unsigned)c * 16u : kBadOff, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j, flat = pp0 - (W + 1) + i;
+            const bool ok = on && i < WIN && flat >= 0 && flat < HW;
+#pragma unroll
+            for (int sc = 0; sc < CSN; ++sc)
+                wr[sc][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rss, ok ? (unsigned)((b * CSN + sc) * HW + flat) * 4u : kBadOff, 0, 0));
+        }
+    };
+    auto park_tile = [&](const u32x4s (&br)[8], const float (&wr)[CSN][2]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<u32x4s*>(bigt + (c >> 4) * kRow + (c & 15) * 16) = br[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j;
+            if (i < WIN) {
+#pragma unroll
+                for (int sc = 0; sc < CSN; ++sc) win[sc * kTileWin + i] = wr[sc][j];
+            }
+        }
+    };
+    u32x4s br[8];
+    float wr[CSN][2];
+    load_tile(blockIdx.x, br, wr);
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                  // every wave is done with the previous tile
+        park_tile(br, wr);
+        __syncthreads();
+        load_tile(tile + gridDim.x, br, wr);              // in flight under this tile's work
+        const int b = (int)(tile / (unsigned)tiles_per_sample), pp0 = ((int)tile - b * tiles_per_sample) * 128;
+        (void)b;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // B operand: tap entry j = r at pixels pl .. pl + 7
+            const int pl = wave * 32 + 16 * ks + 8 * h;
+            int pp = pp0 + pl;
+            int y = pp / W, x = pp - y * W;
+            frag_t bhi, blo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ok = (int)kin & (int)(pp < HW) & (int)((unsigned)(y + dy) < (unsigned)H) & (int)((unsigned)(x + dx) < (unsigned)W);
+                float v = win[woff + pl + e];
+                v = ok ? v : 0.f;
+                if (FLIP) bsum += t == 4 ? v : 0.f;
+                const bf16_t hi = (bf16_t)v;
+                bhi[e] = hi;
+                blo[e] = (bf16_t)(v - (float)hi);
+                ++pp; ++x;
+                const int wrap = x >= W;
+                x = wrap ? 0 : x; y += wrap;
+            }
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                // A operand: channel 32 cb + r at the same 8 pixels, transposed out of the tile by 2-byte reads
+                frag_t a, alo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const T av = *reinterpret_cast<const T*>(bigt + (pl + e) * kRow + (cb * 32 + r) * 2);
+                    if constexpr (__is_same(T, bf16_t)) a[e] = av;
+                    else {
+                        const float af = (float)av;
+                        const bf16_t hi = (bf16_t)af;
+                        a[e] = hi;
+                        alo[e] = (bf16_t)(af - (float)hi);
+                    }
+                }
+                if constexpr (!__is_same(T, bf16_t)) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, blo, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bhi, acc[cb], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                      // the tile buffers become the reduction buffer
+    float* red = reinterpret_cast<float*>(smem);
+    // lane (j = r, h) holds dW^T[32 cb + (e & 3) + 8 (e >> 2) + 4 h][j]
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave * (128 * 32) + (cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[cb][e];
+    if (FLIP && kin && t == 4) bred[wave][s_][h] = bsum;
+    __syncthreads();
+    const size_t rowlen = (size_t)CSN * C * 9 + (FLIP ? CSN : 0);
+    float* out = part + (size_t)blockIdx.x * rowlen;
+    for (int idx = tid; idx < CSN * 128 * 9; idx += 256) {
+        int c, j;
+        if (FLIP) { const int sc = idx / (128 * 9), rem = idx - sc * 128 * 9; c = rem / 9; j = sc * 9 + (rem - c * 9); }
+        else { c = idx / K; j = idx - c * K; }
+        out[idx] = (red[c * 32 + j] + red[128 * 32 + c * 32 + j]) + (red[2 * 128 * 32 + c * 32 + j] + red[3 * 128 * 32 + c * 32 + j]);
+    }
+    if (FLIP && tid < CSN) {
+        float sum = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) sum += bred[wv][tid][0] + bred[wv][tid][1];
+        out[(size_t)CSN * C * 9 + tid] = sum;
+    }
+}
+
 // ---- head forward (C -> cs): out[b,s,p] = bias[s] + sum_{t,c} a[b,p + off(t),c] * w[s][c][t] ----------------------------
 // One workgroup = one band of image rows.  Pass 1 reads every activation vector of the band (+1 row above/below) once and
 // leaves its 9 per-tap channel sums in LDS (tap[t][q] = sum_c a[q,c] w[s][c][t], reduced over the pixel's lanes with DPP);
@@ -789,6 +936,18 @@ static void launch_wgrad(const float* small, const T* big, float* part, int B, i
         const unsigned npairs = (unsigned)((npix + 1) / 2);
         unsigned ppw = (npairs + (unsigned)nb * 4 - 1) / ((unsigned)nb * 4);
         ppw = (ppw + 7) & ~7u;                                         // whole groups of 8 pairs
+        if constexpr (sizeof(T) == 2) {          // 16-bit tensors: tiles through LDS, 16-bit matrix cores (GMK_DEV_VARIANT 42 keeps the fp32 chain: A/B)
+            if (W <= 128 && small_bytes < 0xFFFFFF00ull && gmk_kernel_choice(3, "GMK_DEV_VARIANT") != 42) {
+                const int tps = (H * W + 127) / 128;
+                const unsigned ntiles = (unsigned)B * (unsigned)tps;
+#define GMK_WGRAD_T16(CSN) wgrad3x3_tile16_kernel<T, CSN, FLIP><<<nb, 256, 0, stream>>>(small, big, part, H, W, C, tps, ntiles, (unsigned)small_bytes, (unsigned)big_bytes)
+                if (cs == 1) GMK_WGRAD_T16(1);
+                else if (cs == 2) GMK_WGRAD_T16(2);
+                else GMK_WGRAD_T16(3);
+#undef GMK_WGRAD_T16
+                return;
+            }
+        }
 #define GMK_WGRAD_M(CSN) wgrad3x3_mfma_kernel<T, CSN, FLIP><<<nb, 256, 0, stream>>>(small, big, part, H, W, C, (unsigned)npix, (unsigned)small_bytes, (unsigned)big_bytes, ppw)
         if (cs == 1) GMK_WGRAD_M(1);
         else if (cs == 2) GMK_WGRAD_M(2);

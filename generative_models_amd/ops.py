@@ -467,6 +467,11 @@ def _expand_name(dtype, cs, W):
     return "expand3x3_tile16_kernel" if dtype in (torch.float16, torch.bfloat16) and cs <= 3 and W <= 128 else "expand3x3_mfma_kernel"
 
 
+def _wgrad3_name(dtype, cs, W):
+    """Profile label of the stem / head weight-gradient launch (smallconv.hip launch_wgrad: 16-bit tensors run tiled)."""
+    return "wgrad3x3_tile16_kernel" if dtype in (torch.float16, torch.bfloat16) and cs <= 3 and W <= 128 and W % 2 == 0 else "wgrad3x3_mfma_kernel"
+
+
 def stem_fwd(x, w, bias, C, dtype):
     _f32(x, "x"); _f32(w, "w"); _f32(bias, "bias")
     B, cin, H, W = x.shape
@@ -483,7 +488,7 @@ def stem_wgrad(x, dy, dw):
     C = dy.shape[3]
     nb = lib.gmk_stem_wgrad_blocks(B * H * W)
     part = torch.empty((nb, C * cin * 9), device=x.device, dtype=torch.float32)
-    with _Timed("wgrad3x3_mfma_kernel", 2.0 * B * H * W * C * cin * 9, _nbytes(x, dy), fixed=True):
+    with _Timed(_wgrad3_name(dy.dtype, cin, W), 2.0 * B * H * W * C * cin * 9, _nbytes(x, dy), fixed=True):
         check(lib.gmk_stem_wgrad(_p(x), _p(dy), _p(part), B, cin, H, W, C, _DT[dy.dtype], _s()), "stem_wgrad")
     return colsum(part, dw)
 
@@ -518,7 +523,7 @@ def head_wgrad(dout, a, dwb):
     assert dwb.numel() == n
     nb = lib.gmk_head_wgrad_blocks(B * H * W)
     part = torch.empty((nb, n), device=a.device, dtype=torch.float32)
-    with _Timed("wgrad3x3_mfma_kernel", 2.0 * B * H * W * C * cout * 9, _nbytes(dout, a), fixed=True):
+    with _Timed(_wgrad3_name(a.dtype, cout, W), 2.0 * B * H * W * C * cout * 9, _nbytes(dout, a), fixed=True):
         check(lib.gmk_head_wgrad(_p(dout), _p(a), _p(part), B, cout, H, W, C, _DT[a.dtype], _s()), "head_wgrad")
     return colsum(part, dwb)
 

@@ -232,13 +232,20 @@ def test_stem_and_head_with_fp16_activations(ops, cs, S, B):
     wh = rnd(cs, C, 3, 3, seed=45) / math.sqrt(C * 9); bh = 0.1 * rnd(cs, seed=46)
     out = ops.head_fwd(nhwc(a, H), wh.cuda(), bh.cuda())
     assert rel_err(out, F.conv2d(a, wh, bh, padding=1)) < 1e-3
-    # head weight gradient (exact-fp32 MFMA on the converted activations): bf16-representable activations give identical bits
+    # head weight gradient: an fp16 tensor is split into bf16 hi + lo exactly (8 + 3 bits), so activations representable in both types give the
+    # same bits whichever type stores them - and both agree with autograd to the split of the fp32 gradient operand (2^-17)
     dout = rnd(B, cs, S, S, seed=47).cuda()
     ab = both16(a)
     n = cs * C * 9 + cs
     g1 = ops.head_wgrad(dout, nhwc(ab, H), torch.empty(n, device="cuda")).clone()
     g2 = ops.head_wgrad(dout, nhwc(ab, BF), torch.empty(n, device="cuda")).clone()
     assert torch.equal(g1, g2)
+    w0 = torch.zeros(cs, C, 3, 3, requires_grad=True); b0 = torch.zeros(cs, requires_grad=True)
+    F.conv2d(ab, w0, b0, padding=1).backward(dout.cpu())
+    assert rel_err(g1, torch.cat([w0.grad.reshape(-1), b0.grad])) < 2e-5
+    # and with a gradient operand far below fp16's range (a large global batch's 1 / B): nothing is flushed
+    tiny = ops.head_wgrad(dout * 1e-9, nhwc(ab, H), torch.empty(n, device="cuda")).clone()
+    assert rel_err(tiny * 1e9, g1) < 2e-5
 
 
 def test_cast16_round_trip(ops):

@@ -545,7 +545,8 @@ def test_training_learns_class_conditional_templates(compute_dtype):
     from generative_models_amd.diffusion.diffusion_model import DiffusionModel
     G = common.AttrDict(DiffusionModel.DG)
     G.update(dict(lr=3e-4, timesteps=50, eval_heavy=0, seed=1, compute_dtype=compute_dtype))
-    model = DiffusionModel(G).cuda()
+    torch.manual_seed(0)        # the net's default init draws from torch's global generator (as the reference's does): without this the outcome
+    model = DiffusionModel(G).cuda()      # depended on which tests ran before (init seeds 0 - 5: 20 / 20 hits in both modes; an unlucky one: 17)
     g = torch.Generator().manual_seed(3)
     T = F.interpolate(torch.randn(10, 1, 7, 7, generator=g), size=28, mode="bicubic", align_corners=False).clamp(-1.5, 1.5) / 1.5
     T = T.cuda()
