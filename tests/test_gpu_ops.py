@@ -175,6 +175,43 @@ def test_stem_head(ops, dtype, cs, S, B):
     assert rel_err(dwb[cs * C * 9:], bh.grad) < 1e-3
 
 
+def test_stem_head_random_shapes(ops):
+    """The four stem / head launches of the 16-bit mode on 24 random shapes (non-square, rows that fill no 64- or 128-pixel tile, widths on
+    both sides of the tiled kernels' W <= 128, 1 - 3 image channels, batches of 1 - 6) against autograd on the same rounded operands."""
+    import random
+    rng = random.Random(7)
+    C = 128
+    for case in range(24):
+        cs, B = rng.randint(1, 3), rng.randint(1, 6)
+        H, W = 2 * rng.randint(2, 24), 2 * rng.randint(2, 70 if case % 6 == 0 else 24)
+        if H * W < 32:
+            H = 8
+        x = rnd(B, cs, H, W, seed=100 + case).clamp(-1, 1)
+        w = (rnd(C, cs, 3, 3, seed=200 + case) / 3).requires_grad_(True)
+        b = 0.1 * rnd(C, seed=300 + case)
+        tag = (case, B, cs, H, W)
+        y_ref = F.conv2d(x, w, b, padding=1)
+        y = ops.stem_fwd(x.cuda(), w.detach().cuda(), b.cuda(), C, torch.float16)
+        assert rel_err(nchw(y), y_ref) < 1e-3, tag
+        dy = q(rnd(B, C, H, W, seed=400 + case), torch.bfloat16)
+        y_ref.backward(dy)
+        dw = torch.empty_like(w.detach()).cuda()
+        ops.stem_wgrad(x.cuda(), nhwc(dy, torch.bfloat16), dw)
+        assert rel_err(dw, w.grad) < 2e-5, tag
+        a = rnd(B, C, H, W, seed=500 + case).half().float().requires_grad_(True)
+        wh = (rnd(cs, C, 3, 3, seed=600 + case) / math.sqrt(9 * C)).requires_grad_(True)
+        bh = (0.1 * rnd(cs, seed=700 + case)).requires_grad_(True)
+        o_ref = F.conv2d(a, wh, bh, padding=1)
+        do = rnd(B, cs, H, W, seed=800 + case) / 64
+        o_ref.backward(do)
+        da = ops.head_dgrad(do.cuda(), wh.detach().cuda(), torch.bfloat16)
+        assert rel_err(nchw(da), a.grad) < 5e-3, tag                    # bf16 result: one ulp of the largest entry
+        dwb = torch.empty(cs * C * 9 + cs, device="cuda")
+        ops.head_wgrad(do.cuda(), nhwc(a.detach(), torch.float16), dwb)
+        assert rel_err(dwb[:cs * C * 9].view_as(wh), wh.grad) < 2e-5, tag
+        assert rel_err(dwb[cs * C * 9:], bh.grad) < 1e-4, tag                 # a cancelling fp32 sum in another order
+
+
 def test_embedding_path(ops, golden):
     g = golden("schedule.npz")
     t = torch.from_numpy(g["temb_t"]).cuda()
