@@ -1093,6 +1093,13 @@ extern "C" int gmk_conv1x1_pair(const void* src, int c, int B, int H, int W, con
                                 void* out_b, int dtype, void* stream) {
     GMK_REQUIRE(src && w && out_a && out_b, "gmk_conv1x1_pair: null pointer");
     GMK_REQUIRE(n0 >= 0 && n0 + 256 <= w_rows, "gmk_conv1x1_pair: rows n0 .. n0 + 255 outside the %d packed rows", w_rows);
+    if (c == 128 && B > 0 && H > 0 && W > 0) {             // the streaming form for the train step's sizes (conv1x1_stream.hip)
+        const size_t es = 2;
+        if (gmk_conv1x1_pair_stream_try(src, (int64_t)B * H * W, (const char*)w + (size_t)n0 * 128 * es, out_a, out_b, dtype, gmk_stream(stream))) {
+            gmk_note_kernel(14);
+            return gmk_check_launch("gmk_conv1x1_pair(stream)");
+        }
+    }
     return conv_igemm_impl(src, nullptr, c, 0, B, H, W, H, W, 1, GMK_CONV_NORMAL, w, w_rows, n0, 128, nullptr, nullptr, 0, nullptr,
                            out_a, out_b, 128, nullptr, 0, nullptr, nullptr, 0, dtype, stream);
 }

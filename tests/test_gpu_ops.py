@@ -609,11 +609,11 @@ def test_fused_attention_forward(ops, N, fp8):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,S", [(3, 8), (160, 32)])
+@pytest.mark.parametrize("B,S", [(3, 8), (160, 32), (85, 28)])
 def test_conv1x1_pair_equals_two_launches(ops, dtype, B, S):
     """gmk_conv1x1_pair (both halves of the skip connection's data gradient from one read of the output gradient) against two
-    gmk_conv_igemm launches with n0 = 0 / 128: the same bits.  (160, 32) runs on the LDS-DMA kernel (two output blocks per pixel
-    tile), (3, 8) takes the two-launch route inside the library."""
+    gmk_conv_igemm launches with n0 = 0 / 128: the same bits.  (160, 32) runs on the streaming kernel in the 16-bit modes and on the LDS-DMA
+    kernel (two output blocks per pixel tile) in fp32, (3, 8) takes the two-launch route inside the library, (85, 28) ends in a partial tile."""
     from generative_models_amd._lib import lib
     C = 128
     dy = q(rnd(B, S, S, C, seed=70), dtype).cuda().to(dtype)
@@ -623,7 +623,8 @@ def test_conv1x1_pair_equals_two_launches(ops, dtype, B, S):
     ra = ops.conv_igemm([dy], w, 2 * C, 1, ops.NORMAL, (S, S), n0=0)
     rb = ops.conv_igemm([dy], w, 2 * C, 1, ops.NORMAL, (S, S), n0=C)
     assert torch.equal(a, ra) and torch.equal(b, rb)
-    assert kernel == (2 if B * S * S >= 256 * 512 else 1)
+    # 16-bit problems of at least two 128-pixel tiles per CU: the streaming kernel (weights resident in LDS; conv1x1_stream.hip) - the same bits
+    assert kernel == (14 if dtype != torch.float32 and B * S * S >= 128 * 512 else 2 if B * S * S >= 256 * 512 else 1)
     ref = dy.float().reshape(-1, C) @ w.float().t()
     assert rel_err(torch.cat([a, b], -1).reshape(-1, 2 * C), ref.cpu()) < TOL[dtype]
 
