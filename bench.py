@@ -60,6 +60,7 @@ KERNEL_DESC = {
     "conv_igemm_dma_kernel": "im2col LDS-DMA convolution (1x1, strided, upsampled, fp32)",
     "conv_igemm_dma_kernel[stride-2 dgrad phases]": "data gradient of the stride-2 convs where the halo kernel declines: four output-parity phase launches of the LDS-DMA kernel (1 / 2 / 2 / 4 taps); one timed unit = the four launches",
     "conv_igemm_kernel": "im2col register-staged convolution (small problems)",
+    "conv1x1_wgrad_stream_kernel": "weight gradient of the 1x1 skip convolution over the concatenated input: one workgroup per pixel range owns both input blocks (+ slab reduce)",
     "conv1x1_pair_stream_kernel": "data gradient of the 1x1 skip convolution, both 128-channel halves from one read: weights resident in LDS, 128-pixel tiles streamed",
     "conv_wgrad_slots_kernel": "3x3 weight gradient over padded slots, 8 compute waves (+ slab reduce)",
     "conv_wgrad_slots_ws_kernel": "3x3 weight gradient over padded slots, wave-specialised (+ slab reduce)",

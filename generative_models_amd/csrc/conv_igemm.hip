@@ -1143,6 +1143,18 @@ extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, 
             return gmk_check_launch("gmk_conv_wgrad(reduce)");
         }
     }
+    if (wforce != 1 && ksize == 1 && mode == GMK_CONV_NORMAL && dtype == GMK_BF16 && c0 == 128 && c1 == 128 && cout == 128) {
+        // the skip convolution over the concatenated input at the train step's sizes: one workgroup per pixel range owns both input blocks
+        const int ns1 = gmk_conv1x1_wgrad_stream_try(dy, dy_cstride, src0, src1, (int64_t)B * ho * wo, (float*)workspace, workspace_bytes, xf16,
+                                                     gmk_stream(stream));
+        if (ns1 > 0) {
+            gmk_note_kernel(15);
+            int rc1 = gmk_check_launch("gmk_conv_wgrad(1x1 stream)");
+            if (rc1) return rc1;
+            launch_wgrad_reduce((const float*)workspace, dw, ns1, 1, cout, 256, gmk_stream(stream));
+            return gmk_check_launch("gmk_conv_wgrad(reduce)");
+        }
+    }
     p.dy = dy; p.dy_cstride = dy_cstride; p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.ktot = c0 + c1;
     p.cout = cout; p.M = B * ho * wo;
     const int ns = wgrad_nsplit(p.M, taps, cout, p.ktot, &p.chunk);

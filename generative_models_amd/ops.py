@@ -23,7 +23,7 @@ PROFILE = None
 
 
 KERNEL_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_dma_kernel", 3: "conv3x3_halo_kernel", 4: "conv3x3_halo_ws_kernel", 11: "conv_wgrad_kernel",
-                12: "conv_wgrad_slots_kernel", 13: "conv_wgrad_slots_ws_kernel", 14: "conv1x1_pair_stream_kernel",
+                12: "conv_wgrad_slots_kernel", 13: "conv_wgrad_slots_ws_kernel", 14: "conv1x1_pair_stream_kernel", 15: "conv1x1_wgrad_stream_kernel",
                 # same binary as 4, launched on the zero-stuffed gradient of a stride-2 conv: 4x the algorithmic MFMA work by
                 # construction, so the profile keeps it apart from the plain 3x3 convolutions
                 5: "conv3x3_halo_ws_kernel[zero-stuffed transposed conv]",

@@ -629,6 +629,34 @@ def test_conv1x1_pair_equals_two_launches(ops, dtype, B, S):
     assert rel_err(torch.cat([a, b], -1).reshape(-1, 2 * C), ref.cpu()) < TOL[dtype]
 
 
+@pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,S", [(140, 32), (171, 28)])
+def test_skip_conv_weight_gradient_streaming_kernel(ops, xdt, B, S):
+    """Weight gradient of the 1x1 skip convolution over a concatenated input at sizes where the streaming kernel takes it (conv1x1_stream.hip: one
+    workgroup per pixel range owns both 128-channel input blocks): the same bits as the im2col kernel (GMK_DEV_VARIANT=47: same split of the pixels,
+    same order inside the MFMA), and autograd's values.  (171, 28): a pixel count that is no multiple of the 64-pixel step."""
+    from generative_models_amd._lib import lib
+    C = 128
+    g = torch.Generator().manual_seed(B + S)
+    xs = [torch.randn((B, S, S, C), generator=g).to(xdt).cuda() for _ in range(2)]
+    dy = (torch.randn((B, S, S, C), generator=g) / 16).bfloat16().cuda()
+    out = {}
+    for variant in (0, 47):
+        lib.gmk_set_dev_variant(variant)
+        try:
+            dw = torch.empty((C, 2 * C, 1, 1), device="cuda")
+            ops.conv_wgrad(dy, xs, 1, ops.NORMAL, dw)
+            out[variant] = (dw.clone(), lib.gmk_last_kernel())
+        finally:
+            lib.gmk_set_dev_variant(0)
+    assert out[0][1] == 15 and out[47][1] == 11
+    assert torch.equal(out[0][0], out[47][0])
+    # fp16 activations are re-rounded to bf16 on their way to the MFMA (as in every weight-gradient kernel): the reference uses the same values
+    xr = torch.cat([x.float().bfloat16().double() for x in xs], -1).reshape(-1, 2 * C)
+    ref = dy.double().reshape(-1, C).t() @ xr
+    assert rel_err(out[0][0].reshape(C, 2 * C), ref) < 1e-4
+
+
 @pytest.mark.parametrize("B,S,two,res", [(40, 28, False, True), (40, 28, True, False), (33, 32, True, True), (64, 16, False, True), (9, 64, False, False)])
 def test_conv_with_fused_groupnorm_is_bit_identical(ops, B, S, two, res):
     """gmk_gn_stats + gmk_conv_igemm(gn_scale, gn_shift): GroupNorm-apply + SiLU in the convolution's producer waves instead of a
