@@ -430,10 +430,11 @@ class Bench:
         roof = self.roofline(prof, nprof, elapsed, steps, key) if self.rank == 0 else None
         if roof:
             out["roofline"] = roof
-        if headline and steps < 50:              # >= 50 steady-state steps after >= 10 warm-up
-            e2, _ = self.timed_steps(model, batches, 50, None)
-            out["steady_state"] = {"value": round(self.world * B * 50 / e2, 1), "steps": 50, "warmup": warmup + steps,
-                                   "ms_per_step": round(e2 / 50 * 1e3, 3)}
+        n_steady = int(os.environ.get("GMK_BENCH_STEADY_STEPS", "50"))     # (the 2-rank rehearsal over gloo shortens its loops: every step stages 24 MB through the host)
+        if headline and steps < n_steady:        # >= 50 steady-state steps after >= 10 warm-up
+            e2, _ = self.timed_steps(model, batches, n_steady, None)
+            out["steady_state"] = {"value": round(self.world * B * n_steady / e2, 1), "steps": n_steady, "warmup": warmup + steps,
+                                   "ms_per_step": round(e2 / n_steady * 1e3, 3)}
         torch.cuda.synchronize()
         exchange = sync.describe() if self.world > 1 else None      # exposed_ms of the timed loops above
         ab = None
@@ -442,13 +443,14 @@ class Bench:
             # GMK_RCCL_CUS CUs (default 8) left to RCCL while buckets are in flight, 20 with the persistent kernels on the whole chip
             ab = {}
             keep = int(os.environ.get("GMK_RCCL_CUS", "8")) or 8
+            n_ab = int(os.environ.get("GMK_BENCH_AB_STEPS", "20"))
             for name, k in (("carved", keep), ("uncarved", 0)):
                 sync.set_carve(k)
                 self.timed_steps(model, batches, 2, None)
                 sync.set_carve(k)                          # drops the warm-up steps' wait events
-                e3, _ = self.timed_steps(model, batches, 20, None)
+                e3, _ = self.timed_steps(model, batches, n_ab, None)
                 torch.cuda.synchronize()
-                ab[name] = {"ms_per_step": round(e3 / 20 * 1e3, 3), "exposed_ms": sync.exposed_ms(), "persistent_kernel_cus": sync.cu_limit}
+                ab[name] = {"ms_per_step": round(e3 / n_ab * 1e3, 3), "steps": n_ab, "exposed_ms": sync.exposed_ms(), "persistent_kernel_cus": sync.cu_limit}
             sync.set_carve(int(os.environ.get("GMK_RCCL_CUS", "8")))
         if a.sampler_steps > 0:
             model.eval()
