@@ -1,6 +1,6 @@
 """Benchmark of the DDPM hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W           (N > 1 without WORLD_SIZE: starts its own N ranks as a child `torch.distributed.run`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W            (one rank per GPU, RCCL)
 
@@ -532,5 +532,36 @@ class Bench:
             dist.destroy_process_group()
 
 
+def launch_ranks(a, argv=None):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks ourselves, as ONE CHILD process
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>`),
+    stdout / stderr inherited so that rank 0's compact line stays the last line of stdout, and return the child's exit code.
+    This process has not touched the GPU (no torch.cuda call happens before this branch) and never replaces itself with another
+    program: the ranks are children of the child."""
+    import socket
+    import subprocess
+    assert not torch.cuda.is_initialized(), "the launcher must not have initialised the GPU"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC is the only kind the host driver supports (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    if os.environ.get("GMK_BENCH_LAUNCH_DRYRUN"):          # host test: what would be started, and that the GPU is still untouched
+        print(json.dumps({"launch": cmd, "cuda_initialized": torch.cuda.is_initialized()}))
+        return 0
+    return subprocess.run(cmd, env=env).returncode
+
+
+def needs_launcher(a, environ=None):
+    environ = os.environ if environ is None else environ
+    return a.gpus > 1 and "WORLD_SIZE" not in environ
+
+
 if __name__ == "__main__":
-    Bench(parse()).main()
+    args = parse()
+    if needs_launcher(args):
+        sys.exit(launch_ranks(args))
+    Bench(args).main()

@@ -80,16 +80,23 @@ def test_two_rank_step_equals_single_rank(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
-def test_bench_two_ranks_rehearsal():
-    """The driver's scaling command line (torch.distributed.run ... bench.py --gpus N) with N = 2 ranks sharing this GPU over
-    gloo (RCCL refuses two ranks on one device): barrier, bucketed all-reduce from inside backward, max-over-ranks timing,
-    one JSON line from rank 0 with the whole-job rate."""
+@pytest.mark.parametrize("form", ["torch.distributed.run", "plain"])
+def test_bench_two_ranks_rehearsal(form):
+    """Both of the driver's scaling command lines with N = 2 ranks sharing this GPU over gloo (RCCL refuses two ranks on one
+    device): `torch.distributed.run ... bench.py --gpus N`, and plain `python bench.py --gpus N` (no WORLD_SIZE: bench.py starts
+    its own ranks as a child process).  Barrier, bucketed all-reduce from inside backward, max-over-ranks timing, one JSON line
+    from rank 0 with the whole-job rate."""
     import json
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--config", "custom", "--batch", "64", "--sampler_steps", "2", "--sampler_steps_other", "2", "--no_cpu"]
+    flags = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "custom", "--batch", "64", "--sampler_steps", "2",
+             "--sampler_steps_other", "2", "--no_cpu"]
+    if form == "plain":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + flags
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", free_port(), os.path.join(ROOT, "bench.py")] + flags
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
-                       env=dict(os.environ, GMK_DIST_BACKEND="gloo", OMP_NUM_THREADS="2", GMK_BENCH_STEADY_STEPS="6", GMK_BENCH_AB_STEPS="4"))
+                       env=dict(env, GMK_DIST_BACKEND="gloo", OMP_NUM_THREADS="2", GMK_BENCH_STEADY_STEPS="6", GMK_BENCH_AB_STEPS="4"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

@@ -517,6 +517,33 @@ def test_bench_line_stays_inside_the_drivers_window():
     assert len(bench.compact_line(fat)) <= bench.LINE_LIMIT
 
 
+def test_bench_launcher_branch_starts_ranks_without_touching_the_gpu():
+    """Plain `python bench.py --gpus N` (no WORLD_SIZE: how the driver has called bench.py so far) must start its own N ranks as a child
+    `torch.distributed.run`, from a process that has not initialised the GPU; with WORLD_SIZE set (the documented launcher form) or N = 1
+    it must not."""
+    import json
+    import subprocess
+    import bench
+    ns = lambda n: type("A", (), {"gpus": n})()
+    assert bench.needs_launcher(ns(8), {}) and bench.needs_launcher(ns(2), {"RANK": "0"})
+    assert not bench.needs_launcher(ns(1), {}) and not bench.needs_launcher(ns(8), {"WORLD_SIZE": "8"})
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "2"], capture_output=True,
+                       text=True, timeout=300, env=dict(env, GMK_BENCH_LAUNCH_DRYRUN="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["cuda_initialized"] is False
+    cmd = d["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    # the child's exit code is the parent's: a launcher that cannot start its ranks must not look like a finished bench
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no_cpu"],
+                       capture_output=True, text=True, timeout=600, env=dict(env, GMK_DIST_BACKEND="gloo", OMP_NUM_THREADS="1"))
+    assert r.returncode != 0 and "bench.py needs an MI355X" in r.stderr       # (no GPU here: both ranks refuse, loudly)
+
+
 def _device_asm(src_name):
     """gfx950 assembly of one kernel source (hipcc -S, device only), cached under /tmp by source hash: a few seconds per file."""
     import hashlib
