@@ -225,7 +225,7 @@ def compact_line(full, detail_path=None):
         line["sampler"] = _compact_sampler(full["sampler"])
     others = {}
     for k, o in (full.get("other_configs") or {}).items():
-        c = _pick(o, ("value", "ms_per_step", "global_batch", "model_tflops"))
+        c = _pick(o, ("value", "ms_per_step", "global_batch", "model_tflops", "dtype"))
         r = o.get("roofline") or {}
         if r:
             c["frac"] = r.get("frac")
@@ -316,14 +316,14 @@ class Bench:
         ops.PROFILE = None
         return elapsed, nprof
 
-    def roofline(self, prof, nprof, elapsed, steps, key):
+    def roofline(self, prof, nprof, elapsed, steps, key, dtype=None):
         """Dominant kernel against the MFMA roofline (FLOP/s), every HBM-bound kernel and every kernel above 2 % of the step against
         the HBM roofline (algorithmic bytes / HIP-event time / 8 TB/s), all from this run's events; PMC traffic from the committed
         counter passes only if they were taken on these very kernel sources."""
         if not prof:
             return None
         torch.cuda.synchronize()
-        peak = MFMA_BF16_PEAK_TFLOPS if self.a.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        peak = MFMA_BF16_PEAK_TFLOPS if (dtype or self.a.dtype) == "bf16" else MFMA_F32_PEAK_TFLOPS
         by = {}
         for name, s, e, f, nb in prof:
             d = by.setdefault(name, [0.0, 0.0, 0, 0.0])
@@ -394,13 +394,14 @@ class Bench:
         d.sampler = "ddim"
         return round(steps / t, 2)
 
-    def run_config(self, key, spec, steps, warmup, headline):
+    def run_config(self, key, spec, steps, warmup, headline, dtype=None, sampler=True):
         from generative_models_amd import common
         a = self.a
+        dtype = dtype or a.dtype
         cin, S, B, attention, what = spec
         Model = common.discover_models()["diffusion"]
         G = common.AttrDict(dict(Model.DG))
-        G.update(lr=3e-4, pad32=0, device=str(self.dev), timesteps=1000, bs=B, compute_dtype=a.dtype, in_channels=cin, seed=0,
+        G.update(lr=3e-4, pad32=0, device=str(self.dev), timesteps=1000, bs=B, compute_dtype=dtype, in_channels=cin, seed=0,
                  attention=attention)
         hidden = a.hidden if key == "custom" else 128
         G.hidden_size = hidden
@@ -427,7 +428,7 @@ class Bench:
             N, C = (S // 4) ** 2, 128               # the extension's attention block at the S/4 level: qkv + proj 1x1 convs and the two contractions
             att = (8 * N * C * C + 4 * N * N * C) / 1e9 if attention else 0.0
             out["model_tflops"] = round(3 * (FWD_GFLOP[(cin, S)] + att) * ips / 1e3, 2)    # 3x forward FLOPs per train image
-        roof = self.roofline(prof, nprof, elapsed, steps, key) if self.rank == 0 else None
+        roof = self.roofline(prof, nprof, elapsed, steps, key if dtype == a.dtype else f"{key}_{dtype}", dtype) if self.rank == 0 else None
         if roof:
             out["roofline"] = roof
         n_steady = int(os.environ.get("GMK_BENCH_STEADY_STEPS", "50"))     # (the 2-rank rehearsal over gloo shortens its loops: every step stages 24 MB through the host)
@@ -452,7 +453,7 @@ class Bench:
                 torch.cuda.synchronize()
                 ab[name] = {"ms_per_step": round(e3 / n_ab * 1e3, 3), "steps": n_ab, "exposed_ms": sync.exposed_ms(), "persistent_kernel_cus": sync.cu_limit}
             sync.set_carve(int(os.environ.get("GMK_RCCL_CUS", "8")))
-        if a.sampler_steps > 0:
+        if a.sampler_steps > 0 and sampler:
             model.eval()
             x, y = batches[0]
             init = model._aux_rng.normal((B, cin, S, S), self.dev)
@@ -489,6 +490,11 @@ class Bench:
             plan = plan[:1]
         head = self.run_config(plan[0][0], plan[0][1], a.steps, a.warmup, True)
         others = {k: self.run_config(k, spec, max(a.steps, 50), max(a.warmup, 10), False) for k, spec in plan[1:]}
+        if a.config == "auto" and self.world == 1 and a.others and a.dtype == "bf16":
+            # what the north_star's 1e-3 bar costs: the headline workload in the fp32 mode (fp32 storage, exact-fp32 MFMA chains, peak 157 TFLOP/s),
+            # a short loop - 3 warm-up + 10 timed steps, no sampler
+            others["cfg2_fp32"] = self.run_config("cfg2", CONFIGS["cfg2"], 10, 3, False, dtype="fp32", sampler=False)
+            others["cfg2_fp32"]["dtype"] = "fp32"
         cpu = None
         if self.rank == 0 and self.world == 1 and not a.no_cpu:
             cpu = cpu_baseline(a.cpu_seconds, plan[0][1][1], plan[0][1][0])

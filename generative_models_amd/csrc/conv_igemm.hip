@@ -1013,6 +1013,11 @@ static int conv_igemm_impl(const void* src0, const void* src1, int c0, int c1, i
     // the transposed form (data gradient of the stride-2 conv) is the plain 3x3 conv of the zero-stuffed gradient: on the halo
     // kernel 3/4 of the resident pixels are zeros, but it still beats the im2col gather by 1.7x (215 vs 360 us at 28x28)
     const bool stuffed = mode == GMK_CONV_TRANSPOSED2 && !((ho | wo) & 1);
+    // The transposed form in its sub-pixel shape (conv_subpixel.hip, round 5): output parities meet 1 / 2 / 2 / 4 of the 9 taps over the gradient's
+    // own grid, the halo of a low-resolution tile stays in LDS for all four parities - the zero-stuffed form below multiplies 27 of 36 tap-images by zero.
+    if (stuffed && force == 0 && gmk_is16(dtype) && ksize == 3 && c0 == 128 && c1 == 0 && cout == 128 && !emb && !gn_scale && !gn_stats && !out2 &&
+        ho == 2 * hs && wo == 2 * ws && gmk_conv_subpixel_ok(B, hs, ws, c0, cout, dtype))
+        return gmk_conv_subpixel(src0, B, hs, ws, c0, w, w_rows, n0, cout, GMK_SUBPIXEL_TRANSPOSED, bias, residual, out, out_cstride, dtype, stream);
     if ((force == 0 || force == 3) && gmk_is16(dtype) && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2 || stuffed) && ksize == 3) {
         const int rc = gmk_conv3x3_halo_try(src0, src1, c0, c1, B, ho, wo, w, w_rows, n0, cout, bias, emb, emb_stride, residual,
                                             out, out_cstride, (force == 3 || !stuffed) ? 1 : 32, stuffed ? 2 : mode == GMK_CONV_UPSAMPLE2, gn_stats,

@@ -248,6 +248,7 @@ class SimpleUnet(nn.Module):
             self._pv[n] = p.data
             self._gv[n] = p.grad
         self._packs = None
+        self._up_packs = None
         self._plist = [named[n] for n, _ in self._inventory]
         self._packed_version = -1
         self._side = None          # side stream of the weight gradients (backward_hip)
@@ -271,6 +272,13 @@ class SimpleUnet(nn.Module):
         """ops.conv_igemm with this net's width as the output-channel count (the C-ABI default is one 128-channel block)."""
         kw.setdefault("cout", self.channels)
         return ops.conv_igemm(*args, **kw)
+
+    def _upsample_conv(self, name, x, out_hw):
+        """`Upsample` (simple_unet.py:112-122): nearest x2 + 3x3 convolution.  Sub-pixel form (four 2x2-tap parities of the low-resolution tensor on
+        pre-summed weights, gmk_conv_subpixel) where the kernel takes the shape; else the nearest-x2 addressing of the stride-1 kernels."""
+        if self._up_packs is not None and ops.conv_subpixel_ok(x):
+            return ops.conv_subpixel(x, self._up_packs[name], self.channels, ops.SUBPIXEL_UPSAMPLE, bias=self._pv[name + ".bias"])
+        return self._conv([x], self._packs[name][0], self.channels, 3, ops.UPSAMPLE2, out_hw, bias=self._pv[name + ".bias"], gn_stats=True)
 
     def mark_params_changed(self):
         self._packs_stale = True
@@ -330,6 +338,12 @@ class SimpleUnet(nn.Module):
                 off += 2 * k
             self._pack_table = table
         ops.pack_conv_weights_multi(self.flat_params, self._pack_buf, self._pack_table, self._pack_f16)      # all convolutions, one launch
+        # the two `Upsample` convolutions (simple_unet.py:112-122) also get the pack of their sub-pixel form: 16 pre-summed 2x2-tap matrices
+        if self.channels == 128 and self.compute_dtype == torch.bfloat16:
+            if self._up_packs is None:
+                self._up_packs = {n: torch.empty(16 * 128 * 128, device=dev, dtype=self.act_dtype) for n in ("up.seq.0.1.conv", "up.seq.3.1.conv")}
+            for n, buf in self._up_packs.items():
+                ops.pack_upsample_weight(self._pv[n + ".weight"], buf)
         self._packs_stale = False
         self._packed_version = self._version_sum()
 
@@ -648,13 +662,11 @@ class SimpleUnet(nn.Module):
         if self.attention:
             t7 = self._attn_fwd(t7, ctx)
         u0r = self._res_fwd("up.seq.0.0", [t7, t6], emb_all, 5, ctx)
-        u0 = self._conv([u0r], self._packs["up.seq.0.1.conv"][0], C, 3, ops.UPSAMPLE2, (H2, W2),
-                            bias=P["up.seq.0.1.conv.bias"], gn_stats=True)
+        u0 = self._upsample_conv("up.seq.0.1.conv", u0r, (H2, W2))
         u1 = self._res_fwd("up.seq.1", [u0, t5], emb_all, 6, ctx)
         u2 = self._res_fwd("up.seq.2", [u1, t4], emb_all, 7, ctx)
         u3r = self._res_fwd("up.seq.3.0", [u2, t3], emb_all, 8, ctx)
-        u3 = self._conv([u3r], self._packs["up.seq.3.1.conv"][0], C, 3, ops.UPSAMPLE2, (H, W),
-                            bias=P["up.seq.3.1.conv.bias"], gn_stats=True)
+        u3 = self._upsample_conv("up.seq.3.1.conv", u3r, (H, W))
         u4 = self._res_fwd("up.seq.4", [u3, t2], emb_all, 9, ctx)
         u5 = self._res_fwd("up.seq.5", [u4, t1], emb_all, 10, ctx)
         u6 = self._res_fwd("up.seq.6", [u5, t0], emb_all, 11, ctx)

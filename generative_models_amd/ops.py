@@ -31,6 +31,8 @@ KERNEL_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_dma_kernel", 3: "conv3x3_
                 7: "conv3x3_halo_ws_kernel[+1x1 skip]",
                 # stride-2 data gradient where the halo kernel declines (fp32, small problems): four output-parity phase launches of the LDS-DMA kernel
                 6: "conv_igemm_dma_kernel[stride-2 dgrad phases]",
+                # sub-pixel (output-parity) forms: `Upsample` as four 2x2-tap parities on pre-summed weights, the stride-2 data gradient as 1 / 2 / 2 / 4 taps
+                8: "conv_subpixel_ws_kernel[upsample]", 9: "conv_subpixel_ws_kernel[transposed]",
                 21: "gn_silu_fwd_reg_kernel", 22: "gn_silu_fwd_kernel", 23: "gn_silu_bwd_hybrid_kernel", 24: "gn_silu_bwd_kernel"}
 
 
@@ -386,6 +388,49 @@ def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, 
               "conv_igemm")
     if part is not None and lib.gmk_last_kernel() == 3 and ho * wo >= 32:      # only the 8-compute-wave halo kernel emits statistics
         out._gn_stats = (part, tp, nt)     # consumed by gn_silu_fwd(out, ...)
+    return out
+
+
+SUBPIXEL_UPSAMPLE, SUBPIXEL_TRANSPOSED = 0, 1
+
+
+def conv_subpixel_ok(src, cout=128):
+    """True if the x2 resampling convolutions of a low-resolution NHWC `src` run in their sub-pixel form (gmk_conv_subpixel)."""
+    if src.dtype not in _HALF:
+        return False
+    B, H, W, c = src.shape
+    return bool(lib.gmk_conv_subpixel_ok(B, H, W, c, cout, _DT[src.dtype]))
+
+
+def pack_upsample_weight(w, out):
+    """w: fp32 [Cout][Cin][3][3] (a contiguous arena view) -> out: 16 x Cout x Cin elements of out.dtype, the pre-summed 2x2-tap matrices of
+    the sub-pixel `Upsample` (reference simple_unet.py:112-122)."""
+    _f32(w, "w")
+    cout, cin = w.shape[0], w.shape[1]
+    assert w.shape[2:] == (3, 3) and w.is_contiguous() and out.numel() == 16 * cout * cin and out.dtype in _HALF
+    _chk(out, name="out")
+    check(lib.gmk_pack_upsample_weight(_p(w), _p(out), cout, cin, _DT[out.dtype], _s()), "pack_upsample_weight")
+    return out
+
+
+def conv_subpixel(src, w, w_rows, mode, bias=None, residual=None, n0=0, cout=128):
+    """Low-resolution NHWC src [B,H,W,128] -> [B,2H,2W,cout]: SUBPIXEL_UPSAMPLE = conv3x3(nearest x2 (src)) with the pack of
+    pack_upsample_weight, SUBPIXEL_TRANSPOSED = the data gradient of a 3x3 stride-2 convolution with its ordinary data-gradient pack."""
+    s0 = _chk(src, name="src")
+    B, H, W, c = s0.shape
+    _chk(w, s0.dtype, "w")
+    taps = 16 if mode == SUBPIXEL_UPSAMPLE else 9
+    assert w.numel() == taps * w_rows * c, (w.numel(), taps, w_rows, c)
+    out = torch.empty((B, 2 * H, 2 * W, cout), device=s0.device, dtype=s0.dtype)
+    if bias is not None:
+        _f32(bias, "bias"); assert bias.numel() == cout
+    if residual is not None:
+        _chk(residual, s0.dtype, "residual"); assert residual.shape == out.shape
+    # algorithmic work: that of the reference's op (9 taps per OUTPUT pixel for the upsampled convolution, 9 per SOURCE pixel for the transposed one)
+    mpix = B * 4 * H * W if mode == SUBPIXEL_UPSAMPLE else B * H * W
+    with _Timed("conv_subpixel", 2.0 * mpix * cout * c * 9, _nbytes(s0, residual, out)):
+        check(lib.gmk_conv_subpixel(_p(s0), B, H, W, c, _p(w), w_rows, n0, cout, mode, _p(bias), _p(residual), _p(out), cout,
+                                    _DT[s0.dtype], _s()), "conv_subpixel")
     return out
 
 

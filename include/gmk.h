@@ -35,7 +35,7 @@ extern "C" {
 int gmk_version(void);
 const char* gmk_last_error(void);
 /* profiling aid: which kernel the calling thread's last gmk_conv_igemm / gmk_conv_wgrad / gmk_gn_* call launched
- * (1 conv_igemm_kernel, 2 conv_igemm_dma_kernel, 3 conv3x3_halo_kernel, 4 conv3x3_halo_ws_kernel, 7 conv3x3_halo_ws_kernel with the folded 1x1 skip convolution, 5 a halo kernel on the zero-stuffed source of GMK_CONV_TRANSPOSED2 (GMK_CONV_KERNEL=3), 6 the four parity-phase launches of the LDS-DMA kernel for GMK_CONV_TRANSPOSED2, 11 conv_wgrad_kernel,
+ * (1 conv_igemm_kernel, 2 conv_igemm_dma_kernel, 3 conv3x3_halo_kernel, 4 conv3x3_halo_ws_kernel, 7 conv3x3_halo_ws_kernel with the folded 1x1 skip convolution, 8 / 9 conv_subpixel_ws_kernel (upsample / transposed), 5 a halo kernel on the zero-stuffed source of GMK_CONV_TRANSPOSED2 (GMK_CONV_KERNEL=3), 6 the four parity-phase launches of the LDS-DMA kernel for GMK_CONV_TRANSPOSED2, 11 conv_wgrad_kernel,
  * 12 conv_wgrad_slots_kernel, 13 conv_wgrad_slots_ws_kernel, 14 conv1x1_pair_stream_kernel, 15 conv1x1_wgrad_stream_kernel, 21 gn_silu_fwd_reg_kernel, 22 gn_silu_fwd_kernel, 23 gn_silu_bwd_hybrid_kernel, 24 gn_silu_bwd_kernel) */
 int gmk_last_kernel(void);
 /* development aid: force kernel variants (0 = automatic; see GMK_CONV_KERNEL / GMK_WGRAD_KERNEL / GMK_GN_KERNEL); -1 = unset */
@@ -148,6 +148,23 @@ int gmk_conv3x3_skipfold_ok(int B, int H, int W, int c0, int cs, int cout);
 int gmk_conv3x3_skipfold(const void* src, int c0, int B, int H, int W, const void* w, int w_rows, int n0, int cout,
                          const float* bias, const void* sk0, const void* sk1, int cs, const void* wsk, int wsk_rows, int nsk0,
                          const float* bias_sk, void* out, int out_cstride, int dtype, void* stream);
+/* Sub-pixel (output-parity) form of the two x2 resampling convolutions: a LOW-resolution source [B][H][W][cin] -> out [B][2H][2W][cout].
+ *   GMK_SUBPIXEL_UPSAMPLE    `Upsample` (simple_unet.py:112-122: F.interpolate(nearest, x2), then Conv2d(C, C, 3, padding=1)).  Output pixel
+ *                            (2i + a, 2j + b) only meets low-resolution rows {i + a - 1, i + a} and columns {j + b - 1, j + b}: w is the pack of
+ *                            gmk_pack_upsample_weight, `[4 (2a + b) + 2 ty + tx][w_rows][cin]` = the 3x3 weights that land on one low-resolution
+ *                            pixel summed in fp32 and rounded once - 16 tap-products per low-resolution pixel instead of the 36 of
+ *                            gmk_conv_igemm(GMK_CONV_UPSAMPLE2) (same sum, other rounding order: not bit-identical to it)
+ *   GMK_SUBPIXEL_TRANSPOSED  data gradient of `Downsample` (simple_unet.py:75-84, Conv2d(C, C, 3, stride=2, padding=1)): w is the ordinary
+ *                            w_dgrad pack `[9][w_rows][cin]` of gmk_pack_conv_weight; parities meet 1 / 2 / 2 / 4 of its taps (the same products
+ *                            in the same order as gmk_conv_igemm(GMK_CONV_TRANSPOSED2) on the zero-stuffed gradient, minus its 27 of 36 multiplications by zero)
+ * bias / residual (NHWC, the output's shape) optional.  16-bit types, cin = cout = 128, shapes where gmk_conv_subpixel_ok(...) returns 1; otherwise
+ * the call fails (callers fall back to gmk_conv_igemm).  GMK_SUBPIXEL=0 in the environment makes gmk_conv_subpixel_ok answer 0 (A/B switch). */
+#define GMK_SUBPIXEL_UPSAMPLE 0
+#define GMK_SUBPIXEL_TRANSPOSED 1
+int gmk_conv_subpixel_ok(int B, int H, int W, int cin, int cout, int dtype);
+int gmk_pack_upsample_weight(const float* w, void* w_sub, int cout, int cin, int dtype, void* stream);
+int gmk_conv_subpixel(const void* src, int B, int H, int W, int cin, const void* w, int w_rows, int n0, int cout, int mode,
+                      const float* bias, const void* residual, void* out, int out_cstride, int dtype, void* stream);
 /* statistics-only GroupNorm for the above: mean / rstd [B][groups] and the affine tables (columns [0, C) of rows of tab_stride
  * floats: a concatenated input passes the same table with a column offset); xadd as in gmk_gn_silu_fwd */
 int gmk_gn_stats(const void* x, const float* gamma, const float* beta, float* mean, float* rstd, float* tab_scale,

@@ -736,3 +736,85 @@ def test_skip_convolution_folded_into_conv2(ops, dtype, S, B):
     assert e_ref < 0.75 * ulp and e_ref <= rel_err(nchw(two), ref) + 1e-6, (e_ref, rel_err(nchw(two), ref))
     assert e_two < 1.5 * ulp, e_two
     assert torch.equal(out, out2)                                   # bit-reproducible
+
+
+SUBPIXEL_SHAPES = [(7, 9), (8, 37), (16, 3), (16, 300), (32, 2), (14, 5), (14, 400), (32, 70)]      # (low-resolution size, batch)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("S,B", SUBPIXEL_SHAPES)
+def test_upsample_conv_subpixel(ops, dtype, S, B):
+    """`Upsample` (reference simple_unet.py:112-122: F.interpolate(nearest, x2), then Conv2d(C, C, 3, padding=1)) in its sub-pixel form: four output
+    parities, each a 2x2-tap convolution of the LOW-resolution tensor with the 3x3 weights that land on one low-resolution pixel pre-summed in fp32
+    (16 tap-products per low-resolution pixel instead of 36).  Against torch fp32 on the rounded input and the fp32 weights at the 16-bit mode's bar
+    (measured far below it), against the nearest-x2 form of the halo kernel it replaces (the same sum, other rounding order), bit-reproducible.
+    Shapes: 7 -> 14 ... 32 -> 64; tiles spanning images with ragged tiles (7, 14), one image per tile (16), several tiles per image (32), more
+    tiles than CUs (several jobs per workgroup), fewer tiles than XCDs (16 x 16, B = 3)."""
+    from generative_models_amd._lib import lib
+    C = 128
+    x = q(rnd(B, C, S, S, seed=300), dtype)
+    w = rnd(C, C, 3, 3, seed=301) / math.sqrt(C * 9)             # fp32 master weights: the pack sums them before rounding
+    bias = rnd(C, seed=302) * 0.1
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, bias, padding=1)
+    xd = nhwc(x, dtype)
+    assert ops.conv_subpixel_ok(xd)
+    wsub = torch.empty(16 * C * C, device="cuda", dtype=dtype)
+    ops.pack_upsample_weight(w.cuda(), wsub)
+    # the pack itself: [4 (2a + b) + 2 ty + tx][cout][cin] = fp32 sums of the 3x3 taps that meet one low-resolution pixel, rounded once
+    rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
+    pk = wsub.float().cpu().view(2, 2, 2, 2, C, C)
+    for a in range(2):
+        for b in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    want = sum(w[:, :, y, x_] for y in rows[a][ty] for x_ in rows[b][tx])
+                    assert torch.equal(pk[a, b, ty, tx], q(want, dtype))
+    out = ops.conv_subpixel(xd, wsub, C, ops.SUBPIXEL_UPSAMPLE, bias=bias.cuda())
+    assert lib.gmk_last_kernel() == 8 and out.shape == (B, 2 * S, 2 * S, C)
+    e = rel_err(nchw(out), ref)
+    assert e < TOL[torch.bfloat16], e
+    wf = torch.empty(w.numel(), device="cuda", dtype=dtype)
+    ops.pack_conv_weight(w.cuda(), wf, None)
+    old = ops.conv_igemm([xd], wf, C, 3, ops.UPSAMPLE2, (2 * S, 2 * S), bias=bias.cuda())
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    assert rel_err(nchw(out), nchw(old)) < 3 * ulp
+    assert e <= rel_err(nchw(old), ref) + 0.5 * ulp                 # not worse than the form it replaces
+    assert torch.equal(out, ops.conv_subpixel(xd, wsub, C, ops.SUBPIXEL_UPSAMPLE, bias=bias.cuda()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("res", [True, False])
+@pytest.mark.parametrize("S,B", SUBPIXEL_SHAPES)
+def test_transposed_dgrad_subpixel(ops, dtype, S, B, res):
+    """Data gradient of `Downsample` (reference simple_unet.py:75-84: Conv2d(C, C, 3, stride=2, padding=1)) in its sub-pixel form: output parities
+    meet 1 / 2 / 2 / 4 taps of the ordinary data-gradient pack over the gradient's own grid - the products of the zero-stuffed halo form without
+    its multiplications by zero.  Against autograd, with and without the residual the net adds there (the skip path's gradient), and against the
+    zero-stuffed form: the same products accumulated in fp32, so the two differ by summation order only (<= 1 ulp of the 16-bit output)."""
+    from generative_models_amd._lib import lib
+    C = 128
+    x = q(rnd(B, C, 2 * S, 2 * S, seed=310), dtype).requires_grad_(True)
+    w = q(rnd(C, C, 3, 3, seed=311) / math.sqrt(C * 9), dtype).requires_grad_(True)
+    out_ref = F.conv2d(x, w, None, stride=2, padding=1)
+    dy = q(rnd(*out_ref.shape, seed=312), dtype)
+    out_ref.backward(dy)
+    r = q(rnd(B, C, 2 * S, 2 * S, seed=313), dtype) if res else None
+    ref = x.grad + (r if res else 0)
+    wf = torch.empty(w.numel(), device="cuda", dtype=dtype); wd = torch.empty_like(wf)
+    ops.pack_conv_weight(w.detach().cuda(), wf, wd)
+    dyd = nhwc(dy, dtype)
+    rd = nhwc(r, dtype) if res else None
+    assert ops.conv_subpixel_ok(dyd)
+    dx = ops.conv_subpixel(dyd, wd, C, ops.SUBPIXEL_TRANSPOSED, residual=rd)
+    assert lib.gmk_last_kernel() == 9
+    assert rel_err(nchw(dx), ref) < TOL[torch.bfloat16]
+    try:
+        lib.gmk_set_kernel_choice(2, -1, -1)                        # the four phase launches of the LDS-DMA kernel: the same products per output
+        dx_p = ops.conv_igemm([dyd], wd, C, 3, ops.TRANSPOSED2, (2 * S, 2 * S), residual=rd)
+        assert lib.gmk_last_kernel() == 6
+    finally:
+        lib.gmk_set_kernel_choice(-1, -1, -1)
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    assert rel_err(nchw(dx), nchw(dx_p)) < 1.5 * ulp
+    # through the dispatcher: gmk_conv_igemm(GMK_CONV_TRANSPOSED2) takes the sub-pixel form where it is eligible
+    dx_auto = ops.conv_igemm([dyd], wd, C, 3, ops.TRANSPOSED2, (2 * S, 2 * S), residual=rd)
+    assert lib.gmk_last_kernel() == 9 and torch.equal(dx_auto, dx)

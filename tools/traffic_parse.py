@@ -5,6 +5,38 @@ import csv, glob, json, sys, collections, re
 out = sys.argv[1]
 
 
+def instantiation(name):
+    """The 3x3 halo kernel runs as several template instantiations with different work per launch (fp16 forward, bf16 data gradient, the
+    folded skip convolution, the sub-pixel phase forms): each gets its OWN record, keyed `conv3x3_halo_ws_kernel<f16>`, `<bf16>`, `<f16,+skip>` ...
+    (rocprofv3 prints some instantiations demangled - bf16 as "bool _Accum, bool, E" - and some mangled)."""
+    base = short(name)
+    if not base.startswith("conv3x3_halo") and not base.startswith("conv_phase"):
+        return None
+    if name.startswith("_Z"):
+        m = re.search(r"kernelI(DF16_|DF16b)((?:L[bi]\d+E)*)E", name)
+        if not m:
+            return None
+        typ = "f16" if m.group(1) == "DF16_" else "bf16"
+        args = re.findall(r"L([bi])(\d+)E", m.group(2))
+        vals = [int(v) for _, v in args]
+    else:
+        m = re.search(r"kernel<(.*)>\(", name)
+        if not m:
+            return None
+        body = m.group(1)
+        typ = "bf16" if "_Accum" in body or "bfloat" in body or "__bf16" in body else "f16"
+        vals = [1 if t.strip() == "true" else 0 if t.strip() == "false" else int(t) for t in body.split(",") if t.strip() in ("true", "false") or t.strip().lstrip("-").isdigit()]
+    tags = [typ]
+    if base == "conv3x3_halo_ws_kernel":          # <T, kPrefetchW, kShape, kFuse, kSkip>
+        if len(vals) >= 3 and vals[2]:
+            tags.append("+gn")
+        if len(vals) >= 4 and vals[3]:
+            tags.append("+skip")
+    else:
+        tags += [str(v) for v in vals]
+    return f"{base}<{','.join(tags)}>"
+
+
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
@@ -19,11 +51,17 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 clk = collections.defaultdict(lambda: [0.0, 0.0])          # kernel -> [GRBM_GUI_ACTIVE cycles (sum over the 8 XCDs), dispatch ns]
 for f in sorted(glob.glob(f"{out}/g*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        k = short(r["Kernel_Name"])
-        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and "End_Timestamp" in r:
-            clk[k][0] += float(r["Counter_Value"])
-            clk[k][1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        inst = instantiation(r["Kernel_Name"])
+        keys = [short(r["Kernel_Name"])]
+        if inst:
+            keys.append(inst)
+            if inst.endswith("+skip>"):      # the bench line's name for the folded launches; the plain name keeps the plain instantiations only
+                keys[0] = keys[0] + "[+1x1 skip]"
+        for k in keys:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and "End_Timestamp" in r:
+                clk[k][0] += float(r["Counter_Value"])
+                clk[k][1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
 res = {}
 for k, c in agg.items():
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
