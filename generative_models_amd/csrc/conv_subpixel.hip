@@ -16,6 +16,13 @@
 // of a tile is filled during the first segment of that tile (parity 0, half 0 reads buffer 0 only), half-buffer 0 of the NEXT tile during the
 // last segment (parity 3, half 1 reads buffer 1 only): 7 pieces in a window of NT0 / NT3 K-steps, everything else carries weights only.
 // Wave specialisation, LDS map, swizzles, counted vmcnt waits, one s_barrier per K-step and the 16x16x32 consumer are those of conv_halo.hip.
+//
+// The third form runs the other way (HIGH -> LOW): the data gradient of `Upsample`, dx_low = sumpool2x2(dgrad3x3(dy_high)) in the reference's
+// autograd, is the transpose of the sub-pixel forward: dx_low[i][j] = sum over the four parity VIEWS V_ab[r][c] = dy[2r + a][2c + b] of a 2x2-tap
+// convolution with the transposed pre-summed matrices - 16 tap-products per low-resolution pixel, one launch, no high-resolution intermediate and no
+// pooling pass.  Here the eight (view, channel half) segments of a tile each have their OWN halo: the two half-buffers alternate per segment, the
+// next segment's 7 pieces stream in during the current segment's 4 K-steps (conv_halo.hip's double buffering at 4 steps per phase instead of 9),
+// one accumulator set, one dense epilogue per tile.
 #include "gmk_common.h"
 
 namespace {
@@ -49,15 +56,19 @@ __device__ __forceinline__ int div_small(int a, float inv) { return (int)(((floa
 // kMode 0: upsample (parities in order (0,0) (0,1) (1,0) (1,1), 4 taps each, pack index 4 (2a + b) + 2 ty + tx, dy = a - 1 + ty, dx = b - 1 + tx)
 // kMode 1: transposed (parity order (1,1) (0,0) (0,1) (1,0): the 4-tap parity first and a 2-tap one last, so the fill windows are 4 and 2 steps;
 //          per axis: parity 0 meets tap 1 (offset 0), parity 1 meets tap 0 (offset 0) and tap 2 (offset +1); pack index 3 ty + tx)
-struct Step { int ph, a, b, dy, dx, ptap, half, first_ph, last_ph; };
+struct Step { int ph, a, b, dy, dx, ptap, half, buf, first_ph, last_ph; };
+// kMode 2: `Upsample` data gradient (HIGH -> LOW): segments (view (a, b), channel half) in order, 4 taps each; tap (ty, tx) of view (a, b) reads the
+//          view at low-resolution offset (1 - a - ty, 1 - b - tx) (the transpose of kMode 0's (a - 1 + ty, b - 1 + tx)); pack index as kMode 0;
+//          half-buffer = segment & 1; one accumulation over all 32 steps
 template <int kMode> struct Plan {
-    static constexpr int pa(int i) { return kMode == 0 ? (i >> 1) : (i == 0 || i == 3) ? 1 : 0; }
-    static constexpr int pb(int i) { return kMode == 0 ? (i & 1) : (i == 0 || i == 2) ? 1 : 0; }
-    static constexpr int nax(int par) { return kMode == 0 ? 2 : (par ? 2 : 1); }            // taps along one axis
+    static constexpr bool kDown = kMode == 2;
+    static constexpr int pa(int i) { return kMode != 1 ? (i >> 1) : (i == 0 || i == 3) ? 1 : 0; }
+    static constexpr int pb(int i) { return kMode != 1 ? (i & 1) : (i == 0 || i == 2) ? 1 : 0; }
+    static constexpr int nax(int par) { return kMode != 1 ? 2 : (par ? 2 : 1); }            // taps along one axis
     static constexpr int ntaps(int i) { return nax(pa(i)) * nax(pb(i)); }
     static constexpr int nsteps() { return 2 * (ntaps(0) + ntaps(1) + ntaps(2) + ntaps(3)); }
-    static constexpr int axis_tap(int par, int k) { return kMode == 0 ? k : (par ? 2 * k : 1); }          // (transposed) 3x3 tap index along the axis
-    static constexpr int axis_off(int par, int k) { return kMode == 0 ? par - 1 + k : (par ? k : 0); }      // low-resolution offset
+    static constexpr int axis_tap(int par, int k) { return kMode != 1 ? k : (par ? 2 * k : 1); }          // (transposed) 3x3 tap index along the axis
+    static constexpr int axis_off(int par, int k) { return kMode == 0 ? par - 1 + k : kMode == 2 ? 1 - par - k : (par ? k : 0); }      // low-resolution offset
     static constexpr Step at(int s) {
         int base = 0;
         for (int i = 0; i < 4; ++i) {
@@ -66,27 +77,33 @@ template <int kMode> struct Plan {
                 const int l = s - base, half = l / nt, t = l % nt;
                 const int a = pa(i), b = pb(i), nx = nax(b);
                 const int ky = t / nx, kx = t % nx;
-                const int ptap = kMode == 0 ? 4 * (2 * a + b) + 2 * ky + kx : 3 * axis_tap(a, ky) + axis_tap(b, kx);
-                return Step{i, a, b, axis_off(a, ky), axis_off(b, kx), ptap, half, l == 0, l == 2 * nt - 1};
+                const int ptap = kMode != 1 ? 4 * (2 * a + b) + 2 * ky + kx : 3 * axis_tap(a, ky) + axis_tap(b, kx);
+                return Step{i, a, b, axis_off(a, ky), axis_off(b, kx), ptap, half, kDown ? ((2 * i + half) & 1) : half,
+                            kDown ? s == 0 : l == 0, kDown ? s == nsteps() - 1 : l == 2 * nt - 1};
             }
             base += 2 * nt;
         }
-        return Step{0, 0, 0, 0, 0, 0, 0, 0, 0};
+        return Step{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     }
     static constexpr int S = nsteps(), NT0 = ntaps(0), NT3 = ntaps(3);
-    // halo pieces issued behind the weights of step s: [lo, hi) of half-buffer 1 of THIS tile (window A: steps 0 .. NT0 - 1) or of
-    // half-buffer 0 of the NEXT tile (window B: steps S - NT3 .. S - 1)
+    // halo pieces issued behind the weights of step s.  LOW -> HIGH: [lo, hi) of half-buffer 1 of THIS tile (window A: steps 0 .. NT0 - 1) or of
+    // half-buffer 0 of the NEXT tile (window B: steps S - NT3 .. S - 1).  HIGH -> LOW: of the NEXT segment, spread over the current segment's 4 steps.
     static constexpr int win_lo(int k, int n) { return (7 * k + n - 1) / n; }
-    static constexpr int fill_lo(int s) { return s < NT0 ? win_lo(s, NT0) : s >= S - NT3 ? win_lo(s - (S - NT3), NT3) : 0; }
-    static constexpr int fill_hi(int s) { return s < NT0 ? win_lo(s + 1, NT0) : s >= S - NT3 ? win_lo(s - (S - NT3) + 1, NT3) : 0; }
+    static constexpr int fill_lo(int s) { return kDown ? win_lo(s & 3, 4) : s < NT0 ? win_lo(s, NT0) : s >= S - NT3 ? win_lo(s - (S - NT3), NT3) : 0; }
+    static constexpr int fill_hi(int s) { return kDown ? win_lo((s & 3) + 1, 4) : s < NT0 ? win_lo(s + 1, NT0) : s >= S - NT3 ? win_lo(s - (S - NT3) + 1, NT3) : 0; }
     static constexpr int nfill(int s) { return fill_hi(s) - fill_lo(s); }
-    // the consumers read a step's first pixel fragments behind its barrier (instead of under the previous step's last MFMA group) where the
-    // half-buffer only became valid with that barrier (steps 0 and NT0) and at the start of every parity (the epilogue needs the registers)
-    static constexpr bool post_barrier_loads(int s) { return at(s).first_ph || s == NT0; }
+    // steps whose half-buffer only became valid with their own barrier (everything older has to have landed: vmcnt(0))
+    static constexpr bool fresh_halo(int s) { return kDown ? (s & 3) == 0 : (s == 0 || s == NT0); }
+    // the consumers read a step's first pixel fragments behind its barrier (instead of under the previous step's last MFMA group) there, and
+    // at the start of every parity of the LOW -> HIGH forms (the epilogue needs the registers)
+    static constexpr bool post_barrier_loads(int s) { return fresh_halo(s) || at(s).first_ph; }
 };
 static_assert(Plan<0>::S == 32 && Plan<1>::S == 18 && Plan<0>::NT0 == 4 && Plan<1>::NT0 == 4 && Plan<1>::NT3 == 2, "K-step plan");
 static_assert(Plan<1>::at(0).ptap == 0 && Plan<1>::at(3).ptap == 8 && Plan<1>::at(3).dy == 1 && Plan<1>::at(8).ptap == 4 && Plan<1>::at(8).last_ph == 0 &&
               Plan<1>::at(9).last_ph == 1 && Plan<1>::at(10).ptap == 3 && Plan<1>::at(11).ptap == 5 && Plan<1>::at(11).dx == 1, "transposed plan");
+static_assert(Plan<2>::S == 32 && Plan<2>::at(0).dy == 1 && Plan<2>::at(3).dy == 0 && Plan<2>::at(3).dx == 0 && Plan<2>::at(4).buf == 1 && Plan<2>::at(8).buf == 0 &&
+              Plan<2>::at(8).b == 1 && Plan<2>::at(8).dx == 0 && Plan<2>::at(9).dx == -1 && Plan<2>::at(31).dy == -1 && Plan<2>::at(31).last_ph == 1 &&
+              Plan<2>::at(7).last_ph == 0 && Plan<2>::at(28).ptap == 12 && Plan<2>::nfill(3) == 1 && Plan<2>::nfill(4) == 2, "upsample data-gradient plan");
 
 template <typename T, int kMode>
 __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParams p) {
@@ -95,6 +112,7 @@ __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParam
     typedef typename Frag16<T>::half_type half_t;
     constexpr int ES = 2;
     constexpr int S = PL::S, NT0 = PL::NT0, NT3 = PL::NT3;
+    constexpr bool kDown = PL::kDown;
     fp16_saturating_stores<T>();
     __shared__ __attribute__((aligned(16))) char smem[kWOFF + 3 * kWST];
 
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParam
             w_off[u] = (unsigned)(p.n0 + row) * 128u * ES + (unsigned)((lch ^ ((row >> 1) & 7)) << 4);
         }
         unsigned hvoff[7][2];                 // byte offset of this lane's slot of piece j in the source (pixel x 256 B + swizzled chunk)
-        auto resolve_piece = [&](int tile, int j) {
+        auto resolve_piece = [&](int tile, int j, int va = 0, int vb = 0) {      // HIGH -> LOW: of the parity view (va, vb) of the high-resolution source
             const bool exists = tile < p.ntiles;
             const int gr0 = tile * p.R;
             const int b0 = gr0 / H;
@@ -150,15 +168,15 @@ __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParam
                 const int x = xe - 1;
                 const int b = b0 + k;
                 const bool ok = exists && y >= 0 && y < H && x >= 0 && x < W && b < p.B;
-                const unsigned pix = ok ? (unsigned)((b * H + y) * W + x) : kBadPix;
+                const unsigned pix = !ok ? kBadPix : kDown ? (unsigned)(((b * H + y) * 2 + va) * (2 * W) + 2 * x + vb) : (unsigned)((b * H + y) * W + x);
                 hvoff[j][u] = __umul24(pix, 128u * ES) + ((unsigned)(lch ^ ((n >> 1) & 7)) << 4);
             }
         };
-        auto issue_fill = [&](int hbuf, int j) {          // channel half hbuf of the source into half-buffer hbuf
+        auto issue_fill = [&](int hbuf, int j, int half) {          // channel half `half` of the source into half-buffer hbuf
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 GMK_LDS char* dst = (GMK_LDS char*)(smem + hbuf * kHB + j * 8192 + (pw * 2 + u) * 1024);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (GMK_LDS void*)dst, 16, hvoff[j][u], (unsigned)hbuf << 7, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (GMK_LDS void*)dst, 16, hvoff[j][u], (unsigned)half << 7, 0, 0);
             }
         };
         auto issue_w = [&](int stage, int ptap, int half) {
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParam
         int sq = 2;
         int tile = job_tile(0);
 #pragma unroll
-        for (int j = 0; j < 7; ++j) { resolve_piece(tile, j); issue_fill(0, j); }
+        for (int j = 0; j < 7; ++j) { resolve_piece(tile, j); issue_fill(0, j, 0); }
         issue_w(0, PL::at(0).ptap, PL::at(0).half);
         issue_w(1, PL::at(1).ptap, PL::at(1).half);
         wait_vmcnt<4>();
@@ -184,17 +202,26 @@ __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParam
                 // at barrier s the weight tile of step s + 1 (the first 4 ops of step s - 1) must have landed - the consumers read its first
                 // fragments before barrier s + 1; only the halo pieces issued behind it may still fly.  Steps 0 and NT0 are the first to read
                 // half-buffer 0 / 1 of this tile: everything older has to be there.
-                if constexpr (s == 0 || s == NT0) wait_vmcnt<0>();
+                if constexpr (PL::fresh_halo(s)) wait_vmcnt<0>();
                 else wait_vmcnt<2 * PL::nfill(s - 1)>();
                 __builtin_amdgcn_s_barrier();
                 constexpr Step s2 = PL::at((s + 2) % S);              // (the next tile runs the same convolution: same weights)
                 issue_w(sq, s2.ptap, s2.half);
-                if constexpr (s < NT0) {
+                if constexpr (kDown) {
+                    // the NEXT segment's halo (the other half-buffer): the same view's second channel half, or a new view (of the next tile
+                    // behind the last segment), whose pieces are resolved right before they are issued
+                    constexpr Step sg = PL::at((s | 3) + 1 < S ? (s | 3) + 1 : 0);
 #pragma unroll
-                    for (int j = PL::fill_lo(s); j < PL::fill_hi(s); ++j) issue_fill(1, j);
+                    for (int j = PL::fill_lo(s); j < PL::fill_hi(s); ++j) {
+                        if constexpr (sg.half == 0) resolve_piece((s | 3) + 1 < S ? tile : ntile, j, sg.a, sg.b);
+                        issue_fill(sg.buf, j, sg.half);
+                    }
+                } else if constexpr (s < NT0) {
+#pragma unroll
+                    for (int j = PL::fill_lo(s); j < PL::fill_hi(s); ++j) issue_fill(1, j, 1);
                 } else if constexpr (s >= S - NT3) {
 #pragma unroll
-                    for (int j = PL::fill_lo(s); j < PL::fill_hi(s); ++j) { resolve_piece(ntile, j); issue_fill(0, j); }
+                    for (int j = PL::fill_lo(s); j < PL::fill_hi(s); ++j) { resolve_piece(ntile, j); issue_fill(0, j, 0); }
                 }
                 sq = sq == 2 ? 0 : sq + 1;
             });
@@ -287,9 +314,12 @@ __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParam
             asm volatile("" : "+v"(ml));                                    // (addresses are recomputed per epilogue: hoisted out of the tile loop they cost 16 registers)
             const int m = tile * p.TP + ml;
             const bool live = ml < p.TP && m < p.M;
-            const int srow = div_small(ml, p.inv_w), sx = ml - srow * W;     // its row in the tile and column, low resolution
-            const int orow = 2 * (tile * p.R + srow) + a;                    // row of the output's global row list
-            const unsigned mo = (unsigned)(orow * (2 * W) + 2 * sx + b);
+            unsigned mo = (unsigned)m;                                       // HIGH -> LOW: the low-resolution pixel itself
+            if constexpr (!kDown) {
+                const int srow = div_small(ml, p.inv_w), sx = ml - srow * W;     // its row in the tile and column, low resolution
+                const int orow = 2 * (tile * p.R + srow) + a;                    // row of the output's global row list
+                mo = (unsigned)(orow * (2 * W) + 2 * sx + b);
+            }
             const unsigned row_b = live ? mo * (unsigned)p.out_cstride * ES + (unsigned)((q >> 1) * 8) * ES : kBadOff;
             u32x4 rres[2][2];
             auto load_res = [&](int cp) {
@@ -348,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParam
             constexpr bool post = PL::post_barrier_loads(s);
             constexpr bool pref_next = s + 1 < S && !PL::post_barrier_loads(s + 1);      // next step's addresses + first pixel fragments under this step's last group
             __builtin_amdgcn_s_barrier();
-            if constexpr (post) { addr(si.dy, si.dx); load_px(si.half, 0, 0, 0, 4); }
+            if constexpr (post) { addr(si.dy, si.dx); load_px(si.buf, 0, 0, 0, 4); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g8 = 0; g8 < 8; ++g8) {
@@ -358,13 +388,13 @@ __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParam
                 // first half's last two groups; in the step's last group the next step's addresses, first pixel fragments and first weight
                 // fragments (its weight tile landed at this step's barrier)
                 if (!last) load_wt(st, (g8 + 1) / 4, (g8 + 1) % 4, (g8 + 1) & 1);
-                if (k2 == 0 && pair == 2) load_px(si.half, 1, 1, 0, 2);
-                if (k2 == 0 && pair == 3) load_px(si.half, 1, 1, 2, 4);
+                if (k2 == 0 && pair == 2) load_px(si.buf, 1, 1, 0, 2);
+                if (k2 == 0 && pair == 3) load_px(si.buf, 1, 1, 2, 4);
                 if (last) {
                     st = st == 2 ? 0 : st + 1;
                     if constexpr (pref_next) {
                         constexpr Step sn = PL::at(s + 1 < S ? s + 1 : 0);
-                        addr(sn.dy, sn.dx); load_px(sn.half, 0, 0, 0, 4);
+                        addr(sn.dy, sn.dx); load_px(sn.buf, 0, 0, 0, 4);
                     }
                     load_wt(st, 0, 0, 0);
                 }
@@ -402,13 +432,14 @@ __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParam
     }
 }
 
-// nn.Conv2d weight [Cout][Cin][3][3] fp32 -> the 16 pre-summed 2x2-tap matrices of the sub-pixel form, [4 (2a + b) + 2 ty + tx][Cout][Cin]:
-// parity a = 0 meets low-resolution rows i - 1 (3x3 row 0) and i (rows 1 + 2); parity 1 rows i (rows 0 + 1) and i + 1 (row 2); columns alike.
-// Summed in fp32, rounded once.
-template <typename TF>
-__global__ __launch_bounds__(256) void pack_upsample_kernel(const float* __restrict__ w, TF* __restrict__ wf, int cout, int cin) {
+// nn.Conv2d weight [Cout][Cin][3][3] fp32 -> the 16 pre-summed 2x2-tap matrices of the sub-pixel form, [4 (2a + b) + 2 ty + tx][Cout][Cin] (forward) and
+// their transposes [..][Cin][Cout] (data gradient): parity a = 0 meets low-resolution rows i - 1 (3x3 row 0) and i (rows 1 + 2); parity 1 rows i
+// (rows 0 + 1) and i + 1 (row 2); columns alike.  Summed in fp32, rounded once.
+template <typename TF, typename TD>
+__global__ __launch_bounds__(256) void pack_upsample_kernel(const float* __restrict__ w, TF* __restrict__ wf, TD* __restrict__ wd, int cout, int cin) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= cout * cin) return;
+    const int co = idx / cin, ci = idx - co * cin;
     const float* s = w + (int64_t)idx * 9;
     float v[9];
 #pragma unroll
@@ -426,7 +457,9 @@ __global__ __launch_bounds__(256) void pack_upsample_kernel(const float* __restr
                     float acc = 0.f;
                     for (int y = y0; y <= y1; ++y)
                         for (int x = x0; x <= x1; ++x) acc += v[3 * y + x];
-                    wf[(int64_t)(4 * (2 * a + b) + 2 * ty + tx) * cout * cin + idx] = (TF)acc;
+                    const int64_t pt = 4 * (2 * a + b) + 2 * ty + tx;
+                    if (wf) wf[pt * cout * cin + idx] = (TF)acc;
+                    if (wd) wd[(pt * cin + ci) * cout + co] = (TD)acc;
                 }
 }
 
@@ -447,7 +480,7 @@ static int subpixel_geometry(int B, int H, int W, int cin, int cout, int w_rows,
     if (!gmk_halo_geometry(B, H, W, cin, 0, w_rows, cout, out_cstride, 1, 0, 0, g)) return 0;
     const int64_t lim = 0xFFFF0000ll;
     const int64_t nbo = 4 * g->M * out_cstride * 2, nbw = (int64_t)ntaps * w_rows * cin * 2;
-    if (nbo >= lim || nbw >= lim || 4 * g->M >= 0x7FFFFFFFll / 2) return 0;
+    if (nbo >= lim || nbw >= lim || 4 * g->nb0 >= lim || 4 * g->M >= 0x00FFFFFF) return 0;      // (4 M: pixel indices of the high-resolution tensor, 24 bits)
     g->nbo = nbo; g->nbw = nbw;
     return 1;
 }
@@ -459,12 +492,15 @@ extern "C" int gmk_conv_subpixel_ok(int B, int H, int W, int cin, int cout, int 
     return subpixel_geometry(B, H, W, cin, cout, cout, 16, cout, &g);
 }
 
-extern "C" int gmk_pack_upsample_weight(const float* w, void* w_sub, int cout, int cin, int dtype, void* stream) {
-    GMK_REQUIRE(w && w_sub && cout > 0 && cin > 0, "gmk_pack_upsample_weight: bad arguments");
-    GMK_REQUIRE(gmk_is16(dtype), "gmk_pack_upsample_weight: 16-bit packs only (dtype %d)", dtype);
+extern "C" int gmk_pack_upsample_weight(const float* w, void* w_sub, void* w_sub_dgrad, int cout, int cin, int dtype, int dgrad_dtype, void* stream) {
+    GMK_REQUIRE(w && (w_sub || w_sub_dgrad) && cout > 0 && cin > 0, "gmk_pack_upsample_weight: bad arguments");
+    GMK_REQUIRE(gmk_is16(dtype) && gmk_is16(dgrad_dtype), "gmk_pack_upsample_weight: 16-bit packs only (dtypes %d, %d)", dtype, dgrad_dtype);
     const int blocks = (cout * cin + 255) / 256;
-    if (dtype == GMK_F16) pack_upsample_kernel<f16_t><<<blocks, 256, 0, gmk_stream(stream)>>>(w, (f16_t*)w_sub, cout, cin);
-    else pack_upsample_kernel<bf16_t><<<blocks, 256, 0, gmk_stream(stream)>>>(w, (bf16_t*)w_sub, cout, cin);
+    hipStream_t st = gmk_stream(stream);
+    if (dtype == GMK_F16 && dgrad_dtype == GMK_BF16) pack_upsample_kernel<f16_t, bf16_t><<<blocks, 256, 0, st>>>(w, (f16_t*)w_sub, (bf16_t*)w_sub_dgrad, cout, cin);
+    else if (dtype == GMK_BF16 && dgrad_dtype == GMK_BF16) pack_upsample_kernel<bf16_t, bf16_t><<<blocks, 256, 0, st>>>(w, (bf16_t*)w_sub, (bf16_t*)w_sub_dgrad, cout, cin);
+    else if (dtype == GMK_F16 && dgrad_dtype == GMK_F16) pack_upsample_kernel<f16_t, f16_t><<<blocks, 256, 0, st>>>(w, (f16_t*)w_sub, (f16_t*)w_sub_dgrad, cout, cin);
+    else GMK_REQUIRE(false, "gmk_pack_upsample_weight: forward packs fp16 or bf16, data-gradient packs of the same type or bf16");
     return gmk_check_launch("gmk_pack_upsample_weight");
 }
 
@@ -472,9 +508,10 @@ extern "C" int gmk_conv_subpixel(const void* src, int B, int H, int W, int cin, 
                                  const float* bias, const void* residual, void* out, int out_cstride, int dtype, void* stream) {
     GMK_REQUIRE(src && w && out, "gmk_conv_subpixel: null pointer");
     GMK_REQUIRE(gmk_is16(dtype), "gmk_conv_subpixel: 16-bit types only (dtype %d)", dtype);
-    GMK_REQUIRE(mode == GMK_SUBPIXEL_UPSAMPLE || mode == GMK_SUBPIXEL_TRANSPOSED, "gmk_conv_subpixel: bad mode %d", mode);
+    GMK_REQUIRE(mode == GMK_SUBPIXEL_UPSAMPLE || mode == GMK_SUBPIXEL_TRANSPOSED || mode == GMK_SUBPIXEL_UPSAMPLE_DGRAD, "gmk_conv_subpixel: bad mode %d", mode);
     GMK_REQUIRE(n0 >= 0 && n0 + cout <= w_rows && out_cstride >= cout, "gmk_conv_subpixel: bad output channels n0=%d cout=%d w_rows=%d", n0, cout, w_rows);
-    const int ntaps = mode == GMK_SUBPIXEL_UPSAMPLE ? 16 : 9;
+    const bool down = mode == GMK_SUBPIXEL_UPSAMPLE_DGRAD;
+    const int ntaps = mode == GMK_SUBPIXEL_TRANSPOSED ? 9 : 16;
     HaloGeometry g;
     GMK_REQUIRE(subpixel_geometry(B, H, W, cin, cout, w_rows, ntaps, out_cstride, &g),
                 "gmk_conv_subpixel: shape B=%d %dx%d cin=%d cout=%d is not eligible (ask gmk_conv_subpixel_ok first)", B, H, W, cin, cout);
@@ -482,7 +519,8 @@ extern "C" int gmk_conv_subpixel(const void* src, int B, int H, int W, int cin, 
     p.src = src; p.B = B; p.H = H; p.W = W; p.WE = W + 2; p.R = g.R; p.TP = g.TP; p.ntiles = (int)g.ntiles; p.M = (int)g.M;
     p.w = w; p.w_tap_stride_b = (unsigned)w_rows * (unsigned)cin * 2u; p.n0 = n0;
     p.bias = bias; p.residual = residual; p.out = out; p.out_cstride = out_cstride;
-    p.nb0 = (unsigned)g.nb0; p.nbw = (unsigned)g.nbw; p.nbo = (unsigned)g.nbo;
+    // (H, W) is the LOW-resolution grid in every mode: the source of the LOW -> HIGH forms, the output of the HIGH -> LOW one
+    p.nb0 = (unsigned)(down ? 4 * g.nb0 : g.nb0); p.nbw = (unsigned)g.nbw; p.nbo = (unsigned)(down ? g.nbo / 4 : g.nbo);
     p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 2); p.inv_w = 1.0f / (float)W;
     const int ncu = gmk_cu_limit();
     const dim3 grid((unsigned)(g.ntiles < ncu ? g.ntiles : ncu));
@@ -490,10 +528,13 @@ extern "C" int gmk_conv_subpixel(const void* src, int B, int H, int W, int cin, 
     if (mode == GMK_SUBPIXEL_UPSAMPLE) {
         if (dtype == GMK_F16) conv_subpixel_ws_kernel<f16_t, 0><<<grid, 512, 0, st>>>(p);
         else conv_subpixel_ws_kernel<bf16_t, 0><<<grid, 512, 0, st>>>(p);
-    } else {
+    } else if (mode == GMK_SUBPIXEL_TRANSPOSED) {
         if (dtype == GMK_F16) conv_subpixel_ws_kernel<f16_t, 1><<<grid, 512, 0, st>>>(p);
         else conv_subpixel_ws_kernel<bf16_t, 1><<<grid, 512, 0, st>>>(p);
+    } else {
+        if (dtype == GMK_F16) conv_subpixel_ws_kernel<f16_t, 2><<<grid, 512, 0, st>>>(p);
+        else conv_subpixel_ws_kernel<bf16_t, 2><<<grid, 512, 0, st>>>(p);
     }
-    gmk_note_kernel(mode == GMK_SUBPIXEL_UPSAMPLE ? 8 : 9);
+    gmk_note_kernel(mode == GMK_SUBPIXEL_UPSAMPLE ? 8 : mode == GMK_SUBPIXEL_TRANSPOSED ? 9 : 10);
     return gmk_check_launch("gmk_conv_subpixel");
 }

@@ -276,9 +276,26 @@ class SimpleUnet(nn.Module):
     def _upsample_conv(self, name, x, out_hw):
         """`Upsample` (simple_unet.py:112-122): nearest x2 + 3x3 convolution.  Sub-pixel form (four 2x2-tap parities of the low-resolution tensor on
         pre-summed weights, gmk_conv_subpixel) where the kernel takes the shape; else the nearest-x2 addressing of the stride-1 kernels."""
-        if self._up_packs is not None and ops.conv_subpixel_ok(x):
-            return ops.conv_subpixel(x, self._up_packs[name], self.channels, ops.SUBPIXEL_UPSAMPLE, bias=self._pv[name + ".bias"])
+        B, H, W, c = x.shape
+        if self._up_packs is not None and ops.conv_subpixel_ok(B, H, W, c, x.dtype):
+            return ops.conv_subpixel(x, self._up_packs[name][0], self.channels, ops.SUBPIXEL_UPSAMPLE, bias=self._pv[name + ".bias"])
         return self._conv([x], self._packs[name][0], self.channels, 3, ops.UPSAMPLE2, out_hw, bias=self._pv[name + ".bias"], gn_stats=True)
+
+    def _upsample_wgrad(self, name, dy, x):
+        """Weight gradient of `Upsample` on the side stream: the sub-pixel slot correlation where the kernel takes the shape."""
+        B, H, W, c = x.shape
+        dw = self._gv[name + ".weight"]
+        if self._up_packs is not None and ops.conv_wgrad_subpixel_ok(B, H, W, c, dy.dtype):
+            self._on_side(lambda: ops.conv_wgrad_subpixel(dy, x, dw), (dy, x))
+            return dw
+        return self._wgrad(dy, [x], 3, ops.UPSAMPLE2, dw)
+
+    def _upsample_dgrad(self, name, dy):
+        """Data gradient of `Upsample`: sumpool2x2(dgrad3x3(dy)) - one launch in the sub-pixel form (no high-resolution intermediate), else two."""
+        B, H, W, c = dy.shape
+        if self._up_packs is not None and ops.conv_subpixel_ok(B, H // 2, W // 2, c, dy.dtype):
+            return ops.conv_subpixel(dy, self._up_packs[name][1], self.channels, ops.SUBPIXEL_UPSAMPLE_DGRAD)
+        return ops.sumpool2x2(self._conv([dy], self._packs[name][1], self.channels, 3, ops.NORMAL, (H, W)))
 
     def mark_params_changed(self):
         self._packs_stale = True
@@ -340,10 +357,11 @@ class SimpleUnet(nn.Module):
         ops.pack_conv_weights_multi(self.flat_params, self._pack_buf, self._pack_table, self._pack_f16)      # all convolutions, one launch
         # the two `Upsample` convolutions (simple_unet.py:112-122) also get the pack of their sub-pixel form: 16 pre-summed 2x2-tap matrices
         if self.channels == 128 and self.compute_dtype == torch.bfloat16:
-            if self._up_packs is None:
-                self._up_packs = {n: torch.empty(16 * 128 * 128, device=dev, dtype=self.act_dtype) for n in ("up.seq.0.1.conv", "up.seq.3.1.conv")}
-            for n, buf in self._up_packs.items():
-                ops.pack_upsample_weight(self._pv[n + ".weight"], buf)
+            if self._up_packs is None:      # (forward pack in the activation type, data-gradient pack in the gradient type)
+                self._up_packs = {n: (torch.empty(16 * 128 * 128, device=dev, dtype=self.act_dtype),
+                                      torch.empty(16 * 128 * 128, device=dev, dtype=self.compute_dtype)) for n in ("up.seq.0.1.conv", "up.seq.3.1.conv")}
+            for n, (bf, bd) in self._up_packs.items():
+                ops.pack_upsample_weight(self._pv[n + ".weight"], bf, bd)
         self._packs_stale = False
         self._packed_version = self._version_sum()
 
@@ -741,17 +759,15 @@ class SimpleUnet(nn.Module):
         ready(0)
         # up.seq.3.1: nearest x2 + conv
         ops.colsum(s3, G["up.seq.3.1.conv.bias"], defer=True)
-        self._wgrad(du3, [u3r], 3, ops.UPSAMPLE2, G["up.seq.3.1.conv.weight"])
-        dU = self._conv([du3], self._packs["up.seq.3.1.conv"][1], C, 3, ops.NORMAL, (H, W))
-        du3r = ops.sumpool2x2(dU)
+        self._upsample_wgrad("up.seq.3.1.conv", du3, u3r)
+        du3r = self._upsample_dgrad("up.seq.3.1.conv", du3)
         s3r = ops.chansum(du3r)
         (du2, s2), (dt3a, _) = self._res_bwd("up.seq.3.0", ctx, du3r, s3r, demb_all, 8)
         (du1, s1), (dt4a, _) = self._res_bwd("up.seq.2", ctx, du2, s2, demb_all, 7)
         (du0, s0), (dt5a, _) = self._res_bwd("up.seq.1", ctx, du1, s1, demb_all, 6)
         ops.colsum(s0, G["up.seq.0.1.conv.bias"], defer=True)
-        self._wgrad(du0, [u0r], 3, ops.UPSAMPLE2, G["up.seq.0.1.conv.weight"])
-        dU = self._conv([du0], self._packs["up.seq.0.1.conv"][1], C, 3, ops.NORMAL, (H2, W2))
-        du0r = ops.sumpool2x2(dU)
+        self._upsample_wgrad("up.seq.0.1.conv", du0, u0r)
+        du0r = self._upsample_dgrad("up.seq.0.1.conv", du0)
         s0r = ops.chansum(du0r)
         (dt7, s7), (dt6a, _) = self._res_bwd("up.seq.0.0", ctx, du0r, s0r, demb_all, 5)
         if self.attention:

@@ -23,7 +23,7 @@ PROFILE = None
 
 
 KERNEL_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_dma_kernel", 3: "conv3x3_halo_kernel", 4: "conv3x3_halo_ws_kernel", 11: "conv_wgrad_kernel",
-                12: "conv_wgrad_slots_kernel", 13: "conv_wgrad_slots_ws_kernel", 14: "conv1x1_pair_stream_kernel", 15: "conv1x1_wgrad_stream_kernel",
+                12: "conv_wgrad_slots_kernel", 13: "conv_wgrad_slots_ws_kernel", 16: "conv_wgrad_subpixel_ws_kernel", 14: "conv1x1_pair_stream_kernel", 15: "conv1x1_wgrad_stream_kernel",
                 # same binary as 4, launched on the zero-stuffed gradient of a stride-2 conv: 4x the algorithmic MFMA work by
                 # construction, so the profile keeps it apart from the plain 3x3 convolutions
                 5: "conv3x3_halo_ws_kernel[zero-stuffed transposed conv]",
@@ -32,7 +32,7 @@ KERNEL_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_dma_kernel", 3: "conv3x3_
                 # stride-2 data gradient where the halo kernel declines (fp32, small problems): four output-parity phase launches of the LDS-DMA kernel
                 6: "conv_igemm_dma_kernel[stride-2 dgrad phases]",
                 # sub-pixel (output-parity) forms: `Upsample` as four 2x2-tap parities on pre-summed weights, the stride-2 data gradient as 1 / 2 / 2 / 4 taps
-                8: "conv_subpixel_ws_kernel[upsample]", 9: "conv_subpixel_ws_kernel[transposed]",
+                8: "conv_subpixel_ws_kernel[upsample]", 9: "conv_subpixel_ws_kernel[transposed]", 10: "conv_subpixel_ws_kernel[upsample dgrad]",
                 21: "gn_silu_fwd_reg_kernel", 22: "gn_silu_fwd_kernel", 23: "gn_silu_bwd_hybrid_kernel", 24: "gn_silu_bwd_kernel"}
 
 
@@ -391,43 +391,51 @@ def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, 
     return out
 
 
-SUBPIXEL_UPSAMPLE, SUBPIXEL_TRANSPOSED = 0, 1
+SUBPIXEL_UPSAMPLE, SUBPIXEL_TRANSPOSED, SUBPIXEL_UPSAMPLE_DGRAD = 0, 1, 2
 
 
-def conv_subpixel_ok(src, cout=128):
-    """True if the x2 resampling convolutions of a low-resolution NHWC `src` run in their sub-pixel form (gmk_conv_subpixel)."""
-    if src.dtype not in _HALF:
-        return False
-    B, H, W, c = src.shape
-    return bool(lib.gmk_conv_subpixel_ok(B, H, W, c, cout, _DT[src.dtype]))
+def conv_subpixel_ok(B, H, W, c, dtype, cout=128):
+    """True if the x2 resampling convolutions over the LOW-resolution grid B x H x W run in their sub-pixel form (gmk_conv_subpixel)."""
+    return dtype in _HALF and bool(lib.gmk_conv_subpixel_ok(B, H, W, c, cout, _DT[dtype]))
 
 
-def pack_upsample_weight(w, out):
-    """w: fp32 [Cout][Cin][3][3] (a contiguous arena view) -> out: 16 x Cout x Cin elements of out.dtype, the pre-summed 2x2-tap matrices of
-    the sub-pixel `Upsample` (reference simple_unet.py:112-122)."""
+def pack_upsample_weight(w, out, out_dgrad=None):
+    """w: fp32 [Cout][Cin][3][3] (a contiguous arena view) -> out: 16 x Cout x Cin elements, the pre-summed 2x2-tap matrices of the sub-pixel
+    `Upsample` (reference simple_unet.py:112-122); out_dgrad: their transposes [16][Cin][Cout] for its data gradient.  Either may be None."""
     _f32(w, "w")
     cout, cin = w.shape[0], w.shape[1]
-    assert w.shape[2:] == (3, 3) and w.is_contiguous() and out.numel() == 16 * cout * cin and out.dtype in _HALF
-    _chk(out, name="out")
-    check(lib.gmk_pack_upsample_weight(_p(w), _p(out), cout, cin, _DT[out.dtype], _s()), "pack_upsample_weight")
+    assert w.shape[2:] == (3, 3) and w.is_contiguous()
+    for t in (out, out_dgrad):
+        if t is not None:
+            _chk(t, name="pack"); assert t.numel() == 16 * cout * cin and t.dtype in _HALF
+    ref = out if out is not None else out_dgrad
+    check(lib.gmk_pack_upsample_weight(_p(w), _p(out), _p(out_dgrad), cout, cin, _DT[ref.dtype],
+                                       _DT[(out_dgrad if out_dgrad is not None else ref).dtype], _s()), "pack_upsample_weight")
     return out
 
 
 def conv_subpixel(src, w, w_rows, mode, bias=None, residual=None, n0=0, cout=128):
-    """Low-resolution NHWC src [B,H,W,128] -> [B,2H,2W,cout]: SUBPIXEL_UPSAMPLE = conv3x3(nearest x2 (src)) with the pack of
-    pack_upsample_weight, SUBPIXEL_TRANSPOSED = the data gradient of a 3x3 stride-2 convolution with its ordinary data-gradient pack."""
+    """SUBPIXEL_UPSAMPLE: low-resolution NHWC src [B,H,W,128] -> conv3x3(nearest x2 (src)) [B,2H,2W,cout], w = the forward pack of
+    pack_upsample_weight.  SUBPIXEL_TRANSPOSED: the data gradient of a 3x3 stride-2 convolution (src = its output gradient, w = its ordinary
+    data-gradient pack) -> [B,2H,2W,cout].  SUBPIXEL_UPSAMPLE_DGRAD: src = the HIGH-resolution output gradient [B,2H,2W,128] of the upsampled
+    convolution -> its input gradient [B,H,W,cout] (w = the out_dgrad pack): sumpool2x2(dgrad3x3(src)) in one launch."""
     s0 = _chk(src, name="src")
     B, H, W, c = s0.shape
+    down = mode == SUBPIXEL_UPSAMPLE_DGRAD
+    if down:
+        assert H % 2 == 0 and W % 2 == 0
+        H, W = H // 2, W // 2                  # the C ABI takes the LOW-resolution grid in every mode
     _chk(w, s0.dtype, "w")
-    taps = 16 if mode == SUBPIXEL_UPSAMPLE else 9
+    taps = 9 if mode == SUBPIXEL_TRANSPOSED else 16
     assert w.numel() == taps * w_rows * c, (w.numel(), taps, w_rows, c)
-    out = torch.empty((B, 2 * H, 2 * W, cout), device=s0.device, dtype=s0.dtype)
+    out = torch.empty((B, H, W, cout) if down else (B, 2 * H, 2 * W, cout), device=s0.device, dtype=s0.dtype)
     if bias is not None:
         _f32(bias, "bias"); assert bias.numel() == cout
     if residual is not None:
         _chk(residual, s0.dtype, "residual"); assert residual.shape == out.shape
-    # algorithmic work: that of the reference's op (9 taps per OUTPUT pixel for the upsampled convolution, 9 per SOURCE pixel for the transposed one)
-    mpix = B * 4 * H * W if mode == SUBPIXEL_UPSAMPLE else B * H * W
+    # algorithmic work: that of the reference's op (9 taps per HIGH-resolution pixel for the upsampled convolution and its data gradient,
+    # 9 per LOW-resolution pixel for the transposed one)
+    mpix = B * H * W if mode == SUBPIXEL_TRANSPOSED else B * 4 * H * W
     with _Timed("conv_subpixel", 2.0 * mpix * cout * c * 9, _nbytes(s0, residual, out)):
         check(lib.gmk_conv_subpixel(_p(s0), B, H, W, c, _p(w), w_rows, n0, cout, mode, _p(bias), _p(residual), _p(out), cout,
                                     _DT[s0.dtype], _s()), "conv_subpixel")
@@ -504,6 +512,30 @@ def conv_wgrad(dy, srcs, ksize, mode, dw):
     with _Timed("conv_wgrad", 2.0 * B * ho * wo * cout * (c0 + c1) * ksize * ksize, _nbytes(dy, s0, s1)):
         check(lib.gmk_conv_wgrad(_p(dy), cout, _p(s0), _p(s1), c0, c1, B, hs, ws_, ho, wo, ksize, mode, _p(dw), cout,
                                  _p(wsbuf), wsbuf.numel(), _DT[dy.dtype], _DT[s0.dtype], _s()), "conv_wgrad")
+    return dw
+
+
+def conv_wgrad_subpixel_ok(B, H, W, c, dy_dtype, cout=128):
+    """True if the weight gradient of `Upsample` over the LOW-resolution grid B x H x W runs in its sub-pixel form (gmk_conv_wgrad_subpixel)."""
+    return dy_dtype == torch.bfloat16 and bool(lib.gmk_conv_wgrad_subpixel_ok(B, H, W, c, cout))
+
+
+def conv_wgrad_subpixel(dy, x, dw):
+    """dw (fp32 [cout][cin][3][3], a contiguous arena view) = weight gradient of conv3x3(nearest x2 (x)) given the high-resolution output
+    gradient dy [B,2H,2W,cout] (bf16) and the saved low-resolution input x [B,H,W,cin] (bf16 / fp16)."""
+    _chk(dy, torch.bfloat16, "dy")
+    _chk(x, name="x")
+    assert x.dtype in _HALF
+    B, H, W, cin = x.shape
+    cout = dy.shape[3]
+    assert dy.shape == (B, 2 * H, 2 * W, cout)
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * cin * 9
+    need = lib.gmk_conv_wgrad_subpixel_workspace_bytes(B, H, W, cin, cout)
+    assert need > 0
+    wsbuf = _workspace(need, dy.device)
+    with _Timed("conv_wgrad", 2.0 * B * 4 * H * W * cout * cin * 9, _nbytes(dy, x)):
+        check(lib.gmk_conv_wgrad_subpixel(_p(dy), cout, _p(x), B, H, W, cin, cout, _p(dw), _p(wsbuf), wsbuf.numel(), _DT[dy.dtype],
+                                          _DT[x.dtype], _s()), "conv_wgrad_subpixel")
     return dw
 
 

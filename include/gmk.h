@@ -35,8 +35,8 @@ extern "C" {
 int gmk_version(void);
 const char* gmk_last_error(void);
 /* profiling aid: which kernel the calling thread's last gmk_conv_igemm / gmk_conv_wgrad / gmk_gn_* call launched
- * (1 conv_igemm_kernel, 2 conv_igemm_dma_kernel, 3 conv3x3_halo_kernel, 4 conv3x3_halo_ws_kernel, 7 conv3x3_halo_ws_kernel with the folded 1x1 skip convolution, 8 / 9 conv_subpixel_ws_kernel (upsample / transposed), 5 a halo kernel on the zero-stuffed source of GMK_CONV_TRANSPOSED2 (GMK_CONV_KERNEL=3), 6 the four parity-phase launches of the LDS-DMA kernel for GMK_CONV_TRANSPOSED2, 11 conv_wgrad_kernel,
- * 12 conv_wgrad_slots_kernel, 13 conv_wgrad_slots_ws_kernel, 14 conv1x1_pair_stream_kernel, 15 conv1x1_wgrad_stream_kernel, 21 gn_silu_fwd_reg_kernel, 22 gn_silu_fwd_kernel, 23 gn_silu_bwd_hybrid_kernel, 24 gn_silu_bwd_kernel) */
+ * (1 conv_igemm_kernel, 2 conv_igemm_dma_kernel, 3 conv3x3_halo_kernel, 4 conv3x3_halo_ws_kernel, 7 conv3x3_halo_ws_kernel with the folded 1x1 skip convolution, 8 / 9 / 10 conv_subpixel_ws_kernel (upsample / transposed / upsample data gradient), 5 a halo kernel on the zero-stuffed source of GMK_CONV_TRANSPOSED2 (GMK_CONV_KERNEL=3), 6 the four parity-phase launches of the LDS-DMA kernel for GMK_CONV_TRANSPOSED2, 11 conv_wgrad_kernel,
+ * 12 conv_wgrad_slots_kernel, 13 conv_wgrad_slots_ws_kernel, 16 conv_wgrad_subpixel_ws_kernel, 14 conv1x1_pair_stream_kernel, 15 conv1x1_wgrad_stream_kernel, 21 gn_silu_fwd_reg_kernel, 22 gn_silu_fwd_kernel, 23 gn_silu_bwd_hybrid_kernel, 24 gn_silu_bwd_kernel) */
 int gmk_last_kernel(void);
 /* development aid: force kernel variants (0 = automatic; see GMK_CONV_KERNEL / GMK_WGRAD_KERNEL / GMK_GN_KERNEL); -1 = unset */
 int gmk_set_kernel_choice(int conv, int wgrad, int gn);
@@ -158,13 +158,29 @@ int gmk_conv3x3_skipfold(const void* src, int c0, int B, int H, int W, const voi
  *                            w_dgrad pack `[9][w_rows][cin]` of gmk_pack_conv_weight; parities meet 1 / 2 / 2 / 4 of its taps (the same products
  *                            in the same order as gmk_conv_igemm(GMK_CONV_TRANSPOSED2) on the zero-stuffed gradient, minus its 27 of 36 multiplications by zero)
  * bias / residual (NHWC, the output's shape) optional.  16-bit types, cin = cout = 128, shapes where gmk_conv_subpixel_ok(...) returns 1; otherwise
- * the call fails (callers fall back to gmk_conv_igemm).  GMK_SUBPIXEL=0 in the environment makes gmk_conv_subpixel_ok answer 0 (A/B switch). */
+ * the call fails (callers fall back to gmk_conv_igemm).  GMK_SUBPIXEL=0 in the environment makes gmk_conv_subpixel_ok answer 0 (A/B switch).
+ *   GMK_SUBPIXEL_UPSAMPLE_DGRAD  the data gradient of `Upsample` - HIGH -> LOW: src is the output gradient [B][2H][2W][cin], out [B][H][W][cout] =
+ *                            sumpool2x2(dgrad3x3(src)) of the reference's autograd in ONE launch: the transpose of the sub-pixel forward, 16 tap-products
+ *                            per low-resolution pixel over the four parity views of src; w = the w_sub_dgrad pack of gmk_pack_upsample_weight
+ *                            (`[16][w_rows = Cin of the convolution][Cout]`); (H, W) is the LOW-resolution grid in every mode
+ * gmk_pack_upsample_weight: w fp32 [Cout][Cin][3][3] -> w_sub (forward, `dtype`) and / or w_sub_dgrad (`dgrad_dtype`), either may be NULL. */
 #define GMK_SUBPIXEL_UPSAMPLE 0
 #define GMK_SUBPIXEL_TRANSPOSED 1
+#define GMK_SUBPIXEL_UPSAMPLE_DGRAD 2
 int gmk_conv_subpixel_ok(int B, int H, int W, int cin, int cout, int dtype);
-int gmk_pack_upsample_weight(const float* w, void* w_sub, int cout, int cin, int dtype, void* stream);
+int gmk_pack_upsample_weight(const float* w, void* w_sub, void* w_sub_dgrad, int cout, int cin, int dtype, int dgrad_dtype, void* stream);
 int gmk_conv_subpixel(const void* src, int B, int H, int W, int cin, const void* w, int w_rows, int n0, int cout, int mode,
                       const float* bias, const void* residual, void* out, int out_cstride, int dtype, void* stream);
+/* Weight gradient of `Upsample` (simple_unet.py:112-122) in the sub-pixel form: dy = the HIGH-resolution output gradient [B][2H][2W][dy_cstride]
+ * (bf16), x = the saved LOW-resolution input [B][H][W][cin] (bf16, or fp16 re-rounded to bf16 on its way into LDS), dw = the reference's
+ * [Cout][Cin][3][3] fp32 (overwritten).  The 16 tap gradients of the pre-summed 2x2-tap matrices are accumulated over the low-resolution slots
+ * (16 tap-products per low-resolution pixel; gmk_conv_wgrad(GMK_CONV_UPSAMPLE2) multiplies 36) and folded onto the 9 taps by a deterministic
+ * two-stage reduce.  cin = cout = 128, W <= 62, where gmk_conv_wgrad_subpixel_ok(...) returns 1 (GMK_SUBPIXEL=0 / GMK_WGRAD_KERNEL != 0: never);
+ * workspace: gmk_conv_wgrad_subpixel_workspace_bytes(...) bytes. */
+int gmk_conv_wgrad_subpixel_ok(int B, int H, int W, int cin, int cout);
+int64_t gmk_conv_wgrad_subpixel_workspace_bytes(int B, int H, int W, int cin, int cout);
+int gmk_conv_wgrad_subpixel(const void* dy, int dy_cstride, const void* x, int B, int H, int W, int cin, int cout, float* dw,
+                            void* workspace, int64_t workspace_bytes, int dtype, int x_dtype, void* stream);
 /* statistics-only GroupNorm for the above: mean / rstd [B][groups] and the affine tables (columns [0, C) of rows of tab_stride
  * floats: a concatenated input passes the same table with a column offset); xadd as in gmk_gn_silu_fwd */
 int gmk_gn_stats(const void* x, const float* gamma, const float* beta, float* mean, float* rstd, float* tab_scale,

@@ -420,7 +420,7 @@ def test_transposed_dgrad_as_four_phases(ops, dtype, S, B, res):
     rd = nhwc(r, dtype) if res else None
     ref = x.grad + (r if res else 0)
     dx0 = ops.conv_igemm([dyd], wd, C, 3, ops.TRANSPOSED2, (S, S), residual=rd)       # automatic choice
-    assert lib.gmk_last_kernel() == 6 if dtype == torch.float32 else lib.gmk_last_kernel() in (5, 6)
+    assert lib.gmk_last_kernel() == 6 if dtype == torch.float32 else lib.gmk_last_kernel() in (5, 6, 9)      # (9: the sub-pixel form, round 5)
     assert rel_err(nchw(dx0), ref) < TOL[dtype]
     try:
         lib.gmk_set_kernel_choice(2, -1, -1)
@@ -757,9 +757,10 @@ def test_upsample_conv_subpixel(ops, dtype, S, B):
     bias = rnd(C, seed=302) * 0.1
     ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, bias, padding=1)
     xd = nhwc(x, dtype)
-    assert ops.conv_subpixel_ok(xd)
+    assert ops.conv_subpixel_ok(B, S, S, C, dtype)
     wsub = torch.empty(16 * C * C, device="cuda", dtype=dtype)
-    ops.pack_upsample_weight(w.cuda(), wsub)
+    wsub_d = torch.empty(16 * C * C, device="cuda", dtype=torch.bfloat16)
+    ops.pack_upsample_weight(w.cuda(), wsub, wsub_d)
     # the pack itself: [4 (2a + b) + 2 ty + tx][cout][cin] = fp32 sums of the 3x3 taps that meet one low-resolution pixel, rounded once
     rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
     pk = wsub.float().cpu().view(2, 2, 2, 2, C, C)
@@ -769,6 +770,7 @@ def test_upsample_conv_subpixel(ops, dtype, S, B):
                 for tx in range(2):
                     want = sum(w[:, :, y, x_] for y in rows[a][ty] for x_ in rows[b][tx])
                     assert torch.equal(pk[a, b, ty, tx], q(want, dtype))
+                    assert torch.equal(wsub_d.float().cpu().view(2, 2, 2, 2, C, C)[a, b, ty, tx], q(want, torch.bfloat16).t())
     out = ops.conv_subpixel(xd, wsub, C, ops.SUBPIXEL_UPSAMPLE, bias=bias.cuda())
     assert lib.gmk_last_kernel() == 8 and out.shape == (B, 2 * S, 2 * S, C)
     e = rel_err(nchw(out), ref)
@@ -803,7 +805,7 @@ def test_transposed_dgrad_subpixel(ops, dtype, S, B, res):
     ops.pack_conv_weight(w.detach().cuda(), wf, wd)
     dyd = nhwc(dy, dtype)
     rd = nhwc(r, dtype) if res else None
-    assert ops.conv_subpixel_ok(dyd)
+    assert ops.conv_subpixel_ok(B, S, S, C, dtype)
     dx = ops.conv_subpixel(dyd, wd, C, ops.SUBPIXEL_TRANSPOSED, residual=rd)
     assert lib.gmk_last_kernel() == 9
     assert rel_err(nchw(dx), ref) < TOL[torch.bfloat16]
@@ -818,3 +820,70 @@ def test_transposed_dgrad_subpixel(ops, dtype, S, B, res):
     # through the dispatcher: gmk_conv_igemm(GMK_CONV_TRANSPOSED2) takes the sub-pixel form where it is eligible
     dx_auto = ops.conv_igemm([dyd], wd, C, 3, ops.TRANSPOSED2, (2 * S, 2 * S), residual=rd)
     assert lib.gmk_last_kernel() == 9 and torch.equal(dx_auto, dx)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("S,B", SUBPIXEL_SHAPES)
+def test_upsample_dgrad_subpixel(ops, dtype, S, B):
+    """Data gradient of `Upsample` (reference simple_unet.py:112-122; autograd: dgrad of the 3x3 convolution at the high resolution, then the 2x2
+    sum-pool that is the backward of F.interpolate(nearest)) as ONE launch: the transpose of the sub-pixel forward - the four parity views of the
+    output gradient, 2x2 taps each on the transposed pre-summed matrices, accumulated in fp32 and rounded once.  Against autograd in fp32 on the rounded
+    gradient and fp32 weights, and against the two launches it replaces (which round the high-resolution intermediate to 16 bits before the pool)."""
+    from generative_models_amd._lib import lib
+    C = 128
+    x = rnd(B, C, S, S, seed=320).requires_grad_(True)
+    w = rnd(C, C, 3, 3, seed=321) / math.sqrt(C * 9)
+    out = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, None, padding=1)
+    dy = q(rnd(*out.shape, seed=322), dtype)
+    out.backward(dy)
+    dyd = nhwc(dy, dtype)
+    wsub_d = torch.empty(16 * C * C, device="cuda", dtype=dtype)
+    ops.pack_upsample_weight(w.cuda(), None, wsub_d)
+    assert ops.conv_subpixel_ok(B, S, S, C, dtype)
+    dx = ops.conv_subpixel(dyd, wsub_d, C, ops.SUBPIXEL_UPSAMPLE_DGRAD)
+    assert lib.gmk_last_kernel() == 10 and dx.shape == (B, S, S, C)
+    e = rel_err(nchw(dx), x.grad)
+    assert e < TOL[torch.bfloat16], e
+    if dtype == torch.bfloat16:            # (gradients are bf16 in the product; the pooling kernel has no fp16 form)
+        wf = torch.empty(w.numel(), device="cuda", dtype=dtype); wd = torch.empty_like(wf)
+        ops.pack_conv_weight(w.cuda(), wf, wd)
+        old = ops.sumpool2x2(ops.conv_igemm([dyd], wd, C, 3, ops.NORMAL, (2 * S, 2 * S)))
+        e_old = rel_err(nchw(old), x.grad)
+        ulp = 2.0 ** -7
+        assert e <= e_old + 0.5 * ulp, (e, e_old)                   # one rounding instead of two: not worse than the pair it replaces
+        assert rel_err(nchw(dx), nchw(old)) < 4 * ulp
+    assert torch.equal(dx, ops.conv_subpixel(dyd, wsub_d, C, ops.SUBPIXEL_UPSAMPLE_DGRAD))
+
+
+@pytest.mark.parametrize("xdt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("S,B", [(16, 300), (16, 2048), (8, 1100), (14, 400), (7, 1024), (32, 70), (16, 3)])
+def test_upsample_wgrad_subpixel(ops, xdt, S, B):
+    """Weight gradient of `Upsample` (reference simple_unet.py:112-122) in the sub-pixel form: the 16 tap gradients of the pre-summed 2x2-tap
+    matrices accumulated over the LOW-resolution slots (two dY parity streams and eight accumulators per workgroup), folded onto the 9 taps by a
+    deterministic reduce.  Against autograd in fp32 on the rounded operands, against the nearest-x2 slot kernel it replaces (the same products,
+    other summation order), bit-reproducible; small problems (too few slot chunks per split) are declined."""
+    from generative_models_amd._lib import lib
+    C = 128
+    x = q(rnd(B, C, S, S, seed=330), xdt)
+    w = (rnd(C, C, 3, 3, seed=331) / math.sqrt(C * 9)).requires_grad_(True)
+    out = F.conv2d(F.interpolate(q(x, torch.bfloat16), scale_factor=2, mode="nearest"), w, None, padding=1)      # the kernels multiply bf16(x)
+    dy = q(rnd(*out.shape, seed=332), torch.bfloat16)
+    out.backward(dy)
+    xd, dyd = nhwc(x, xdt), nhwc(dy, torch.bfloat16)
+    ok = ops.conv_wgrad_subpixel_ok(B, S, S, C, torch.bfloat16)
+    if (S, B) == (16, 3):
+        assert not ok
+        return
+    assert ok
+    dw = torch.empty((C, C, 3, 3), device="cuda")
+    ops.conv_wgrad_subpixel(dyd, xd, dw)
+    assert lib.gmk_last_kernel() == 16
+    e = rel_err(dw, w.grad)
+    assert e < TOL[torch.bfloat16], e
+    dw_old = torch.empty_like(dw)
+    ops.conv_wgrad(dyd, [xd], 3, ops.UPSAMPLE2, dw_old)
+    assert rel_err(dw, dw_old) < 1e-4, rel_err(dw, dw_old)            # the same bf16 x bf16 products, fp32 sums in another order
+    assert e <= rel_err(dw_old, w.grad) + 1e-4
+    dw2 = torch.empty_like(dw)
+    ops.conv_wgrad_subpixel(dyd, xd, dw2)
+    assert torch.equal(dw, dw2)

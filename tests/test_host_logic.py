@@ -575,21 +575,20 @@ def _regs(operand_text):
     return out
 
 
-def test_wgrad_register_loads_stay_untouched_while_in_flight():
-    """The advisor's medium finding of round 3 (csrc/conv_wgrad_slots.hip, kXF16 producers): the fp16 activation chunks arrive by inline-asm
-    `buffer_load_dwordx4` into C++ variables and are retired only by a hand-counted `s_waitcnt vmcnt(12)` three steps later - the compiler
-    believes the registers are defined when the asm statement ends, so a copy, phi move or spill of a set before the wait would read stale
-    VGPRs.  This checks the COMPILED kernels mechanically, over the control-flow graph, for every kXF16 instance:
+def _check_register_loads_in_flight(src, name_regex, n_instances, vm_per_step, min_consumed):
+    """Mechanical check of COMPILED kernels whose producer waves keep inline-asm `buffer_load_dwordx4` results in C++ variables across barriers,
+    retired only by a hand-counted `s_waitcnt vmcnt(N)` steps later (the compiler believes the registers are defined when the asm statement
+    ends, so a copy, phi move or spill of a set before the wait would read stale VGPRs).  Over the control-flow graph of every instance:
       * no scratch memory, no VGPR / SGPR spills;
       * on EVERY path from a register load, no instruction reads or writes its destination registers while the load may still be in flight
         (in-order vmcnt: it has retired once a `vmcnt(N)` is crossed with at least N younger VMEM operations issued), and the first
-        instruction that does read them is their consumer - the fp16 -> fp32 conversion of an activation chunk, the `ds_write_b128` of a dY
-        chunk (round 4: dY takes the same register pipeline);
-      * between two barriers of the steady-state loop exactly four VMEM operations are issued on every path (the literal 12 = 4 x 3 steps)."""
-    L = _device_asm("conv_wgrad_slots.hip")
+        instruction that does read them is their consumer - the fp16 -> fp32 conversion of an activation chunk, or a `ds_write_b128`;
+      * between two barriers of the steady-state loop exactly `vm_per_step` VMEM operations are issued on every path (the wait literal is
+        vm_per_step x 3 steps)."""
+    L = _device_asm(src)
     text = "\n".join(L)
-    names = sorted(set(re.findall(r"^(_ZN\S*conv_wgrad_slots_ws_kernelILi\dELb1ELb[01]E\S*):", text, flags=re.M)))
-    assert len(names) == 4, names                                   # LOOK in {1, 2} x kShare in {0, 1}, all with kXF16 = true
+    names = sorted(set(re.findall(r"^(_ZN\S*%s\S*):" % name_regex, text, flags=re.M)))
+    assert len(names) == n_instances, names
     is_reg_load = lambda t: t.startswith("buffer_load_dwordx4 v[") and " lds" not in t
     is_vmem = lambda t: re.match(r"(buffer|global|flat)_(load|store|atomic)", t) is not None
     for name in names:
@@ -653,7 +652,7 @@ def test_wgrad_register_loads_stay_untouched_while_in_flight():
             return [(k + 1, known)] if k + 1 < len(ins) else []
 
         loads = [k for k, t in enumerate(ins) if is_reg_load(t)]
-        assert len(loads) >= 8, (name, len(loads))
+        assert len(loads) >= 2 * vm_per_step, (name, len(loads))
         consumed = 0
         for k0 in loads:
             dest = _regs(ins[k0].split(",")[0])
@@ -693,8 +692,8 @@ def test_wgrad_register_loads_stay_untouched_while_in_flight():
                     parent.setdefault(nxt_st, st)
                     stack.append(nxt_st)
             consumed += hit
-        assert consumed >= 16, (name, consumed)                 # the steady-state loads (8 activation + 8 dY per 4 unrolled steps) all reach their consumer
-        # four VMEM operations between two barriers of the steady-state loop, on every path
+        assert consumed >= min_consumed, (name, consumed)       # the steady-state loads of the 4 unrolled steps all reach their consumer
+        # vm_per_step VMEM operations between two barriers of the steady-state loop, on every path
         bars = [k for k, t in enumerate(ins) if t == "s_barrier"]
 
         def to_next_barrier(b):
@@ -713,9 +712,21 @@ def test_wgrad_register_loads_stay_untouched_while_in_flight():
         cyc = [b for b in bars if any(b in {k for k, _ in nxt[c]} for c in bars if c != b) and nxt[b]]      # barriers inside the loop
         steady = [b for b in cyc if all(k in cyc for k, _ in nxt[b])]
         assert len(steady) >= 4, (name, steady)
-        loop_loads = set(loads[-8:])
+        loop_loads = set(loads[-2 * vm_per_step:])
         for b in steady:
             counts = {n for _, n in nxt[b]}
             # (the prologue's barrier-free issue blocks are not in `steady`: every one of these barriers is followed by another loop barrier)
             if any(ins[k] for k in range(b, min(b + 400, len(ins))) if k in loop_loads):
-                assert counts == {4}, (name, b, counts)
+                assert counts == {vm_per_step}, (name, b, counts)
+
+
+def test_wgrad_register_loads_stay_untouched_while_in_flight():
+    """The advisor's medium finding of round 3 (csrc/conv_wgrad_slots.hip, kXF16 producers: activation AND dY chunks through registers since
+    round 4; four VMEM operations per step, `vmcnt(12)`): LOOK in {1, 2} x kShare in {0, 1}, all with kXF16 = true."""
+    _check_register_loads_in_flight("conv_wgrad_slots.hip", r"conv_wgrad_slots_ws_kernelILi\dELb1ELb[01]E", 4, 4, 16)
+
+
+def test_subpixel_wgrad_register_loads_stay_untouched_while_in_flight():
+    """The same guard for the sub-pixel `Upsample` weight gradient (csrc/conv_wgrad_subpixel.hip, round 5): one activation chunk and two dY
+    parity streams through registers - six VMEM operations per step, `vmcnt(18)` - with fp16 and with bf16 activations."""
+    _check_register_loads_in_flight("conv_wgrad_subpixel.hip", r"conv_wgrad_subpixel_ws_kernelILb[01]E", 2, 6, 24)

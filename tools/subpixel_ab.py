@@ -37,6 +37,22 @@ for (B, S) in ((2048, 16), (2048, 8), (1024, 14), (1024, 7), (1024, 32), (1024, 
             t_new = timed(lambda: ops.conv_subpixel(x, wsub, C, ops.SUBPIXEL_UPSAMPLE, bias=bias))
             fl = 2.0 * B * 4 * S * S * C * C * 9
             print(f"B={B} {S}->{2 * S} {name}: nearest-x2 halo {t_old:7.1f} us ({fl / t_old / 1e6:6.0f} TFLOP/s)  sub-pixel {t_new:7.1f} us ({fl / t_new / 1e6:6.0f} algorithmic TFLOP/s)  ratio {t_new / t_old:.3f}", flush=True)
+    dyh = torch.randn((B, 2 * S, 2 * S, C), generator=g).cuda().bfloat16()
+    wfb0 = torch.empty(w.numel(), device="cuda", dtype=torch.bfloat16); wd0 = torch.empty_like(wfb0)
+    ops.pack_conv_weight(w, wfb0, wd0)
+    wsd = torch.empty(16 * C * C, device="cuda", dtype=torch.bfloat16)
+    ops.pack_upsample_weight(w, None, wsd)
+    for rnd in range(2):
+        t_old = timed(lambda: ops.sumpool2x2(ops.conv_igemm([dyh], wd0, C, 3, ops.NORMAL, (2 * S, 2 * S))))
+        t_new = timed(lambda: ops.conv_subpixel(dyh, wsd, C, ops.SUBPIXEL_UPSAMPLE_DGRAD))
+        print(f"B={B} {2 * S}->{S} upsample dgrad (bf16): dgrad3x3 + sumpool {t_old:7.1f} us  sub-pixel {t_new:7.1f} us  ratio {t_new / t_old:.3f}", flush=True)
+    xa = torch.randn((B, S, S, C), generator=g).cuda().half()
+    dwa, dwb = torch.empty((C, C, 3, 3), device="cuda"), torch.empty((C, C, 3, 3), device="cuda")
+    if ops.conv_wgrad_subpixel_ok(B, S, S, C, torch.bfloat16):
+        for rnd in range(2):
+            t_old = timed(lambda: ops.conv_wgrad(dyh, [xa], 3, ops.UPSAMPLE2, dwa))
+            t_new = timed(lambda: ops.conv_wgrad_subpixel(dyh, xa, dwb))
+            print(f"B={B} {S}->{2 * S} upsample wgrad (fp16 x): nearest-x2 slots {t_old:7.1f} us  sub-pixel {t_new:7.1f} us  ratio {t_new / t_old:.3f}", flush=True)
     dy = torch.randn((B, S, S, C), generator=g).cuda().bfloat16()
     res = torch.randn((B, 2 * S, 2 * S, C), generator=g).cuda().bfloat16()
     wfb = torch.empty(w.numel(), device="cuda", dtype=torch.bfloat16); wd = torch.empty_like(wfb)
