@@ -65,6 +65,10 @@ KERNEL_DESC = {
     "conv_wgrad_slots_kernel": "3x3 weight gradient over padded slots, 8 compute waves (+ slab reduce)",
     "conv_wgrad_slots_ws_kernel": "3x3 weight gradient over padded slots, wave-specialised (+ slab reduce)",
     "conv_wgrad_kernel": "im2col split-K weight gradient (+ slab reduce)",
+    "conv_subpixel_ws_kernel[upsample]": "`Upsample` (nearest x2 + 3x3) as four output parities of 2x2 taps on pre-summed weights, low-resolution halo resident for all four (16 of 36 tap-products; FLOPs quoted are the reference op's)",
+    "conv_subpixel_ws_kernel[transposed]": "data gradient of the stride-2 convs: output parities meet 1 / 2 / 2 / 4 taps over the gradient's own grid (9 of 36 tap-products of the zero-stuffed form)",
+    "conv_subpixel_ws_kernel[upsample dgrad]": "data gradient of `Upsample`: the transposed sub-pixel form over the four parity views of the gradient, one launch instead of dgrad3x3 + sumpool2x2",
+    "conv_wgrad_subpixel_ws_kernel": "weight gradient of `Upsample`: 16 tap gradients over the low-resolution slots, two dY parity streams (+ two-stage reduce onto the 9 taps)",
     "gn_silu_fwd_reg_kernel": "GroupNorm+SiLU forward, register-resident (one read + one write of the tensor)",
     "gn_silu_fwd_kernel": "GroupNorm+SiLU forward, two-sweep streaming (8x8 / 7x7 levels, 64-pixel rows)",
     "gn_silu_bwd_hybrid_kernel": "GroupNorm+SiLU backward, dy in registers + x parked in LDS (x, dy, addends read once, dx written once)",

@@ -2,7 +2,7 @@
 // `skip_connection = nn.Conv2d(2C, C, 1)`, gms/diffusion/simple_unet.py:176,186): out_a | out_b [pixel][128] = dout[pixel][128] . Wd[128][256],
 // a [pixels x 128] x [128 x 256] GEMM that moves 3 N bytes for 128 k of work per output - bound by memory, not by the matrix cores.
 // The general LDS-DMA convolution kernel runs it at 3.2 TB/s (two K-steps per 256-pixel tile: its pipeline never fills).  Here, as in the
-// stem kernels: a persistent workgroup per CU keeps the 256 x 128 weight block in LDS for the whole launch, streams
+// stem kernels (docs/EXPERIMENTS.md section 7b.4): a persistent workgroup per CU keeps the 256 x 128 weight block in LDS for the whole launch, streams
 // tiles of 128 pixels - the next tile's 32 KiB arrive by dense 16-byte loads while the current one is computed - and every wave multiplies its
 // 32 pixels with v_mfma_f32_32x32x16 (A = weight rows from LDS, B = the pixel rows from LDS, D[channel][pixel]: a lane ends up with 4
 // consecutive channels of one pixel), packs to 16 bits and leaves through a per-wave LDS tile so that a store instruction writes 1 KiB of

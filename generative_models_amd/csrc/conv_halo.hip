@@ -453,7 +453,7 @@ template <int N> struct IntTag { static constexpr int value = N; };
 // Every dense piece is issued at least four K-steps before its step and every slot is re-used only behind the barrier that follows its last
 // read.  (The first form of the round put the eight dense steps in ONE block in front of the halo phases: 17 of a tile's 31 pieces then had
 // to arrive within eight 512-cycle steps, an issue distance of two short steps could not cover the HBM latency, and the block took 8.0 us
-// per tile for 2.0 us of MFMA work - 979 -> 796 us per launch at 32 x 32, B = 2048; DESIGN.md section 7b.2 has both measurements.)
+// per tile for 2.0 us of MFMA work - 979 -> 796 us per launch at 32 x 32, B = 2048; docs/EXPERIMENTS.md section 7b.2 has both measurements.)
 
 // 64-byte rows: lane (row = lane >> 2, chunk = lane & 3) of a DMA instruction writes 16 rows of 64 B; physical chunk c of row n holds logical
 // chunk c ^ ((n >> 2) & 3), so the 16 rows a ds_read_b128 lane group touches (consecutive n, one logical chunk) cover all 64 banks.
@@ -597,6 +597,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             const char* gsrc[2] = {(const char*)p.src0, (const char*)(p.c1 ? p.src1 : p.src0)};
             u32x4 L[3][2];
             f32x4 Csc[2][2], Csh[2][2];         // [sample b0 / b0 + 1][channels 0-3 / 4-7 of this lane's chunk] of the phase being filled
+            // ident (experiment, GMK_DEV_VARIANT=11 without GroupNorm tables): the same register-staged fill with NO transform - the halo rows two
+            // neighbouring tiles share then arrive by register loads, which the L2 merges (LDS-DMA reads of one line by two workgroups both reach memory)
+            const bool ident = p.gn_scale == nullptr;
             auto load_tables = [&](int tl, int ph) {          // 8 x 16-byte loads (counted by hand)
                 const int gr0 = (tl < p.ntiles ? tl : 0) * p.R;
                 const int b0 = gr0 / H;
@@ -604,8 +607,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 #pragma unroll
                 for (int sidx = 0; sidx < 2; ++sidx) {
                     const int bb = min(b0 + sidx, p.B - 1);
-                    const float* ps = p.gn_scale + (size_t)bb * p.gn_stride + kch;
-                    const float* ph_ = p.gn_shift + (size_t)bb * p.gn_stride + kch;
+                    const float* ps = ident ? (const float*)p.src0 : p.gn_scale + (size_t)bb * p.gn_stride + kch;          // (ident: any valid 32 bytes - the counts stay)
+                    const float* ph_ = ident ? (const float*)p.src0 : p.gn_shift + (size_t)bb * p.gn_stride + kch;
                     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Csc[sidx][0]) : "v"(ps) : "memory");
                     asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(Csc[sidx][1]) : "v"(ps) : "memory");
                     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Csh[sidx][0]) : "v"(ph_) : "memory");
@@ -661,7 +664,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     const unsigned long long mv = __builtin_amdgcn_ballot_w64(valid);
                     const unsigned long long m1 = __builtin_amdgcn_ballot_w64(valid && ((hp >> 28) & 1u));
                     u32x4 o = {0u, 0u, 0u, 0u};
-                    if (mv != 0) {                       // pieces of pad slots only (a third of a 28 x 28 halo) skip the arithmetic
+                    if (ident) {
+                        if (valid) o = L[set][u];
+                    } else if (mv != 0) {                // pieces of pad slots only (a third of a 28 x 28 halo) skip the arithmetic
                         if (m1 == 0) o = xform(L[set][u], hp, IntTag<0>{});
                         else if (m1 == mv) o = xform(L[set][u], hp, IntTag<1>{});
                         else o = xform(L[set][u], hp, IntTag<2>{});
@@ -1626,7 +1631,8 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     // the 16 x 16 x 32 form everywhere, so it is the form of every launch now.  GMK_DEV_VARIANT=32 forces the other.
     // kind: 0 the 8-compute-wave kernel (variants 1, 3, or statistics wanted), 1 fused GroupNorm-apply + SiLU in the producer waves
     // (tables from gmk_gn_stats), 2 variant 4 (no weight prefetch), 3 the wave-specialised kernel
-    const int kind = gn_scale ? 1 : (p.variant == 4 && !p.stats) ? 2 : (!p.stats && (use16 || (p.variant != 1 && p.variant != 3))) ? 3 : 0;
+    const bool regfill = p.variant == 11 && !gn_scale && !p.stats && !upsample;      // experiment: halo pieces through registers, no transform
+    const int kind = (gn_scale || regfill) ? 1 : (p.variant == 4 && !p.stats) ? 2 : (!p.stats && (use16 || (p.variant != 1 && p.variant != 3))) ? 3 : 0;
     auto launch = [&](auto tag) {
         typedef decltype(tag) T;
         if (kind == 1) {

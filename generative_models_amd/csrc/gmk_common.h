@@ -191,7 +191,7 @@ __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0
 
 // Cross-lane reductions WITHOUT ds_bpermute (`__shfl_xor` lowers to ds_bpermute_b32, which runs through the LDS crossbar): DPP inside a
 // 16-lane row and v_permlane{16,32}_swap across rows never touch the LDS pipeline, pair the same lanes as the xor butterfly
-// (bit-identical sums) and are faster.  DESIGN.md section 5 records the round-1/2 investigation of a GroupNorm miscompare that only a
+// (bit-identical sums) and are faster.  docs/EXPERIMENTS.md section 5 records the round-1/2 investigation of a GroupNorm miscompare that only a
 // ds_bpermute build showed, including what the ISA of both builds looks like; no kernel in csrc/ uses ds_bpermute.
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void expand3x3_mfma_kernel(const float* __rest
 }
 
 // ---- the "expand" convolution for 16-bit outputs, round 4: tiles of 128 pixels, image window in LDS, bf16 hi + lo operands ----------------
-// What binds the exact-fp32 kernel above is not one thing (timing-only builds): with a ninth of the MFMA cycles it is
+// What binds the exact-fp32 kernel above is not one thing (timing-only builds, docs/EXPERIMENTS.md section 7b.4): with a ninth of the MFMA cycles it is
 // 9 % faster, with half of its gathers no faster, with dense stores no faster, with neither gathers nor MFMAs it writes at 5.2 TB/s - the
 // per-lane image gathers (16 four-byte loads per 32 pixels through the texture path) and the fp32 MFMA chain (56 x 64 cycles per block) each
 // cap it near 2.7 / 4.8 TB/s.  This form removes both: a workgroup owns 128 consecutive pixels of ONE sample, the window of image values they

@@ -450,7 +450,7 @@ class SimpleUnet(nn.Module):
         elif len(srcs) == 2:
             # The 1x1 skip convolution (HBM-bound) only needs the block input.  With GMK_FWD_SIDE=1 it runs on the side stream beside
             # GroupNorm / conv1 / GroupNorm and is joined in front of conv2 (-1 % of a forward).  OFF by default: that co-residency
-            # (conv_igemm_kernel's LDS staging next to the GroupNorm kernel) is where round 1's unexplained fault lived.
+            # (conv_igemm_kernel's LDS staging next to the GroupNorm kernel) is where round 1's unexplained fault lived (docs/EXPERIMENTS.md section 5).
             wfs, _ = self._packs[f"{name}.skip_connection"]
             run_skip = lambda: skip.__setitem__("res", self._conv(srcs, wfs, C, 1, ops.NORMAL, (H, W),
                                                                       bias=P[f"{name}.skip_connection.bias"]))

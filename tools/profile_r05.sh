@@ -1,15 +1,15 @@
 #!/bin/bash
-# Round-4 judged artefacts.  usage: [PARTS="stats pmc"] tools/profile_r04.sh [tag]   (writes gpurun_out/<tag>/..., copies the summaries into
+# Round-5 judged artefacts.  usage: [PARTS="stats pmc"] tools/profile_r05.sh [tag]   (writes gpurun_out/<tag>/..., copies the summaries into
 # profiles/; the whole script is ~ 18 minutes of GPU time: PARTS=stats (kernel traces) and PARTS=pmc (counter passes + bench line + reports)
 # run it in two calls)
-#   r04_<cfg>_train_serial_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the train steps with non-overlapping launches
+#   r05_<cfg>_train_serial_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the train steps with non-overlapping launches
 #                                             (GMK_WGRAD_STREAM=0): the averages that compare with the bench line's HIP events
-#   r04_bench_kernel_stats.csv                the default `python bench.py` command (all configs, samplers, overlapping streams)
-#   r04_traffic.json                          HBM bytes per launch of every kernel of the headline config, separate --pmc passes,
+#   r05_bench_kernel_stats.csv                the default `python bench.py` command (all configs, samplers, overlapping streams)
+#   r05_traffic.json                          HBM bytes per launch of every kernel of the headline config, separate --pmc passes,
 #                                             stamped with the kernel-source hash (bench.py quotes it only for the same sources)
-#   r04_bench.json                            the bench line of the same build;  r04_parity_report.txt  tests/parity_report.py
-#   r04_trajectory_report.txt                 tests/trajectory_report.py: 150 Adam steps, CPU oracle vs HIP fp32 vs HIP 16-bit
-TAG=${1:-r04}
+#   r05_bench.json                            the bench line of the same build;  r05_parity_report.txt  tests/parity_report.py
+#   r05_trajectory_report.txt                 tests/trajectory_report.py: 150 Adam steps, CPU oracle vs HIP fp32 vs HIP 16-bit
+TAG=${1:-r05}
 OUT=/tmp/gmk_$TAG                 # raw traces are hundreds of MB: they stay on the box; only the summaries travel
 KEEP=gpurun_out/$TAG
 REPO=$(pwd)
@@ -20,19 +20,19 @@ cd $REPO
 if [[ " $PARTS " == *" stats "* ]]; then
 for cfg in cfg2 cfg1 cfg3; do
   GMK_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial_$cfg -o serial -- python bench.py --config $cfg --others 0 --sampler_steps 0 --no_profile --no_cpu --steps 10 --warmup 3 > $OUT/serial_$cfg.log 2>&1 || exit 1
-  cp $(find $OUT/serial_$cfg -name "*kernel_stats.csv" | head -1) profiles/r04_${cfg}_train_serial_kernel_stats.csv
+  cp $(find $OUT/serial_$cfg -name "*kernel_stats.csv" | head -1) profiles/r05_${cfg}_train_serial_kernel_stats.csv
   echo "serial $cfg done"
 done
 for cfg in cfg2 cfg1; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sampler_$cfg -o sampler -- python tools/sampler_probe.py $cfg 40 > $OUT/sampler_$cfg.log 2>&1 || exit 1
-  cp $(find $OUT/sampler_$cfg -name "*kernel_stats.csv" | head -1) profiles/r04_${cfg}_sampler_kernel_stats.csv
+  cp $(find $OUT/sampler_$cfg -name "*kernel_stats.csv" | head -1) profiles/r05_${cfg}_sampler_kernel_stats.csv
   echo "sampler $cfg done"
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python bench.py --no_cpu --sampler_steps 100 > $OUT/prof_bench.log 2>&1 || exit 1
-cp $(find $OUT/bench -name "*kernel_stats.csv" | head -1) profiles/r04_bench_kernel_stats.csv
+cp $(find $OUT/bench -name "*kernel_stats.csv" | head -1) profiles/r05_bench_kernel_stats.csv
 echo "bench stats done"
 fi
-[[ " $PARTS " == *" pmc "* ]] || { cp profiles/r04_*kernel_stats.csv $KEEP/; exit 0; }
+[[ " $PARTS " == *" pmc "* ]] || { cp profiles/r05_*kernel_stats.csv $KEEP/; exit 0; }
 for cfg in cfg2 cfg1 cfg3 cfg4; do      # every single-GPU configuration of the bench line gets its own counter passes (cfg4 since round 4)
   i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
@@ -50,17 +50,17 @@ out = {}
 for cfg in ("cfg2", "cfg1", "cfg3", "cfg4"):
     out[cfg] = {"kernel_hash": bench.kernel_hash(), "kernels": json.load(open("$OUT/pmc_%s/kernels.json" % cfg)),
                 "provenance": "rocprofv3 --pmc, three separate passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) of "
-                "'bench.py --config %s --others 0 --steps 3 --warmup 1 --sampler_steps 2' (tools/profile_r04.sh); FETCH_SIZE doubled (gfx950, 16-B/lane "
+                "'bench.py --config %s --others 0 --steps 3 --warmup 1 --sampler_steps 2' (tools/profile_r05.sh); FETCH_SIZE doubled (gfx950, 16-B/lane "
                 "streaming reads: MI355X_MICROARCH.md HBM); bytes averaged over the kernel's launches of 4 train steps + 6 sampler forwards; "
                 "sclk_ghz_est = GRBM_GUI_ACTIVE per XCD / dispatch time of the same pass (tools/traffic_parse.py)" % cfg}
-json.dump(out, open("profiles/r04_traffic.json", "w"), indent=1)
+json.dump(out, open("profiles/r05_traffic.json", "w"), indent=1)
 PY
 echo "traffic done"
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
-cp $OUT/bench.json profiles/r04_bench.json                     # the compact line (what the driver parses)
-cp gpurun_out/bench_detail.json profiles/r04_bench_detail.json   # the full record of the same run
-python tests/parity_report.py > profiles/r04_parity_report.txt 2>/dev/null || exit 1
-python tests/trajectory_report.py 150 2>/dev/null | grep -v "^oracle step" > profiles/r04_trajectory_report.txt || exit 1
-if [[ " $PARTS " == *" stats "* ]]; then cp profiles/r04_* $KEEP/; else cp profiles/r04_traffic.json profiles/r04_bench.json profiles/r04_bench_detail.json profiles/r04_parity_report.txt profiles/r04_trajectory_report.txt $KEEP/; fi
+cp $OUT/bench.json profiles/r05_bench.json                     # the compact line (what the driver parses)
+cp gpurun_out/bench_detail.json profiles/r05_bench_detail.json   # the full record of the same run
+python tests/parity_report.py > profiles/r05_parity_report.txt 2>/dev/null || exit 1
+python tests/trajectory_report.py 150 2>/dev/null | grep -v "^oracle step" > profiles/r05_trajectory_report.txt || exit 1
+if [[ " $PARTS " == *" stats "* ]]; then cp profiles/r05_* $KEEP/; else cp profiles/r05_traffic.json profiles/r05_bench.json profiles/r05_bench_detail.json profiles/r05_parity_report.txt profiles/r05_trajectory_report.txt $KEEP/; fi
 cp $OUT/*.log $OUT/bench.err $KEEP/ 2>/dev/null
 tail -c 300 $OUT/bench.json

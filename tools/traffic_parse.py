@@ -1,50 +1,12 @@
 """Collect the rocprofv3 --pmc passes of tools/traffic.sh into one JSON: per kernel, HBM bytes per launch
 (FETCH_SIZE x 2 on gfx950 for 16-B/lane streaming reads — guides/MI355X_MICROARCH.md, HBM — plus WRITE_SIZE; both counters
 are in KiB) and the MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 4 SIMDs x 256 CUs ... reported raw)."""
-import csv, glob, json, sys, collections, re
+import csv, glob, json, os, sys, collections, re
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 out = sys.argv[1]
 
 
-def instantiation(name):
-    """The 3x3 halo kernel runs as several template instantiations with different work per launch (fp16 forward, bf16 data gradient, the
-    folded skip convolution, the sub-pixel phase forms): each gets its OWN record, keyed `conv3x3_halo_ws_kernel<f16>`, `<bf16>`, `<f16,+skip>` ...
-    (rocprofv3 prints some instantiations demangled - bf16 as "bool _Accum, bool, E" - and some mangled)."""
-    base = short(name)
-    if not base.startswith("conv3x3_halo") and not base.startswith("conv_phase"):
-        return None
-    if name.startswith("_Z"):
-        m = re.search(r"kernelI(DF16_|DF16b)((?:L[bi]\d+E)*)E", name)
-        if not m:
-            return None
-        typ = "f16" if m.group(1) == "DF16_" else "bf16"
-        args = re.findall(r"L([bi])(\d+)E", m.group(2))
-        vals = [int(v) for _, v in args]
-    else:
-        m = re.search(r"kernel<(.*)>\(", name)
-        if not m:
-            return None
-        body = m.group(1)
-        typ = "bf16" if "_Accum" in body or "bfloat" in body or "__bf16" in body else "f16"
-        vals = [1 if t.strip() == "true" else 0 if t.strip() == "false" else int(t) for t in body.split(",") if t.strip() in ("true", "false") or t.strip().lstrip("-").isdigit()]
-    tags = [typ]
-    if base == "conv3x3_halo_ws_kernel":          # <T, kPrefetchW, kShape, kFuse, kSkip>
-        if len(vals) >= 3 and vals[2]:
-            tags.append("+gn")
-        if len(vals) >= 4 and vals[3]:
-            tags.append("+skip")
-    else:
-        tags += [str(v) for v in vals]
-    return f"{base}<{','.join(tags)}>"
-
-
-def short(name):
-    name = re.sub(r"\(anonymous namespace\)::", "", name)
-    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
-    if m:
-        n = int(m.group(1)); start = m.end()
-        name = name[start:start + n]
-    name = re.sub(r"^void ", "", name)
-    return name.split("(")[0].split("<")[0].strip()
+from kernel_names import instantiation, short
 
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
