@@ -54,7 +54,8 @@ __device__ __forceinline__ int div_small(int a, float inv) { return (int)(((floa
 
 // ---- the K-step plan of a tile (compile time) -----------------------------------------------------------------------------------------
 // kMode 0: upsample (parities in order (0,0) (0,1) (1,0) (1,1), 4 taps each, pack index 4 (2a + b) + 2 ty + tx, dy = a - 1 + ty, dx = b - 1 + tx)
-// kMode 1: transposed (parity order (1,1) (0,0) (0,1) (1,0): the 4-tap parity first and a 2-tap one last, so the fill windows are 4 and 2 steps;
+// kMode 1: transposed (parity order (1,1) (1,0) (0,0) (0,1): the 4-tap parity first and a 2-tap one last, so the fill windows are 4 and 2 steps, and the two
+//          column parities of an output row - adjacent 256-byte pixels - are written back to back;
 //          per axis: parity 0 meets tap 1 (offset 0), parity 1 meets tap 0 (offset 0) and tap 2 (offset +1); pack index 3 ty + tx)
 struct Step { int ph, a, b, dy, dx, ptap, half, buf, first_ph, last_ph; };
 // kMode 2: `Upsample` data gradient (HIGH -> LOW): segments (view (a, b), channel half) in order, 4 taps each; tap (ty, tx) of view (a, b) reads the
@@ -62,8 +63,8 @@ struct Step { int ph, a, b, dy, dx, ptap, half, buf, first_ph, last_ph; };
 //          half-buffer = segment & 1; one accumulation over all 32 steps
 template <int kMode> struct Plan {
     static constexpr bool kDown = kMode == 2;
-    static constexpr int pa(int i) { return kMode != 1 ? (i >> 1) : (i == 0 || i == 3) ? 1 : 0; }
-    static constexpr int pb(int i) { return kMode != 1 ? (i & 1) : (i == 0 || i == 2) ? 1 : 0; }
+    static constexpr int pa(int i) { return kMode != 1 ? (i >> 1) : i < 2 ? 1 : 0; }
+    static constexpr int pb(int i) { return kMode != 1 ? (i & 1) : (i == 0 || i == 3) ? 1 : 0; }
     static constexpr int nax(int par) { return kMode != 1 ? 2 : (par ? 2 : 1); }            // taps along one axis
     static constexpr int ntaps(int i) { return nax(pa(i)) * nax(pb(i)); }
     static constexpr int nsteps() { return 2 * (ntaps(0) + ntaps(1) + ntaps(2) + ntaps(3)); }
@@ -99,8 +100,9 @@ template <int kMode> struct Plan {
     static constexpr bool post_barrier_loads(int s) { return fresh_halo(s) || at(s).first_ph; }
 };
 static_assert(Plan<0>::S == 32 && Plan<1>::S == 18 && Plan<0>::NT0 == 4 && Plan<1>::NT0 == 4 && Plan<1>::NT3 == 2, "K-step plan");
-static_assert(Plan<1>::at(0).ptap == 0 && Plan<1>::at(3).ptap == 8 && Plan<1>::at(3).dy == 1 && Plan<1>::at(8).ptap == 4 && Plan<1>::at(8).last_ph == 0 &&
-              Plan<1>::at(9).last_ph == 1 && Plan<1>::at(10).ptap == 3 && Plan<1>::at(11).ptap == 5 && Plan<1>::at(11).dx == 1, "transposed plan");
+static_assert(Plan<1>::at(0).ptap == 0 && Plan<1>::at(3).ptap == 8 && Plan<1>::at(3).dy == 1 && Plan<1>::at(8).ptap == 1 && Plan<1>::at(9).ptap == 7 &&
+              Plan<1>::at(9).dy == 1 && Plan<1>::at(9).last_ph == 0 && Plan<1>::at(11).last_ph == 1 && Plan<1>::at(12).ptap == 4 && Plan<1>::at(13).last_ph == 1 &&
+              Plan<1>::at(14).ptap == 3 && Plan<1>::at(15).ptap == 5 && Plan<1>::at(15).dx == 1 && Plan<1>::at(17).half == 1, "transposed plan");
 static_assert(Plan<2>::S == 32 && Plan<2>::at(0).dy == 1 && Plan<2>::at(3).dy == 0 && Plan<2>::at(3).dx == 0 && Plan<2>::at(4).buf == 1 && Plan<2>::at(8).buf == 0 &&
               Plan<2>::at(8).b == 1 && Plan<2>::at(8).dx == 0 && Plan<2>::at(9).dx == -1 && Plan<2>::at(31).dy == -1 && Plan<2>::at(31).last_ph == 1 &&
               Plan<2>::at(7).last_ph == 0 && Plan<2>::at(28).ptap == 12 && Plan<2>::nfill(3) == 1 && Plan<2>::nfill(4) == 2, "upsample data-gradient plan");
@@ -307,11 +309,12 @@ __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParam
     // of ONE pixel, stored at output pixel (2 row + a, 2 x + b): a pixel's 256 bytes are two whole cache lines, so the stride-2 scatter
     // costs no partial-line writes, and the four parities of a tile complete each other's DRAM pages within one tile time.
     auto epilogue = [&](int tile, int a, int b) __attribute__((always_inline)) {
-        // (the consumers sit at the 256-register limit: bias and residual are loaded per channel-block pair, one pair ahead, not per tile)
+        // (the consumers sit at the 256-register limit: the bias is loaded per channel-block pair; addresses are recomputed per epilogue)
+        unsigned row_b[2];
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip) {
             int ml = pxbase + (2 * ip + (q & 1)) * 16 + r16;                // the pixel this lane stores after the swap
-            asm volatile("" : "+v"(ml));                                    // (addresses are recomputed per epilogue: hoisted out of the tile loop they cost 16 registers)
+            asm volatile("" : "+v"(ml));                                    // (hoisted out of the tile loop these cost 16 registers)
             const int m = tile * p.TP + ml;
             const bool live = ml < p.TP && m < p.M;
             unsigned mo = (unsigned)m;                                       // HIGH -> LOW: the low-resolution pixel itself
@@ -320,17 +323,23 @@ __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParam
                 const int orow = 2 * (tile * p.R + srow) + a;                    // row of the output's global row list
                 mo = (unsigned)(orow * (2 * W) + 2 * sx + b);
             }
-            const unsigned row_b = live ? mo * (unsigned)p.out_cstride * ES + (unsigned)((q >> 1) * 8) * ES : kBadOff;
-            u32x4 rres[2][2];
-            auto load_res = [&](int cp) {
+            row_b[ip] = live ? mo * (unsigned)p.out_cstride * ES + (unsigned)((q >> 1) * 8) * ES : kBadOff;
+        }
+        constexpr bool kRes = kMode == 1;          // only the stride-2 data gradient is ever called with a residual (the skip path's gradient)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    rres[cp & 1][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, row_b, (2 * cp + j) * 16 * ES, 0));
-            };
-            if (p.residual) load_res(0);
+        for (int ip = 0; ip < 2; ++ip) {
+            // the residual of this pixel: all eight 16-byte loads up front (the fragment registers are dead during the epilogue; two at a time
+            // left each pair's HBM latency exposed: 6.6 us per epilogue against 2.9 without a residual; sixteen - both pixels - spill and gain nothing)
+            u32x4 rres[4][2];
+            if (kRes && p.residual) {
+#pragma unroll
+                for (int cp = 0; cp < 4; ++cp)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        rres[cp][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, row_b[ip], (2 * cp + j) * 16 * ES, 0));
+            }
 #pragma unroll
             for (int cp = 0; cp < 4; ++cp) {
-                if (p.residual && cp < 3) load_res(cp + 1);
                 float bz[2][4];
                 if (p.bias) {
 #pragma unroll
@@ -346,8 +355,8 @@ __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParam
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v0[e] += bz[j][e]; v1[e] += bz[j][e]; }
                     }
-                    if (p.residual) {
-                        const u32x4 Rr = rres[cp & 1][j];
+                    if (kRes && p.residual) {
+                        const u32x4 Rr = rres[cp][j];
                         const auto s0 = __builtin_amdgcn_permlane16_swap(Rr[0], Rr[2], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(Rr[1], Rr[3], false, false);
                         const half_t ra = __builtin_bit_cast(half_t, (u32x2_t){s0[0], s1[0]});      // pixel block 2 ip
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void conv_subpixel_ws_kernel(const SubParam
                     const auto s0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
                     const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rso, row_b, cb * 16 * ES, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rso, row_b[ip], cb * 16 * ES, 0);
                 }
             }
         }
@@ -510,6 +519,7 @@ extern "C" int gmk_conv_subpixel(const void* src, int B, int H, int W, int cin, 
     GMK_REQUIRE(gmk_is16(dtype), "gmk_conv_subpixel: 16-bit types only (dtype %d)", dtype);
     GMK_REQUIRE(mode == GMK_SUBPIXEL_UPSAMPLE || mode == GMK_SUBPIXEL_TRANSPOSED || mode == GMK_SUBPIXEL_UPSAMPLE_DGRAD, "gmk_conv_subpixel: bad mode %d", mode);
     GMK_REQUIRE(n0 >= 0 && n0 + cout <= w_rows && out_cstride >= cout, "gmk_conv_subpixel: bad output channels n0=%d cout=%d w_rows=%d", n0, cout, w_rows);
+    GMK_REQUIRE(!residual || mode == GMK_SUBPIXEL_TRANSPOSED, "gmk_conv_subpixel: a residual is taken by GMK_SUBPIXEL_TRANSPOSED only (mode %d)", mode);
     const bool down = mode == GMK_SUBPIXEL_UPSAMPLE_DGRAD;
     const int ntaps = mode == GMK_SUBPIXEL_TRANSPOSED ? 9 : 16;
     HaloGeometry g;

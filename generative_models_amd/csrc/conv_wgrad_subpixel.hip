@@ -319,7 +319,10 @@ static int wgrad_subpixel_plan(int B, int H, int W, int cin, int cout, int dy_cs
     if (4 * M * dy_cstride * 2 >= lim || M * cin * 2 >= lim) return 0;
     const int nch = (int)((total + 63) / 64);
     int ns = gmk_cu_limit() / ((cout / 64) * (cin / 64) * 2);                  // both row parities in one launch
-    if (ns >= 8) ns &= ~7;                                                     // the 8 workgroups of a slot range sit on one XCD
+    if (ns >= 8) {                                                             // the 8 workgroups of a slot range sit on one XCD (a multiple of 8 splits) -
+        const int all8 = ns & ~7, two = ns & ~3;                               // or on two (a multiple of 4) when the CU limit of a data-parallel run (248)
+        ns = all8 * 16 < ns * 15 ? two : all8;                                 // would otherwise leave a fifth of the CUs without a workgroup
+    }
     if (ns < 1) ns = 1;
     if (nch < 8 * ns) return 0;                                                // too little work per split: the nearest-x2 forms
     const int c = (nch + ns - 1) / ns;

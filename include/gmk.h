@@ -157,7 +157,7 @@ int gmk_conv3x3_skipfold(const void* src, int c0, int B, int H, int W, const voi
  *   GMK_SUBPIXEL_TRANSPOSED  data gradient of `Downsample` (simple_unet.py:75-84, Conv2d(C, C, 3, stride=2, padding=1)): w is the ordinary
  *                            w_dgrad pack `[9][w_rows][cin]` of gmk_pack_conv_weight; parities meet 1 / 2 / 2 / 4 of its taps (the same products
  *                            in the same order as gmk_conv_igemm(GMK_CONV_TRANSPOSED2) on the zero-stuffed gradient, minus its 27 of 36 multiplications by zero)
- * bias / residual (NHWC, the output's shape) optional.  16-bit types, cin = cout = 128, shapes where gmk_conv_subpixel_ok(...) returns 1; otherwise
+ * bias optional; residual (NHWC, the output's shape) optional with GMK_SUBPIXEL_TRANSPOSED only.  16-bit types, cin = cout = 128, shapes where gmk_conv_subpixel_ok(...) returns 1; otherwise
  * the call fails (callers fall back to gmk_conv_igemm).  GMK_SUBPIXEL=0 in the environment makes gmk_conv_subpixel_ok answer 0 (A/B switch).
  *   GMK_SUBPIXEL_UPSAMPLE_DGRAD  the data gradient of `Upsample` - HIGH -> LOW: src is the output gradient [B][2H][2W][cin], out [B][H][W][cout] =
  *                            sumpool2x2(dgrad3x3(src)) of the reference's autograd in ONE launch: the transpose of the sub-pixel forward, 16 tap-products

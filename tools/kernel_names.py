@@ -30,7 +30,9 @@ def instantiation(name):
         if len(vals) >= 4 and vals[3]:
             tags.append("+skip")
     elif base == "conv_subpixel_ws_kernel":       # <T, kMode>
-        tags.append({0: "upsample", 1: "transposed", 2: "upsample dgrad"}.get(vals[0] if vals else -1, "?"))
+        # rocprofv3's demangler garbles the FIRST literal behind a bf16 type argument ("<bool _Accum, int, E>": the value of Li1E is lost, while
+        # Li2E stays mangled and is parsed above): the product launches bf16 instances of modes 1 and 2 only, so a bf16 name without a value is mode 1
+        tags.append({0: "upsample", 1: "transposed", 2: "upsample dgrad"}.get(vals[0] if vals else (1 if typ == "bf16" else -1), "?"))
     else:
         tags += [str(v) for v in vals]
     return f"{base}<{','.join(tags)}>"
