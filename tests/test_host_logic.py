@@ -730,3 +730,28 @@ def test_subpixel_wgrad_register_loads_stay_untouched_while_in_flight():
     """The same guard for the sub-pixel `Upsample` weight gradient (csrc/conv_wgrad_subpixel.hip, round 5): one activation chunk and two dY
     parity streams through registers - six VMEM operations per step, `vmcnt(18)` - with fp16 and with bf16 activations."""
     _check_register_loads_in_flight("conv_wgrad_subpixel.hip", r"conv_wgrad_subpixel_ws_kernelILb[01]E", 2, 6, 24)
+
+
+def test_counter_records_are_keyed_per_template_instantiation():
+    """tools/kernel_names.py (the round-4 verdict's item 4a): the 3x3 halo kernel's instantiations do different work per launch (fp16 forward, bf16
+    data gradient, folded skip convolution, in-convolution GroupNorm) and so do the sub-pixel kernel's modes - each gets its own counter record;
+    rocprofv3 prints some names demangled (bf16 garbled as "bool _Accum, bool, E") and some mangled."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from kernel_names import instantiation, short
+    finally:
+        sys.path.pop(0)
+    cases = {
+        "void (anonymous namespace)::conv3x3_halo_ws_kernel<bool _Accum, bool, E, 16, false, false>((anonymous namespace)::HaloParams)": "conv3x3_halo_ws_kernel<bf16>",
+        "_ZN12_GLOBAL__N_122conv3x3_halo_ws_kernelIDF16_Lb1ELi16ELb0ELb0EEEvNS_10HaloParamsE": "conv3x3_halo_ws_kernel<f16>",
+        "_ZN12_GLOBAL__N_122conv3x3_halo_ws_kernelIDF16_Lb1ELi16ELb0ELb1EEEvNS_10HaloParamsE": "conv3x3_halo_ws_kernel<f16,+skip>",
+        "_ZN12_GLOBAL__N_122conv3x3_halo_ws_kernelIDF16_Lb1ELi16ELb1ELb0EEEvNS_10HaloParamsE": "conv3x3_halo_ws_kernel<f16,+gn>",
+        "_ZN12_GLOBAL__N_123conv_subpixel_ws_kernelIDF16_Li0EEEvNS_9SubParamsE": "conv_subpixel_ws_kernel<f16,upsample>",
+        "_ZN12_GLOBAL__N_123conv_subpixel_ws_kernelIDF16bLi2EEEvNS_9SubParamsE": "conv_subpixel_ws_kernel<bf16,upsample dgrad>",
+        "void (anonymous namespace)::conv_subpixel_ws_kernel<bool _Accum, int, E>((anonymous namespace)::SubParams)": "conv_subpixel_ws_kernel<bf16,transposed>",
+    }
+    for name, want in cases.items():
+        assert instantiation(name) == want, (name, instantiation(name))
+        assert short(name) == want.split("<")[0]
+    assert instantiation("_ZN12_GLOBAL__N_125gn_silu_bwd_hybrid_kernelIDF16_Li8ELi512ELi4ELi8ELi0ELb1EEEvPKDF16bPKT_") is None
+    assert short("void (anonymous namespace)::wgrad_reduce_kernel<4>(float const*, float*, int, int, int, int)") == "wgrad_reduce_kernel"

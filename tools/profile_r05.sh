@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-5 judged artefacts.  usage: [PARTS="stats pmc"] tools/profile_r05.sh [tag]   (writes gpurun_out/<tag>/..., copies the summaries into
-# profiles/; the whole script is ~ 18 minutes of GPU time: PARTS=stats (kernel traces) and PARTS=pmc (counter passes + bench line + reports)
-# run it in two calls)
+# Round-5 judged artefacts.  usage: [PARTS="stats pmc reports"] tools/profile_r05.sh [tag]   (writes gpurun_out/<tag>/..., copies the summaries into
+# profiles/; the whole script is ~ 18 minutes of GPU time: PARTS=stats (kernel traces), PARTS=pmc (counter passes -> r05_traffic.json) and
+# PARTS=reports (bench line + parity / trajectory reports) run in separate calls)
 #   r05_<cfg>_train_serial_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the train steps with non-overlapping launches
 #                                             (GMK_WGRAD_STREAM=0): the averages that compare with the bench line's HIP events
 #   r05_bench_kernel_stats.csv                the default `python bench.py` command (all configs, samplers, overlapping streams)
@@ -13,7 +13,7 @@ TAG=${1:-r05}
 OUT=/tmp/gmk_$TAG                 # raw traces are hundreds of MB: they stay on the box; only the summaries travel
 KEEP=gpurun_out/$TAG
 REPO=$(pwd)
-PARTS=${PARTS:-stats pmc}
+PARTS=${PARTS:-stats pmc reports}
 mkdir -p $OUT $KEEP profiles
 cd /tmp && export TMPDIR=/tmp
 cd $REPO
@@ -32,7 +32,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- p
 cp $(find $OUT/bench -name "*kernel_stats.csv" | head -1) profiles/r05_bench_kernel_stats.csv
 echo "bench stats done"
 fi
-[[ " $PARTS " == *" pmc "* ]] || { cp profiles/r05_*kernel_stats.csv $KEEP/; exit 0; }
+if [[ " $PARTS " == *" stats "* ]]; then cp profiles/r05_*kernel_stats.csv $KEEP/; fi
+if [[ " $PARTS " == *" pmc "* ]]; then
 for cfg in cfg2 cfg1 cfg3 cfg4; do      # every single-GPU configuration of the bench line gets its own counter passes (cfg4 since round 4)
   i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
@@ -56,11 +57,14 @@ for cfg in ("cfg2", "cfg1", "cfg3", "cfg4"):
 json.dump(out, open("profiles/r05_traffic.json", "w"), indent=1)
 PY
 echo "traffic done"
+cp profiles/r05_traffic.json $KEEP/
+fi
+[[ " $PARTS " == *" reports "* ]] || exit 0
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 cp $OUT/bench.json profiles/r05_bench.json                     # the compact line (what the driver parses)
 cp gpurun_out/bench_detail.json profiles/r05_bench_detail.json   # the full record of the same run
 python tests/parity_report.py > profiles/r05_parity_report.txt 2>/dev/null || exit 1
 python tests/trajectory_report.py 150 2>/dev/null | grep -v "^oracle step" > profiles/r05_trajectory_report.txt || exit 1
-if [[ " $PARTS " == *" stats "* ]]; then cp profiles/r05_* $KEEP/; else cp profiles/r05_traffic.json profiles/r05_bench.json profiles/r05_bench_detail.json profiles/r05_parity_report.txt profiles/r05_trajectory_report.txt $KEEP/; fi
+cp profiles/r05_bench.json profiles/r05_bench_detail.json profiles/r05_parity_report.txt profiles/r05_trajectory_report.txt $KEEP/
 cp $OUT/*.log $OUT/bench.err $KEEP/ 2>/dev/null
 tail -c 300 $OUT/bench.json
