@@ -378,6 +378,232 @@ __global__ __launch_bounds__(512, 2) void attn_fused_fwd_kernel(const bf16_t* __
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused backward of the same core (round 5): given dO, recompute P = softmax(scale Q K^T) block by block and produce dQ, dK, dV without any
+// N x N matrix in HBM (the three-kernel path stored P [B][N][N] in bf16 and a fp32 dP of the same shape).  Two kernels on the forward's
+// skeleton, one workgroup per sample, 32 rows per wave, bf16 operands, fp32 accumulation, everything deterministic (no atomics):
+//   attn_bwd_dq_kernel    K and V staged in LDS; wave w owns QUERIES 32 w ..: pass 1 = S^T = K Q^T for the row statistics (maximum, sum - the
+//                         forward's own arithmetic) and D_i = sum_c dO_ic O_ic; pass 2 per 32-key block: S^T again, dP^T = V dO^T, dS^T = scale P^T
+//                         (dP^T - D) in registers = the B operand of dQ^T += K^T dS^T (K^T by transposed LDS reads, as V^T in the forward).  Leaves
+//                         (log2-domain LSE, D) per query in a small fp32 table for the second kernel.
+//   attn_bwd_dkv_kernel   Q and dO staged in LDS; wave w owns KEYS 32 w ..: per 32-query block S = Q K^T and dP = dO V^T with the query on the
+//                         accumulator row, P = exp2(s c - LSE), dS = scale P (dP - D); P and dS, rounded pairwise, are the B operands of
+//                         dV^T += dO^T P and dK^T += Q^T dS.
+// LDS image of a staged [N][128] bf16 matrix: row * 256 B, 16-byte chunk ch at ((ch ^ (row & 15)) << 4) (conflict-free row reads; the transposed
+// reads take some bank conflicts on it - the block is < 1 % of a step).  The fp8 forward's backward runs here too: the gradient of the bf16 attention
+// at the same q, k, v (straight-through for the e4m3 rounding).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_rows_bf16(char* dst, const bf16_t* src, int ld, int N, int tid) {
+    for (int idx = tid; idx < N * 16; idx += 512) {
+        const int row = idx >> 4, ch = idx & 15;
+        *reinterpret_cast<bf16x8*>(dst + row * 256 + ((ch ^ (row & 15)) << 4)) = *reinterpret_cast<const bf16x8*>(src + (size_t)row * ld + ch * 8);
+    }
+}
+// A operand [m = 32 channels d of block db][k = 16 rows of the staged matrix, in the k order of a score block's registers 8 s .. 8 s + 7]:
+// rows 32 blk + 16 s + 4 (gg >> 1) + qq (+ 8), columns d = 32 db + 16 (gg & 1) + ... (the forward's V^T read, on the row image)
+__device__ __forceinline__ bf16x8 read_transposed(const char* img, int blk, int s, int db, int lane) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int gg = lane >> 4, i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+    const int c0 = 4 * db + 2 * (gg & 1) + (pp >> 1);
+    const int row0 = blk * 32 + 16 * s + 4 * (gg >> 1) + qq, row1 = row0 + 8;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)(img + row0 * 256 + ((c0 ^ (row0 & 15)) << 4) + 8 * (pp & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)(img + row1 * 256 + ((c0 ^ (row1 & 15)) << 4) + 8 * (pp & 1)));
+    const s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, av);
+}
+__device__ __forceinline__ bf16x8 round8(const f32x16& v, int s) {
+    const bf16x8 t = {(bf16_t)v[8 * s], (bf16_t)v[8 * s + 1], (bf16_t)v[8 * s + 2], (bf16_t)v[8 * s + 3],
+                      (bf16_t)v[8 * s + 4], (bf16_t)v[8 * s + 5], (bf16_t)v[8 * s + 6], (bf16_t)v[8 * s + 7]};
+    return t;
+}
+
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                            const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
+                                                            float* __restrict__ stats, int N, float scale, float c_log2e) {
+    constexpr int C = 128;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 256 * 256];
+    char* Ks = smem;
+    char* Vs = smem + N * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x;
+    const bf16_t* base = qkv + (size_t)b * N * (3 * C);
+    stage_rows_bf16(Ks, base + C, 3 * C, N, tid);
+    stage_rows_bf16(Vs, base + 2 * C, 3 * C, N, tid);
+    __syncthreads();
+    if (wave * 32 >= N) return;
+    const int nkb = N >> 5;
+    const int qi = wave * 32 + r;
+    // B operands of this lane: query qi, channels d = 16 kg + 8 h .. + 7
+    bf16x8 qf[8], dof[8];
+    const bf16_t* qrow = base + (size_t)qi * (3 * C);
+    const bf16_t* dorow = dout + ((size_t)b * N + qi) * C;
+    const bf16_t* orow = o + ((size_t)b * N + qi) * C;
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        qf[kg] = *reinterpret_cast<const bf16x8*>(qrow + kg * 16 + h * 8);
+        dof[kg] = *reinterpret_cast<const bf16x8*>(dorow + kg * 16 + h * 8);
+    }
+    // ---- D = sum_c dO O over the query's 128 channels (this lane holds 64 of them, lane ^ 32 the others)
+    float D = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(orow + kg * 16 + h * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) D = fmaf((float)dof[kg][e], (float)of[e], D);
+    }
+    { float a = D, bq = D; halves_swap32(a, bq); D = a + bq; }
+    // ---- pass 1: the row statistics of S^T = K Q^T (the forward's arithmetic)
+    float mx = -3.0e38f, sum = 0.f;
+    {
+        f32x16 sc[8];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[kb][e] = 0.f;
+            if (kb < nkb) {
+                const int key = kb * 32 + r;
+#pragma unroll
+                for (int kg = 0; kg < 8; ++kg) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + key * 256 + (((kg * 2 + h) ^ (key & 15)) << 4));
+                    sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kg], sc[kb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[kb][e]);
+            }
+        }
+        { float a = mx, bq = mx; halves_swap32(a, bq); mx = fmaxf(a, bq); }
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb)
+            if (kb < nkb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum += __builtin_amdgcn_exp2f((sc[kb][e] - mx) * c_log2e);
+            }
+        { float a = sum, bq = sum; halves_swap32(a, bq); sum = a + bq; }
+    }
+    const float inv = 1.0f / sum;
+    if (h == 0) {
+        float* st = stats + ((size_t)b * N + qi) * 2;
+        st[0] = mx * c_log2e + __builtin_amdgcn_logf(sum);        // log2-domain LSE: P = exp2(s c - st[0])   (v_log_f32 is log2)
+        st[1] = D;
+    }
+    // ---- pass 2: per key block S^T again, dP^T = V dO^T, dS^T, dQ^T += K^T dS^T
+    f32x16 oc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oc[db][e] = 0.f;
+#pragma unroll 1
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int key = kb * 32 + r;
+        f32x16 sv, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sv[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) {
+            const int off = key * 256 + (((kg * 2 + h) ^ (key & 15)) << 4);
+            sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Ks + off), qf[kg], sv, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Vs + off), dof[kg], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float pe = __builtin_amdgcn_exp2f((sv[e] - mx) * c_log2e) * inv;
+            sv[e] = scale * pe * (dp[e] - D);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 dsf = round8(sv, s);
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                oc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_transposed(Ks, kb, s, db, lane), dsf, oc[db], 0, 0, 0);
+        }
+    }
+    // ---- dQ[b][q][d] into columns [0, C) of dqkv, d = 32 db + 8 g + 4 h + (0..3)
+    bf16_t* drow = dqkv + ((size_t)b * N + qi) * (3 * C);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bf16x4 t = {(bf16_t)oc[db][4 * g], (bf16_t)oc[db][4 * g + 1], (bf16_t)oc[db][4 * g + 2], (bf16_t)oc[db][4 * g + 3]};
+            *reinterpret_cast<bf16x4*>(drow + db * 32 + 8 * g + 4 * h) = t;
+        }
+}
+
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                             const float* __restrict__ stats, bf16_t* __restrict__ dqkv, int N, float scale,
+                                                             float c_log2e) {
+    constexpr int C = 128;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 256 * 256];
+    char* Qs = smem;
+    char* Gs = smem + N * 256;                                 // dO
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x;
+    const bf16_t* base = qkv + (size_t)b * N * (3 * C);
+    stage_rows_bf16(Qs, base, 3 * C, N, tid);
+    stage_rows_bf16(Gs, dout + (size_t)b * N * C, C, N, tid);
+    __syncthreads();
+    if (wave * 32 >= N) return;
+    const int nqb = N >> 5;
+    const int ki = wave * 32 + r;
+    const bf16_t* krow = base + (size_t)ki * (3 * C) + C;
+    const bf16_t* vrow = krow + C;
+    const float* st = stats + (size_t)b * N * 2;
+    f32x16 dvc[4], dkc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dvc[db][e] = 0.f; dkc[db][e] = 0.f; }
+#pragma unroll 1
+    for (int qb = 0; qb < nqb; ++qb) {
+        const int qrow = qb * 32 + r;
+        f32x16 sv, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sv[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) {      // B operands: this lane's key, channels 16 kg + 8 h .. (re-read per block: L1 / L2 hits; 64 registers otherwise)
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + kg * 16 + h * 8);
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vrow + kg * 16 + h * 8);
+            const int off = qrow * 256 + (((kg * 2 + h) ^ (qrow & 15)) << 4);
+            sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Qs + off), kf, sv, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Gs + off), vf, dp, 0, 0, 0);
+        }
+        // accumulator element e = 4 g + j belongs to query 32 qb + 8 g + 4 h + j: its LSE and D from the table of the first kernel
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float* sp = st + (size_t)(qb * 32 + 8 * g + 4 * h) * 2;
+            const f32x4 s01 = *reinterpret_cast<const f32x4*>(sp), s23 = *reinterpret_cast<const f32x4*>(sp + 4);
+            const float lse[4] = {s01[0], s01[2], s23[0], s23[2]}, Dq[4] = {s01[1], s01[3], s23[1], s23[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pe = __builtin_amdgcn_exp2f(sv[4 * g + j] * c_log2e - lse[j]);
+                sv[4 * g + j] = pe;
+                dp[4 * g + j] = scale * pe * (dp[4 * g + j] - Dq[j]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 pf = round8(sv, s), dsf = round8(dp, s);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                dvc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_transposed(Gs, qb, s, db, lane), pf, dvc[db], 0, 0, 0);
+                dkc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_transposed(Qs, qb, s, db, lane), dsf, dkc[db], 0, 0, 0);
+            }
+        }
+    }
+    bf16_t* drow = dqkv + ((size_t)b * N + ki) * (3 * C);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bf16x4 tk = {(bf16_t)dkc[db][4 * g], (bf16_t)dkc[db][4 * g + 1], (bf16_t)dkc[db][4 * g + 2], (bf16_t)dkc[db][4 * g + 3]};
+            const bf16x4 tv = {(bf16_t)dvc[db][4 * g], (bf16_t)dvc[db][4 * g + 1], (bf16_t)dvc[db][4 * g + 2], (bf16_t)dvc[db][4 * g + 3]};
+            *reinterpret_cast<bf16x4*>(drow + C + db * 32 + 8 * g + 4 * h) = tk;
+            *reinterpret_cast<bf16x4*>(drow + 2 * C + db * 32 + 8 * g + 4 * h) = tv;
+        }
+}
+
 }  // namespace
 
 extern "C" int gmk_attention_fwd(const void* qkv, void* o, void* p_out, int B, int N, int C, float scale, int fp8, void* stream) {
@@ -387,6 +613,17 @@ extern "C" int gmk_attention_fwd(const void* qkv, void* o, void* p_out, int B, i
     if (fp8) attn_fused_fwd_kernel<true><<<B, 512, 0, gmk_stream(stream)>>>((const bf16_t*)qkv, (bf16_t*)o, (bf16_t*)p_out, N, c_log2e);
     else attn_fused_fwd_kernel<false><<<B, 512, 0, gmk_stream(stream)>>>((const bf16_t*)qkv, (bf16_t*)o, (bf16_t*)p_out, N, c_log2e);
     return gmk_check_launch("gmk_attention_fwd");
+}
+
+extern "C" int gmk_attention_bwd(const void* qkv, const void* o, const void* d_o, void* dqkv, float* stats, int B, int N, int C, float scale,
+                                 void* stream) {
+    GMK_REQUIRE(qkv && o && d_o && dqkv && stats && B > 0, "gmk_attention_bwd: bad arguments");
+    GMK_REQUIRE(C == 128 && (N == 64 || N == 128 || N == 256), "gmk_attention_bwd: needs C = 128 and N in {64, 128, 256} tokens (got C=%d N=%d)", C, N);
+    const float c_log2e = scale * 1.4426950408889634f;
+    hipStream_t st = gmk_stream(stream);
+    attn_bwd_dq_kernel<<<B, 512, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, (bf16_t*)dqkv, stats, N, scale, c_log2e);
+    attn_bwd_dkv_kernel<<<B, 512, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)d_o, stats, (bf16_t*)dqkv, N, scale, c_log2e);
+    return gmk_check_launch("gmk_attention_bwd");
 }
 
 extern "C" int gmk_bgemm_nt(const void* A, int64_t a_batch, int64_t lda, const void* B, int64_t b_batch, int64_t ldb, void* C,

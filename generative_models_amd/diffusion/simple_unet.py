@@ -538,7 +538,8 @@ class SimpleUnet(nn.Module):
         t = qkv.view(B, N, 3 * C)
         q, k, v = t[:, :, :C], t[:, :, C:2 * C], t[:, :, 2 * C:]
         if T == torch.bfloat16 and N in (64, 128, 256):       # fused: K / V resident in LDS, no fp32 score matrix in HBM
-            o, Pm = ops.attention_fwd(t, C ** -0.5, want_p=ctx is not None, fp8=self.attention_fp8)
+            # (the fused backward recomputes P in registers: nothing N x N is kept for it)
+            o, Pm = ops.attention_fwd(t, C ** -0.5, want_p=ctx is not None and not ops.attention_bwd_fused_ok(t), fp8=self.attention_fp8)
             o = o.view(B, H, W, C)
         else:
             S = ops.bgemm_nt(q, k, out_dtype=torch.float32)
@@ -563,13 +564,16 @@ class SimpleUnet(nn.Module):
         self._wgrad(dout, [o], 1, ops.NORMAL, G["attn.proj.weight"])
         do = self._conv([dout], self._packs["attn.proj"][1], C, 1, ops.NORMAL, (H, W)).view(B, N, C)
         # o = P v,  P = softmax(scale * q k^T)
-        dP = ops.bgemm_nt(do, v, out_dtype=torch.float32)
-        dS = ops.softmax_bwd(Pm, dP, scale)
-        dqkv = torch.empty_like(qkv)
-        d3 = dqkv.view(B, N, 3 * C)
-        ops.bgemm_nt(ops.transpose_last2(Pm), ops.transpose_last2(do), out=d3[:, :, 2 * C:])     # dv = P^T do
-        ops.bgemm_nt(dS, ops.transpose_last2(k), out=d3[:, :, :C])                               # dq = dS k
-        ops.bgemm_nt(ops.transpose_last2(dS), ops.transpose_last2(q), out=d3[:, :, C:2 * C])     # dk = dS^T q
+        if Pm is None:          # fused backward: P recomputed block by block in registers (gmk_attention_bwd), no [B, N, N] tensor anywhere
+            dqkv = ops.attention_bwd(t, o.view(B, N, C), do.contiguous()).view(qkv.shape)
+        else:
+            dP = ops.bgemm_nt(do, v, out_dtype=torch.float32)
+            dS = ops.softmax_bwd(Pm, dP, scale)
+            dqkv = torch.empty_like(qkv)
+            d3 = dqkv.view(B, N, 3 * C)
+            ops.bgemm_nt(ops.transpose_last2(Pm), ops.transpose_last2(do), out=d3[:, :, 2 * C:])     # dv = P^T do
+            ops.bgemm_nt(dS, ops.transpose_last2(k), out=d3[:, :, :C])                               # dq = dS k
+            ops.bgemm_nt(ops.transpose_last2(dS), ops.transpose_last2(q), out=d3[:, :, C:2 * C])     # dk = dS^T q
         # (q, k, v) = conv1x1(a)
         G["attn.qkv.bias"].copy_(dqkv.float().sum((0, 1, 2)))        # 3C-channel bias gradient: tiny, off the hot path
         self._wgrad(dqkv, [a], 1, ops.NORMAL, G["attn.qkv.weight"])

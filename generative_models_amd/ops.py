@@ -833,6 +833,24 @@ def transpose_last2(x, out=None):
     return out
 
 
+def attention_bwd_fused_ok(qkv):
+    """True if the fused backward of the attention core takes this shape (bf16, C = 128, N in {64, 128, 256}): the forward then need not keep P."""
+    return qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and qkv.shape[2] == 384 and qkv.shape[1] in (64, 128, 256) and \
+        os.environ.get("GMK_ATTN_BWD", "fused") != "gemm"
+
+
+def attention_bwd(qkv, o, do):
+    """(dq | dk | dv) [B, N, 3C] of o = softmax(scale q k^T) v given do, with P recomputed in registers (gmk_attention_bwd): no N x N matrix in HBM."""
+    _chk(qkv, torch.bfloat16, "qkv"); _chk(o, torch.bfloat16, "o"); _chk(do, torch.bfloat16, "do")
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    assert o.shape == (B, N, C) and do.shape == (B, N, C)
+    dqkv = torch.empty_like(qkv)
+    stats = torch.empty((B, N, 2), device=qkv.device, dtype=torch.float32)
+    check(lib.gmk_attention_bwd(_p(qkv), _p(o), _p(do), _p(dqkv), _p(stats), B, N, C, float(C ** -0.5), _s()), "attention_bwd")
+    return dqkv
+
+
 def softmax_fwd(S, scale, dtype):
     """softmax(scale * S) over the last dimension; S fp32 contiguous -> P in `dtype`."""
     _f32(S, "S")

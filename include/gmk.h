@@ -290,6 +290,11 @@ int gmk_softmax_fwd(const float* S, void* P, int64_t rows, int N, float scale, i
  * probabilities the backward pass needs) is given.  fp8 != 0: both contractions on the fp8 (OCP e4m3) matrix cores with fp32
  * accumulation - BASELINE config 5's "fp8 MFMA".  C = 128, N in {64, 128, 256}. */
 int gmk_attention_fwd(const void* qkv, void* o, void* p_out, int B, int N, int C, float scale, int fp8, void* stream);
+/* fused backward of the same core (round 5): dqkv [B][N][3C] (bf16) = (dq | dk | dv) given d_o [B][N][C] (bf16), the forward's inputs qkv and output o.
+ * P is recomputed block by block in registers: no N x N matrix in HBM (the three-kernel path kept P [B][N][N] and a fp32 dP of that shape).  stats:
+ * fp32 scratch [B][N][2] (log2-domain LSE and sum_c dO O per query, written by the first of the two kernels).  bf16 arithmetic with fp32 accumulation
+ * also behind the fp8 forward (straight-through for the e4m3 rounding); deterministic.  C = 128, N in {64, 128, 256}. */
+int gmk_attention_bwd(const void* qkv, const void* o, const void* d_o, void* dqkv, float* stats, int B, int N, int C, float scale, void* stream);
 int gmk_softmax_bwd(const void* P, const float* dP, void* dS, int64_t rows, int N, float scale, int dtype, void* stream);
 
 /* ---- progressive distillation (gaussian_diffusion.py:87-91,105-154) ------------------------------------------ */

@@ -184,7 +184,7 @@ def test_fp8_attention_net_vs_bf16_attention_net():
     a, b = net1.forward_hip(z, l, y, None), net2.forward_hip(z, l, y, None)
     e = rel_err(b, a)
     assert 0 < e < 2e-2, e
-    # training through the fp8 forward: the backward consumes the stored probabilities as before
+    # training through the fp8 forward: the fused backward recomputes P in bf16 from the same q, k (straight-through for the e4m3 rounding)
     ctx = {}
     out = net2.forward_hip(z, l, y, None, ctx=ctx)
     net2.backward_hip(ctx, torch.randn_like(out))

@@ -150,3 +150,49 @@ def test_fused_groupnorm_forward_equals_materialised_forward(net):
     finally:
         ops.GN_FUSE, ops.GN_FUSE_MIN_HW = keep, keep_min
     assert torch.equal(fused, plain) and torch.equal(fused, train_fwd)
+
+
+def test_subpixel_forms_are_each_others_adjoints_at_the_headline_size():
+    """BASELINE configs[2]'s largest resampling level (B = 2048, 16x16 <-> 32x32, C = 128), where no CPU reference runs in seconds: the three
+    sub-pixel forms of `Upsample` (reference simple_unet.py:112-122) and the stride-2 pair (:75-84) are checked through the identities that tie
+    them together - the data gradient is the adjoint of the forward, <conv(x), dy> = <x, dgrad(dy)>; the weight gradient is the derivative in
+    w, <dW, w> = <conv(x; w), dy>; the transposed form is the adjoint of the stride-2 forward - inner products accumulated in fp64 over 268 M
+    products each, 16-bit storage of every result."""
+    import math
+    from generative_models_amd import ops
+    Bh, Sl = 2048, 16
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((Bh, Sl, Sl, C), generator=g).cuda().bfloat16()
+    dy = torch.randn((Bh, 2 * Sl, 2 * Sl, C), generator=g).cuda().bfloat16()
+    w = (torch.randn((C, C, 3, 3), generator=g) / math.sqrt(9 * C)).cuda()
+    wsub, wsub_d = torch.empty(16 * C * C, device="cuda", dtype=torch.bfloat16), torch.empty(16 * C * C, device="cuda", dtype=torch.bfloat16)
+    ops.pack_upsample_weight(w, wsub, wsub_d)
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    assert ops.conv_subpixel_ok(Bh, Sl, Sl, C, torch.bfloat16) and ops.conv_wgrad_subpixel_ok(Bh, Sl, Sl, C, torch.bfloat16)
+    y = ops.conv_subpixel(x, wsub, C, ops.SUBPIXEL_UPSAMPLE)
+    dx = ops.conv_subpixel(dy, wsub_d, C, ops.SUBPIXEL_UPSAMPLE_DGRAD)
+    dw = torch.empty((C, C, 3, 3), device="cuda")
+    ops.conv_wgrad_subpixel(dy, x, dw)
+    a, b_, c = dot(y, dy), dot(x, dx), dot(dw, w)
+    # <y, dy> of independent tensors is a random-walk sum: its size, and the size of what the 16-bit roundings of y / dx / the weight packs (2^-9
+    # relative each, independent) add to it, is |y| |dy| / sqrt(N) - expected difference 1 - 2e-3 of that, bar 1e-2
+    unit = math.sqrt(float(y.double().pow(2).sum()) * float(dy.double().pow(2).sum()) / y.numel())
+    assert abs(a - b_) < 1e-2 * unit, (a, b_, unit)
+    assert abs(a - c) < 1e-2 * unit, (a, c, unit)
+    # linearity of the forward in its input (fp32 accumulation, one rounding): conv(x1 + x2) = conv(x1) + conv(x2) up to the 16-bit roundings
+    x2 = torch.randn((Bh, Sl, Sl, C), generator=g).cuda().bfloat16()
+    xs = (x.float() + x2.float()).bfloat16()
+    lhs = ops.conv_subpixel(xs, wsub, C, ops.SUBPIXEL_UPSAMPLE).float()
+    rhs = y.float() + ops.conv_subpixel(x2, wsub, C, ops.SUBPIXEL_UPSAMPLE).float() + \
+        ops.conv_subpixel((xs.float() - x.float() - x2.float()).bfloat16(), wsub, C, ops.SUBPIXEL_UPSAMPLE).float()
+    assert float((lhs - rhs).abs().max() / lhs.abs().max()) < 2e-2
+    # stride-2 pair: <conv_s2(xh), dyl> = <xh, transposed(dyl)>
+    xh = dy                                                          # a high-resolution tensor
+    dyl = x                                                          # a low-resolution one
+    wf, wd = torch.empty(w.numel(), device="cuda", dtype=torch.bfloat16), torch.empty(w.numel(), device="cuda", dtype=torch.bfloat16)
+    ops.pack_conv_weight(w, wf, wd)
+    ys2 = ops.conv_igemm([xh], wf, C, 3, ops.STRIDE2, (Sl, Sl))
+    dxh = ops.conv_subpixel(dyl, wd, C, ops.SUBPIXEL_TRANSPOSED)
+    a2, b2 = dot(ys2, dyl), dot(xh, dxh)
+    unit2 = math.sqrt(float(ys2.double().pow(2).sum()) * float(dyl.double().pow(2).sum()) / ys2.numel())
+    assert abs(a2 - b2) < 1e-2 * unit2, (a2, b2, unit2)

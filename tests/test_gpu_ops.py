@@ -887,3 +887,38 @@ def test_upsample_wgrad_subpixel(ops, xdt, S, B):
     dw2 = torch.empty_like(dw)
     ops.conv_wgrad_subpixel(dyd, xd, dw2)
     assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize("N", [64, 128, 256])
+@pytest.mark.parametrize("sharp", [1.0, 3.0])
+def test_fused_attention_backward(ops, N, sharp):
+    """gmk_attention_bwd (BASELINE configs[4]'s block, round 5): (dq | dk | dv) of o = softmax(q k^T / sqrt(C)) v with P recomputed block by block in
+    registers - no N x N matrix in HBM - against torch autograd in fp32 on the same bf16 inputs, and against the three-kernel path it replaces
+    (batched GEMMs + softmax backward on a stored bf16 P, fp32 dP): measured closer to autograd than that path (P is not rounded to bf16 before dV
+    and dS), from soft to sharp softmax; deterministic."""
+    B, C = 5, 128
+    g = torch.Generator().manual_seed(N)
+    qkv = (torch.randn((B, N, 3 * C), generator=g) * sharp).bfloat16()
+    do = torch.randn((B, N, C), generator=g).bfloat16()
+    scale = C ** -0.5
+    t = qkv.float().requires_grad_(True)
+    q, k, v = (t[:, :, i * C:(i + 1) * C] for i in range(3))
+    oref = torch.einsum("bij,bjc->bic", torch.softmax(torch.einsum("bic,bjc->bij", q, k) * scale, dim=-1), v)
+    oref.backward(do.float())
+    qd, dod = qkv.cuda(), do.cuda()
+    o, P = ops.attention_fwd(qd, scale, want_p=True)
+    assert ops.attention_bwd_fused_ok(qd)
+    d = ops.attention_bwd(qd, o, dod)
+    err = lambda a, b: float((a.float().cpu() - b).abs().max() / b.abs().max())
+    errs = [err(d[:, :, i * C:(i + 1) * C], t.grad[:, :, i * C:(i + 1) * C]) for i in range(3)]
+    assert max(errs) < 1.5e-2, errs
+    # the three-kernel path on the stored P
+    dP = ops.bgemm_nt(dod, qd[:, :, 2 * C:], out_dtype=torch.float32)
+    dS = ops.softmax_bwd(P, dP, scale)
+    d3 = torch.empty_like(qd)
+    ops.bgemm_nt(ops.transpose_last2(P), ops.transpose_last2(dod), out=d3[:, :, 2 * C:])
+    ops.bgemm_nt(dS, ops.transpose_last2(qd[:, :, C:2 * C]), out=d3[:, :, :C])
+    ops.bgemm_nt(ops.transpose_last2(dS), ops.transpose_last2(qd[:, :, :C]), out=d3[:, :, C:2 * C])
+    errs3 = [err(d3[:, :, i * C:(i + 1) * C], t.grad[:, :, i * C:(i + 1) * C]) for i in range(3)]
+    assert all(a <= b_ + 3e-3 for a, b_ in zip(errs, errs3)), (errs, errs3)
+    assert torch.equal(d, ops.attention_bwd(qd, o, dod))

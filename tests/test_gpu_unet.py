@@ -530,7 +530,9 @@ def test_attention_extension_vs_oracle(dtype):
     net.backward_hip(ctx, dout.cuda())
     for name in ("attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "attn.norm.weight", "attn.norm.bias",
                  "turn.out_layers.3.weight", "down.seq.1.in_layers.2.weight", "up.seq.0.0.in_layers.2.weight", "time_embed.0.weight"):
-        # (the extension's fp32 path at the bar of the outputs; bf16 internals of the block: measured 2.1e-2 on attn.qkv.weight)
+        # (the extension's fp32 path at the bar of the outputs.  16-bit mode: measured over three input seeds 0.9 - 1.6e-2, 2.8e-2 once on attn.norm.weight -
+        # the bf16 gradient storage of the surrounding net, not the block: the fused backward of round 5 (P recomputed in registers) and the
+        # three-kernel path on a stored bf16 P (GMK_ATTN_BWD=gemm) give the same numbers to two digits)
         assert rel_err(net.grad(name), pr[name].grad) < (1 if dtype == torch.float32 else 3) * tol, name
     # without the flag nothing changes: 160 tensors, reference names only
     assert len(SimpleUnet(128, 0.0).state_dict()) == 160
