@@ -237,6 +237,10 @@ extern "C" int gmk_mean(const float* x, int n, float* out, void* stream) {
 }
 
 static int gemm_ksplit(int M, int N, int K, int* kchunk) {
+    // Short contractions (K <= 256: the Linears of the embedding MLPs and the 12 emb_layers, one ROW per sample) decide their split as if M were 512,
+    // whatever it is: a sample's embedding then does not depend on how many other samples share its launch (round 5: the sampler runs large batches
+    // as two halves on two streams and has to produce the same bits; before, M = 2048 ran unsplit and M = 1024 in four K-chunks - one ulp apart).
+    if (K <= 256) M = 512;
     const int tiles = ((N + TN - 1) / TN) * ((M + TM - 1) / TM);
     int nz = 1;
     if (tiles < 128 && K >= 256) {

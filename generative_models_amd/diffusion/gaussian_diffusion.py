@@ -279,7 +279,72 @@ class GaussianDiffusion:
         w = ops.aligned(as_vec(w)) if w is not None else None
         if w is not None and guide is None:
             raise ValueError("classifier-free guidance needs class labels (net must carry guide=)")
-        z_t = ops.aligned(init_x.float())
+        z_all = ops.aligned(init_x.float())
+        n1 = int(np.prod(init_x.shape[1:]))
+        # Large batches run as TWO half-batches on two HIP streams (round 5): the chains of different samples never meet (GroupNorm is per
+        # sample, the update is elementwise), and a persistent kernel's start-up and tail - about one tile time per launch, ~ 80 launches per
+        # forward - then overlap with the other half's kernels: -2.4 ... -3.0 % per forward at the bench configurations (tools/two_stream_probe.py;
+        # four quarters are slower than one batch), the same bits.  Small batches (the captured-graph path) and odd batches stay on one stream.
+        K = 1
+        if dev.type == "cuda" and self.SAMPLER_STREAMS >= 2 and B % 2 == 0 and ((B // 2) * n1) % 4 == 0 and \
+                (B // 2) * init_x.shape[2] * init_x.shape[3] >= self.STREAM_MIN_PIXELS:
+            K = 2
+        bounds = [(k * B // K, (k + 1) * B // K) for k in range(K)]
+        cut = lambda t, a, b_: None if t is None else ops.aligned(t[a:b_])
+        offs = []                      # Philox counter of each step's noise draw for the WHOLE batch (ancestral sampler): chunks take their slice of it
+        need_rng = self.sampler == "noisy" and noises is None
+        cur = torch.cuda.current_stream() if dev.type == "cuda" else None
+        streams = [cur] if K == 1 else self._chunk_streams(dev, K)
+        gens = []
+        for k, (a, b_) in enumerate(bounds):
+            args = (module, cut(guide, a, b_), cut(student_w, a, b_), cut(w, a, b_), cut(z_all, a, b_),
+                    None if noises is None else noises[:, a:b_], record, offs, a * n1 // 4)
+            gens.append(self._sample_chunk(*args))
+        if K > 1:
+            for st in streams:
+                st.wait_stream(cur)
+
+        def advance():
+            outs = []
+            for k in range(K):
+                if K > 1:
+                    with torch.cuda.stream(streams[k]):
+                        outs.append(next(gens[k]))
+                else:
+                    outs.append(next(gens[k]))
+            return outs
+        for _ in range(self.num_steps):
+            if need_rng:
+                offs.append(self.rng._take(B * n1))
+            advance()
+            if K > 1:                                   # the throttle's event has to cover both halves
+                for st in streams:
+                    cur.wait_stream(st)
+            ops.throttle()                              # at most two sampler iterations queued on the GPU (see ops.throttle)
+        res = advance()                                 # the chunks' results
+        if K == 1:
+            return res[0]
+        for st in streams:
+            cur.wait_stream(st)
+        for r in res:
+            for t in r:
+                if t is not None:
+                    t.record_stream(cur)
+        return tuple(None if res[0][j] is None else torch.cat([r[j] for r in res], dim=1) for j in range(3))
+
+    SAMPLER_STREAMS = int(os.environ.get("GMK_SAMPLER_STREAMS", "2"))            # 1: every batch on one stream (A/B switch)
+    STREAM_MIN_PIXELS = 1 << 18                                                  # images x H x W of a half-batch
+
+    def _chunk_streams(self, dev, K):
+        if getattr(self, "_streams", None) is None or len(self._streams) < K or self._streams[0].device != dev:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
+        return self._streams[:K]
+
+    def _sample_chunk(self, module, guide, student_w, w, z_t, noises, record, offs, q0):
+        """The sampler loop over one (chunk of a) batch as a generator: one `next` per step (everything it launches goes to the stream current at
+        that call), then one more for the result.  offs[it] / q0: Philox counter of step `it`'s whole-batch noise draw / this chunk's offset in it."""
+        B = z_t.shape[0]
+        dev = z_t.device
         zs, xs, es = [], [], []
         guided = w is not None
         nb = 2 * B if guided else B
@@ -305,14 +370,16 @@ class GaussianDiffusion:
                 v, vu = v2[:B], v2[B:]
             noise = None
             if self.sampler == "noisy":
-                noise = ops.aligned(noises[i]) if noises is not None else self.rng.normal(z_t.shape, dev)   # :241
+                noise = ops.aligned(noises[i]) if noises is not None else ops.rng_normal(tuple(z_t.shape), self.rng.seed, offs[it] + q0, dev)   # :241
             z_t, xp, ep = ops.sampler_step(v, z_t, lt, ls, i == 0, v_uncond=vu, cond_w=w, noise=noise, want_pred=record, mean_type=self.mean_type,
                                            dup=guided, logsnr_next=lnext)
             if guided:
                 z_t, z2 = z_t
             if record:
                 zs.append(z_t); xs.append(xp); es.append(ep)
-            ops.throttle()                              # at most two sampler iterations queued on the GPU (see ops.throttle)
+            yield None
         if record:
-            return torch.stack(zs), torch.stack(xs), torch.stack(es)
-        return z_t[None], None, None
+            yield torch.stack(zs), torch.stack(xs), torch.stack(es)
+        else:
+            yield z_t[None], None, None
+

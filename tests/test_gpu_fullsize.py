@@ -196,3 +196,40 @@ def test_subpixel_forms_are_each_others_adjoints_at_the_headline_size():
     a2, b2 = dot(ys2, dyl), dot(xh, dxh)
     unit2 = math.sqrt(float(ys2.double().pow(2).sum()) * float(dyl.double().pow(2).sum()) / ys2.numel())
     assert abs(a2 - b2) < 1e-2 * unit2, (a2, b2, unit2)
+
+
+@pytest.mark.parametrize("kind,cond_w", [("ddim", None), ("ddim", 0.5), ("noisy", None)])
+def test_sampler_on_two_streams_is_bit_identical(net, kind, cond_w):
+    """Round 5: batches of at least 2 x 256 Ki pixels sample as two half-batches on two HIP streams (the start-up and tail of one half's persistent
+    kernels overlap with the other half's kernels: -2.4 ... -3.0 % per forward).  The chains of different samples never meet, so the images -
+    every intermediate z, x-hat and eps-hat of the recorded trajectory - must be the SAME BITS as on one stream: DDIM, guided DDIM (2B-image
+    forwards per half) and the ancestral sampler, whose per-step noise is one Philox draw over the whole batch that the halves slice by counter."""
+    from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    _, y, _, eps = data(2)
+    outs = []
+    for streams in (1, 2):
+        d = GaussianDiffusion(mean_type="v", num_steps=4, sampler=kind, seed=11)
+        d.SAMPLER_STREAMS = streams
+        assert (B // 2) * S * S >= d.STREAM_MIN_PIXELS
+        outs.append(d.sample(net=partial(net, guide=y), init_x=eps, cond_w=cond_w, net_cond_w=None if cond_w is None else torch.full((B,), cond_w).cuda()))
+        last = d.sample(net=partial(net, guide=y), init_x=eps, cond_w=cond_w, net_cond_w=None if cond_w is None else torch.full((B,), cond_w).cuda(),
+                        record=False)[0][-1]
+        if kind != "noisy":                      # (the ancestral sampler's second call draws fresh noise)
+            assert torch.equal(last, outs[-1][0][-1])
+    for a, b in zip(*outs):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert bool(torch.isfinite(outs[0][0]).all())
+
+
+def test_embedding_rows_do_not_depend_on_the_batch_size(net):
+    """What the two-stream sampler's bit-identity rests on besides per-sample GroupNorm: a sample's embedding (time / guide MLPs -> the 12 emb_layers, fp32
+    GEMMs) is the same bits whatever batch it is computed in - the K-split of the short contractions is decided independently of M (round 5; before,
+    a batch of 2048 and one of 1024 differed in the last bit)."""
+    g = torch.Generator().manual_seed(3)
+    for nb in (24, 100, 256, 512, 1024, 2048, 4096):
+        ll = (torch.randn((nb,), generator=g) * 3).cuda()
+        yy = torch.randint(-1, 10, (nb,), generator=g).cuda()
+        full = net._embed_fwd(ll, yy, None, None)
+        for a, b in ((0, nb // 2), (nb // 2, nb), (nb // 4, min(nb, nb // 4 + 100))):
+            part = net._embed_fwd(ll[a:b].clone(), yy[a:b].clone(), None, None)
+            assert torch.equal(full[a:b], part), (nb, a, b)
