@@ -37,7 +37,7 @@ if [[ " $PARTS " == *" pmc "* ]]; then
 for cfg in cfg2 cfg1 cfg3 cfg4; do      # every single-GPU configuration of the bench line gets its own counter passes (cfg4 since round 4)
   i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
-    rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$cfg/g$i -o pmc -- python bench.py --config $cfg --others 0 --steps 3 --warmup 1 --sampler_steps 2 --sampler_steps_other 2 --no_cpu --no_profile > $OUT/pmc_${cfg}_g$i.log 2>&1 || exit 1
+    rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$cfg/g$i -o pmc -- python bench.py --config $cfg --others 0 --steps 3 --warmup 1 --sampler_steps 0 --no_cpu --no_profile > $OUT/pmc_${cfg}_g$i.log 2>&1 || exit 1
     i=$((i+1))
   done
   python tools/traffic_parse.py $OUT/pmc_$cfg > $OUT/pmc_$cfg/kernels.json || exit 1
@@ -52,7 +52,7 @@ for cfg in ("cfg2", "cfg1", "cfg3", "cfg4"):
     out[cfg] = {"kernel_hash": bench.kernel_hash(), "kernels": json.load(open("$OUT/pmc_%s/kernels.json" % cfg)),
                 "provenance": "rocprofv3 --pmc, three separate passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) of "
                 "'bench.py --config %s --others 0 --steps 3 --warmup 1 --sampler_steps 2' (tools/profile_r05.sh); FETCH_SIZE doubled (gfx950, 16-B/lane "
-                "streaming reads: MI355X_MICROARCH.md HBM); bytes averaged over the kernel's launches of 4 train steps + 6 sampler forwards; "
+                "streaming reads: MI355X_MICROARCH.md HBM); bytes averaged over the kernel's launches of 4 train steps (no sampler launches: the sampler runs half-batches); "
                 "sclk_ghz_est = GRBM_GUI_ACTIVE per XCD / dispatch time of the same pass (tools/traffic_parse.py)" % cfg}
 json.dump(out, open("profiles/r05_traffic.json", "w"), indent=1)
 PY
