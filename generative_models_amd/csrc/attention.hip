@@ -561,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         f32x16 sv, dp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { sv[e] = 0.f; dp[e] = 0.f; }
-#pragma unroll
+#pragma unroll 2
         for (int kg = 0; kg < 8; ++kg) {      // B operands: this lane's key, channels 16 kg + 8 h .. (re-read per block: L1 / L2 hits; 64 registers otherwise)
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + kg * 16 + h * 8);
             const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vrow + kg * 16 + h * 8);

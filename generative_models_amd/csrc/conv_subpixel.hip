@@ -36,8 +36,8 @@ constexpr int kWOFF = 2 * kHB;                 // weight ring offset
 constexpr int kWST = 16384;
 
 struct SubParams {
-    const void* src;                           // low-resolution source [B][H][W][128]
-    int B, H, W, WE, R, TP, ntiles, M;         // low-resolution grid; M = B * H * W
+    const void* src;                           // LOW -> HIGH: the low-resolution source [B][H][W][128]; HIGH -> LOW: the high-resolution gradient [B][2H][2W][128]
+    int B, H, W, WE, R, TP, ntiles, M;         // the LOW-resolution grid in every mode; M = B * H * W
     const void* w; unsigned w_tap_stride_b; int n0;
     const float* bias; const void* residual; void* out; int out_cstride;
     unsigned nb0, nbw, nbo;
@@ -53,11 +53,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 __device__ __forceinline__ int div_small(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
 
 // ---- the K-step plan of a tile (compile time) -----------------------------------------------------------------------------------------
+struct Step { int ph, a, b, dy, dx, ptap, half, buf, first_ph, last_ph; };      // parity (order index, a, b), low-resolution offset, pack index, channel half, half-buffer
 // kMode 0: upsample (parities in order (0,0) (0,1) (1,0) (1,1), 4 taps each, pack index 4 (2a + b) + 2 ty + tx, dy = a - 1 + ty, dx = b - 1 + tx)
 // kMode 1: transposed (parity order (1,1) (1,0) (0,0) (0,1): the 4-tap parity first and a 2-tap one last, so the fill windows are 4 and 2 steps, and the two
 //          column parities of an output row - adjacent 256-byte pixels - are written back to back;
 //          per axis: parity 0 meets tap 1 (offset 0), parity 1 meets tap 0 (offset 0) and tap 2 (offset +1); pack index 3 ty + tx)
-struct Step { int ph, a, b, dy, dx, ptap, half, buf, first_ph, last_ph; };
 // kMode 2: `Upsample` data gradient (HIGH -> LOW): segments (view (a, b), channel half) in order, 4 taps each; tap (ty, tx) of view (a, b) reads the
 //          view at low-resolution offset (1 - a - ty, 1 - b - tx) (the transpose of kMode 0's (a - 1 + ty, b - 1 + tx)); pack index as kMode 0;
 //          half-buffer = segment & 1; one accumulation over all 32 steps

@@ -29,7 +29,9 @@ int gmk_conv1x1_wgrad_stream_try(const void* dy, int dy_cstride, const void* src
                                  bool x_f16, hipStream_t stream);        // conv1x1_stream.hip: > 0 = slabs written
 int gmk_cu_limit(void);                   // workgroups a persistent kernel may occupy (gmk_set_cu_limit / GMK_CU_LIMIT, default 256)
 void gmk_note_kernel(int id);             // 1 conv_igemm_kernel, 2 conv_igemm_dma_kernel, 3 conv3x3_halo_kernel,
-                                          // 4 conv3x3_halo_ws_kernel, 5 halo kernel on a zero-stuffed source, 6 stride-2 dgrad as four phase launches of the LDS-DMA kernel, 11 conv_wgrad_kernel, 12 conv_wgrad_slots_kernel, 13 conv_wgrad_slots_ws_kernel,
+                                          // 4 conv3x3_halo_ws_kernel, 5 halo kernel on a zero-stuffed source, 6 stride-2 dgrad as four phase launches of the LDS-DMA kernel, 7 halo kernel with the folded 1x1 skip
+                                          // convolution, 8 / 9 / 10 conv_subpixel_ws_kernel (upsample / transposed / upsample data gradient), 11 conv_wgrad_kernel, 12 conv_wgrad_slots_kernel, 13 conv_wgrad_slots_ws_kernel,
+                                          // 14 / 15 conv1x1_pair_stream_kernel / conv1x1_wgrad_stream_kernel, 16 conv_wgrad_subpixel_ws_kernel,
                                           // 21 gn_silu_fwd_reg_kernel, 22 gn_silu_fwd_kernel, 23 gn_silu_bwd_hybrid_kernel, 24 gn_silu_bwd_kernel
 
 #define GMK_REQUIRE(cond, ...)                 \
