@@ -910,7 +910,7 @@ def test_fused_attention_backward(ops, N, sharp):
     d = ops.attention_bwd(qd, o, dod)
     err = lambda a, b: float((a.float().cpu() - b).abs().max() / b.abs().max())
     errs = [err(d[:, :, i * C:(i + 1) * C], t.grad[:, :, i * C:(i + 1) * C]) for i in range(3)]
-    assert max(errs) < 1.5e-2, errs
+    assert max(errs) < 1e-2, errs                  # the 16-bit bar at 1x (measured 2.4e-3 ... 6.3e-3)
     # the three-kernel path on the stored P
     dP = ops.bgemm_nt(dod, qd[:, :, 2 * C:], out_dtype=torch.float32)
     dS = ops.softmax_bwd(P, dP, scale)
