@@ -476,6 +476,7 @@ class SimpleUnet(nn.Module):
                              tsc[:, i * C:(i + 1) * C], tsh[:, i * C:(i + 1) * C])
             h = self._conv(srcs, wf1, C, 3, ops.NORMAL, (H, W), gn=(tsc, tsh))
             if fold and ops.SKIP_FOLD_OVER_FUSE:      # the fold and the in-convolution GroupNorm do not combine (yet): conv2's input is materialised
+                self._emb_ready()
                 a2, _, _ = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], self._g1, xadd=eadd)
                 return conv2_folded(a2)
             if fold:          # GMK_SKIP_FOLD_FUSE=fuse: conv2 keeps its in-convolution GroupNorm, the skip convolution its own launch
@@ -483,6 +484,7 @@ class SimpleUnet(nn.Module):
                                          bias=P[f"{name}.skip_connection.bias"])
             t2c = torch.empty((B, C), device=h.device, dtype=torch.float32)
             t2h = torch.empty_like(t2c)
+            self._emb_ready()
             ops.gn_stats(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], self._g1, t2c, t2h, xadd=eadd)
             if len(srcs) == 2:
                 res = skip["res"]
@@ -504,6 +506,7 @@ class SimpleUnet(nn.Module):
         if dropping:      # mask = Philox uniform >= p, regenerated by the backward kernel
             drop = (self.dropout, self.drop_seed, self._drop_counter)
             self._drop_counter += (h.numel() + 3) // 4
+        self._emb_ready()
         a2, mean2, rstd2 = ops.gn_silu_fwd(h, P[f"{name}.out_layers.0.weight"], P[f"{name}.out_layers.0.bias"], self._g1, dropout=drop,
                                            xadd=eadd)
         if fold:
@@ -609,6 +612,14 @@ class SimpleUnet(nn.Module):
         for t in tensors:
             t.record_stream(side)
 
+    def _emb_ready(self):
+        """Join the side stream if the embedding path of this forward is still pending there (forward_hip, GMK_EMB_SIDE): its first consumer follows."""
+        pend = getattr(self, "_emb_pending", None)
+        if pend is not None:
+            self._emb_pending = None
+            self._join_side()
+            pend.record_stream(torch.cuda.current_stream())
+
     def _join_side(self):
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
@@ -669,7 +680,15 @@ class SimpleUnet(nn.Module):
             raise ValueError(f"input {tuple(x.shape)}: need {self.in_channels} channels and H, W divisible by 4")
         x = ops.aligned(x.float())
         logsnr, guide, cond_w = ops.aligned(logsnr), ops.aligned(guide), ops.aligned(cond_w)
-        emb_all = self._embed_fwd(logsnr, guide, cond_w, ctx)
+        # The embedding path (a dozen tiny fp32 kernels, ~ 0.2 ms of launch-bound work) is first needed by the SECOND GroupNorm of the first ResBlock:
+        # with GMK_EMB_SIDE=1 it runs on the side stream beside the stem, the first GroupNorm and conv1, and is joined right before its first use
+        if ops.EMB_SIDE and ops.WGRAD_STREAM and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+            box = []
+            self._on_side(lambda: box.append(self._embed_fwd(logsnr, guide, cond_w, ctx)), tuple(t for t in (logsnr, guide, cond_w) if t is not None))
+            emb_all = box[0]
+            self._emb_pending = emb_all
+        else:
+            emb_all = self._embed_fwd(logsnr, guide, cond_w, ctx)
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         t0 = ops.stem_fwd(x, P["down.seq.0.conv.weight"], P["down.seq.0.conv.bias"], C, T)
         t1 = self._res_fwd("down.seq.1", [t0], emb_all, 0, ctx)

@@ -181,6 +181,7 @@ GN_FUSE_MIN_HW = int(os.environ.get("GMK_GN_FUSE_MIN_HW", "2048"))
 # GroupNorm inside the convolution (64-pixel rows), prefer that to the fold (the two do not combine yet)
 SKIP_FOLD = os.environ.get("GMK_SKIP_FOLD", "1") != "0"
 SKIP_FOLD_OVER_FUSE = os.environ.get("GMK_SKIP_FOLD_FUSE", "fold") != "fuse"
+EMB_SIDE = os.environ.get("GMK_EMB_SIDE", "1") == "1"          # the embedding path of a forward on the side stream (simple_unet.forward_hip; round 5: +0.7 % DDIM steps/s, +0.2 % train)
 FWD_SIDE = os.environ.get("GMK_FWD_SIDE", "0") == "1"          # forward 1x1 skip convolutions on the side stream (simple_unet._res_fwd)
 WGRAD_CUS = int(os.environ.get("GMK_WGRAD_CUS", "0"))           # > 0: the side stream's persistent grids take this many CUs, the data-gradient chain's the rest
 WGRAD_STREAM = os.environ.get("GMK_WGRAD_STREAM", "1") != "0"    # weight gradients on a side stream beside the data-gradient chain (simple_unet._wgrad)
