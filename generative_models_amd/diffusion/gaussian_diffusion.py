@@ -286,7 +286,7 @@ class GaussianDiffusion:
         # forward - then overlap with the other half's kernels: -2.4 ... -3.0 % per forward at the bench configurations (tools/two_stream_probe.py;
         # four quarters are slower than one batch), the same bits.  Small batches (the captured-graph path) and odd batches stay on one stream.
         K = 1
-        if dev.type == "cuda" and self.SAMPLER_STREAMS >= 2 and B % 2 == 0 and ((B // 2) * n1) % 4 == 0 and \
+        if dev.type == "cuda" and self.SAMPLER_STREAMS >= 2 and B % 2 == 0 and ((B // 2) * n1) % 4 == 0 and (noises is None or isinstance(noises, torch.Tensor)) and \
                 (B // 2) * init_x.shape[2] * init_x.shape[3] >= self.STREAM_MIN_PIXELS:
             K = 2
         bounds = [(k * B // K, (k + 1) * B // K) for k in range(K)]
@@ -298,7 +298,7 @@ class GaussianDiffusion:
         gens = []
         for k, (a, b_) in enumerate(bounds):
             args = (module, cut(guide, a, b_), cut(student_w, a, b_), cut(w, a, b_), cut(z_all, a, b_),
-                    None if noises is None else noises[:, a:b_], record, offs, a * n1 // 4)
+                    noises if (noises is None or K == 1) else torch.as_tensor(noises)[:, a:b_], record, offs, a * n1 // 4)
             gens.append(self._sample_chunk(*args))
         if K > 1:
             for st in streams:
