@@ -206,7 +206,7 @@ def _compact_sampler(s):
 
 
 def _compact_exchange(e):
-    return _pick(e, ("world", "backend", "rccl_version", "bucket_bytes", "persistent_kernel_cus", "rccl_max_channels", "exposed_ms", "ab")) if e else None
+    return _pick(e, ("world", "backend", "forced", "rccl_version", "bucket_bytes", "persistent_kernel_cus", "rccl_max_channels", "exposed_ms", "ab")) if e else None
 
 
 def compact_line(full, detail_path=None):
@@ -278,7 +278,16 @@ class Bench:
         assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
         torch.cuda.set_device(local)
         self.dev = torch.device("cuda", local)
-        if self.world > 1:
+        # GMK_FORCE_EXCHANGE=1 with one rank (round 6): a ONE-rank RCCL communicator, so that the bucketed all-reduces run from the exchange
+        # stream beside the backward pass on the one GPU a box has (parallel.exchanging); the record's `exchange` block says "forced"
+        self.forced = self.world == 1 and os.environ.get("GMK_FORCE_EXCHANGE", "0") == "1"
+        if self.forced and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local))
+        if self.world > 1 or self.forced:
             from generative_models_amd.parallel import configure_rccl_env
             configure_rccl_env()                     # RCCL's channel count = the CUs the persistent kernels leave free
             if self.backend == "nccl":
@@ -441,9 +450,9 @@ class Bench:
             out["steady_state"] = {"value": round(self.world * B * n_steady / e2, 1), "steps": n_steady, "warmup": warmup + steps,
                                    "ms_per_step": round(e2 / n_steady * 1e3, 3)}
         torch.cuda.synchronize()
-        exchange = sync.describe() if self.world > 1 else None      # exposed_ms of the timed loops above
+        exchange = sync.describe() if parallel.exchanging() else None      # exposed_ms of the timed loops above
         ab = None
-        if headline and self.world > 1:
+        if headline and parallel.exchanging():
             # the first hardware scaling run gets BOTH carve-out settings in one shot (the judge's round-3 item 6): 20 timed steps with
             # GMK_RCCL_CUS CUs (default 8) left to RCCL while buckets are in flight, 20 with the persistent kernels on the whole chip
             ab = {}
@@ -474,6 +483,8 @@ class Bench:
                     "noisy (ancestral), guidance off":
                         {"steps_per_sec": self.time_sampler(model, y, init, "noisy", None, T_other), "timed_steps": T_other}}}
         out["exchange"] = exchange
+        if exchange is not None:
+            out["exchange"]["issued_last_step"] = [{"bucket": k, "bytes": 4 * (e - s_), "persistent_kernel_cus_behind_it": lim} for k, s_, e, lim in sync.last_issued]
         if ab:
             out["exchange"]["ab"] = ab
         del model, batches
@@ -497,8 +508,12 @@ class Bench:
         if a.config == "auto" and self.world == 1 and a.others and a.dtype == "bf16":
             # what the north_star's 1e-3 bar costs: the headline workload in the fp32 mode (fp32 storage, exact-fp32 MFMA chains, peak 157 TFLOP/s),
             # a short loop - 3 warm-up + 10 timed steps, no sampler
-            others["cfg2_fp32"] = self.run_config("cfg2", CONFIGS["cfg2"], 10, 3, False, dtype="fp32", sampler=False)
-            others["cfg2_fp32"]["dtype"] = "fp32"
+            try:                     # an optional record must never cost the headline line
+                others["cfg2_fp32"] = self.run_config("cfg2", CONFIGS["cfg2"], 10, 3, False, dtype="fp32", sampler=False)
+                others["cfg2_fp32"]["dtype"] = "fp32"
+            except Exception as exc:
+                torch.cuda.empty_cache()
+                others["cfg2_fp32"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         cpu = None
         if self.rank == 0 and self.world == 1 and not a.no_cpu:
             cpu = cpu_baseline(a.cpu_seconds, plan[0][1][1], plan[0][1][0])
@@ -538,7 +553,7 @@ class Bench:
                 shown = None
             sys.stdout.flush()
             print(compact_line(line, shown), flush=True)
-        if self.world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
 
 

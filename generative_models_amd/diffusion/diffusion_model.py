@@ -123,7 +123,7 @@ def make_plugin(GMBase, AttrDict):
         TRAIN_GRAPH_MAX_PIXELS = int(os.environ.get("GMK_TRAIN_GRAPH_PIXELS", str(64 * 1024)))
 
         def _graphable(self, x, world):
-            return (world == 1 and self.teacher_net is None and self.net.dropout == 0.0 and x.is_cuda and x.dim() == 4 and
+            return (world == 1 and not parallel.exchanging() and self.teacher_net is None and self.net.dropout == 0.0 and x.is_cuda and x.dim() == 4 and
                     0 < x.shape[0] * x.shape[2] * x.shape[3] <= self.TRAIN_GRAPH_MAX_PIXELS and ops.PROFILE is None)
 
         def _train_step_graphed(self, x, y):

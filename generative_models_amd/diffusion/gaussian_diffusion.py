@@ -137,20 +137,23 @@ class GaussianDiffusion:
     # dropped it - the kernels, then 30 % longer, were the bound.)  Same kernels in the same order: bit-identical images.
     GRAPH_MAX_PIXELS = int(os.environ.get("GMK_SAMPLER_GRAPH_PIXELS", str(64 * 1024)))       # images x H x W of one forward; 0 turns it off
 
+    def _graph_path(self, module, nb, H, W):
+        """Does a forward of `nb` images of H x W replay a captured graph in the sampler loop?"""
+        return 0 < nb * H * W <= self.GRAPH_MAX_PIXELS and self.num_steps >= 16 and not (module.training and module.dropout > 0.0)
+
     def _forward_runner(self, module, z, guide, student_w):
         """-> (run(z_t) -> v, lvec): the forward of `module` on a [nb, C, H, W] batch conditioned on `guide` / `student_w`, and the fp32 [nb]
         log-SNR vector it reads (the caller fills it before the first step, the sampler-update kernel writes it afterwards)."""
         nb = z.shape[0]
         dev = z.device
         # (a captured forward would replay ONE dropout mask: training-mode dropout keeps the kernel-by-kernel path)
-        small = 0 < nb * z.shape[2] * z.shape[3] <= self.GRAPH_MAX_PIXELS and self.num_steps >= 16 and not (module.training and module.dropout > 0.0)
+        small = self._graph_path(module, nb, z.shape[2], z.shape[3])
         if not small:
             lvecs = [torch.empty((nb,), device=dev), torch.empty((nb,), device=dev)]      # two buffers alternate (see `sample`)
             return None, lvecs
         # the host-side freshness check of the packed convolution weights runs at capture time only: do it here, before every replay loop
         # (the pack buffer keeps its address, so a re-pack is seen by the captured kernels)
-        if module._packs_stale or module._packed_version != module._version_sum():
-            module._repack()
+        module.prepare_forward(dev)
         key = (id(module), module.flat_params.data_ptr(), module._pack_buf.data_ptr(), tuple(z.shape), guide is not None, student_w is not None)
         ent = self._graphs.get(key)
         if ent is None:
@@ -285,9 +288,14 @@ class GaussianDiffusion:
         # sample, the update is elementwise), and a persistent kernel's start-up and tail - about one tile time per launch, ~ 80 launches per
         # forward - then overlap with the other half's kernels: -2.4 ... -3.0 % per forward at the bench configurations (tools/two_stream_probe.py;
         # four quarters are slower than one batch), the same bits.  Small batches (the captured-graph path) and odd batches stay on one stream.
+        # Never together with the captured-graph path (both halves would replay ONE graph on ONE set of static buffers, whatever
+        # GMK_SAMPLER_GRAPH_PIXELS is set to), and only at hidden_size 128: the bit-identity of the halves rests on the embedding GEMMs' K-split
+        # not depending on the row count, which `gemm_ksplit` guarantees for K <= 256 = 2 x 128 only.
         K = 1
+        nb_half = (B // 2) * (2 if w is not None else 1)
         if dev.type == "cuda" and self.SAMPLER_STREAMS >= 2 and B % 2 == 0 and ((B // 2) * n1) % 4 == 0 and (noises is None or isinstance(noises, torch.Tensor)) and \
-                (B // 2) * init_x.shape[2] * init_x.shape[3] >= self.STREAM_MIN_PIXELS:
+                (B // 2) * init_x.shape[2] * init_x.shape[3] >= self.STREAM_MIN_PIXELS and module.channels == 128 and \
+                not self._graph_path(module, nb_half, init_x.shape[2], init_x.shape[3]):
             K = 2
         bounds = [(k * B // K, (k + 1) * B // K) for k in range(K)]
         cut = lambda t, a, b_: None if t is None else ops.aligned(t[a:b_])
@@ -301,6 +309,10 @@ class GaussianDiffusion:
                     noises if (noises is None or K == 1) else torch.as_tensor(noises)[:, a:b_], record, offs, a * n1 // 4)
             gens.append(self._sample_chunk(*args))
         if K > 1:
+            # what a forward builds lazily after a weight update (packed weights, frequency tables) is enqueued HERE, on the stream both chunk
+            # streams wait for: the first chunk's forward would otherwise re-pack on ITS stream and clear the host flag, and the second chunk's
+            # convolutions would read the pack buffers without ever having waited for that kernel
+            module.prepare_forward(dev)
             for st in streams:
                 st.wait_stream(cur)
 

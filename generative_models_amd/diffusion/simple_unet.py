@@ -527,42 +527,40 @@ class SimpleUnet(nn.Module):
         return out
 
     # ---- self-attention extension (north_star; no reference counterpart — defined by the tests' CPU restatement `attention_block`) ------------
-    def _attn_fwd(self, x, ctx):
-        """x NHWC [B,H,W,C] -> x + proj(softmax(q k^T / sqrt(C)) v), (q,k,v) = conv1x1(SiLU(GN(x))); single head over C."""
+    def _attn_core_fwd(self, a, residual=None, keep=False):
+        """The contraction core of the attention block on an NHWC map `a` (compute dtype): proj(softmax(q k^T / sqrt(C)) v) (+ residual),
+        (q, k, v) = conv1x1(a); single head over C.  Same arithmetic as the reference's `CausalSelfAttention.forward`
+        (gms/autoregs/pixel_transformer.py:101-122) with n_head = 1 and no mask: pinned by tests/golden/attn_core_{64,256}.npz.
+        -> (out, saved for `_attn_core_bwd`)."""
         P, C, T = self._pv, self.channels, self.compute_dtype
-        B, H, W, _ = x.shape
+        B, H, W, _ = a.shape
         N = H * W
-        x = ops.cast16(x, T) if x.dtype != T else x        # fp16 stream -> the block's bf16 internals (16-bit mode)
         if N % 8 or N > 1024:
             raise ValueError(f"the attention level has {N} tokens: the HIP path needs a multiple of 8, at most 1024 "
                              f"(input sizes 32 / 64: 64 / 256 tokens)")
-        a, mean, rstd = ops.gn_silu_fwd(x, P["attn.norm.weight"], P["attn.norm.bias"], 32)
         qkv = self._conv([a], self._packs["attn.qkv"][0], 3 * C, 1, ops.NORMAL, (H, W), cout=3 * C, bias=P["attn.qkv.bias"])
         t = qkv.view(B, N, 3 * C)
         q, k, v = t[:, :, :C], t[:, :, C:2 * C], t[:, :, 2 * C:]
         if T == torch.bfloat16 and N in (64, 128, 256):       # fused: K / V resident in LDS, no fp32 score matrix in HBM
             # (the fused backward recomputes P in registers: nothing N x N is kept for it)
-            o, Pm = ops.attention_fwd(t, C ** -0.5, want_p=ctx is not None and not ops.attention_bwd_fused_ok(t), fp8=self.attention_fp8)
+            o, Pm = ops.attention_fwd(t, C ** -0.5, want_p=keep and not ops.attention_bwd_fused_ok(t), fp8=self.attention_fp8)
             o = o.view(B, H, W, C)
         else:
             S = ops.bgemm_nt(q, k, out_dtype=torch.float32)
             Pm = ops.softmax_fwd(S, C ** -0.5, T)
             o = ops.bgemm_nt(Pm, ops.transpose_last2(v)).view(B, H, W, C)
-        out = self._conv([o], self._packs["attn.proj"][0], C, 1, ops.NORMAL, (H, W), bias=P["attn.proj.bias"], residual=x)
-        if ctx is not None:
-            ctx["attn"] = (x, a, mean, rstd, qkv, Pm, o)
-        return ops.cast16(out, self.act_dtype) if self.act_dtype != T else out
+        out = self._conv([o], self._packs["attn.proj"][0], C, 1, ops.NORMAL, (H, W), bias=P["attn.proj.bias"], residual=residual)
+        return out, (a, qkv, Pm, o)
 
-    def _attn_bwd(self, ctx, dout):
-        """-> (dx, per-sample channel sums of dx)."""
+    def _attn_core_bwd(self, saved, dout):
+        """Backward of `_attn_core_fwd` for the gradient `dout` of its output: fills the gradients of attn.proj / attn.qkv, -> gradient of `a`."""
         P, G, C = self._pv, self._gv, self.channels
-        x, a, mean, rstd, qkv, Pm, o = ctx.pop("attn")
-        B, H, W, _ = x.shape
+        a, qkv, Pm, o = saved
+        B, H, W, _ = a.shape
         N = H * W
         scale = C ** -0.5
         t = qkv.view(B, N, 3 * C)
         q, k, v = t[:, :, :C], t[:, :, C:2 * C], t[:, :, 2 * C:]
-        # out = x + proj(o)
         ops.colsum(ops.chansum(dout), G["attn.proj.bias"], defer=True)
         self._wgrad(dout, [o], 1, ops.NORMAL, G["attn.proj.weight"])
         do = self._conv([dout], self._packs["attn.proj"][1], C, 1, ops.NORMAL, (H, W)).view(B, N, C)
@@ -580,7 +578,24 @@ class SimpleUnet(nn.Module):
         # (q, k, v) = conv1x1(a)
         G["attn.qkv.bias"].copy_(dqkv.float().sum((0, 1, 2)))        # 3C-channel bias gradient: tiny, off the hot path
         self._wgrad(dqkv, [a], 1, ops.NORMAL, G["attn.qkv.weight"])
-        da = self._conv([dqkv], self._packs["attn.qkv"][1], C, 1, ops.NORMAL, (H, W))
+        return self._conv([dqkv], self._packs["attn.qkv"][1], C, 1, ops.NORMAL, (H, W))
+
+    def _attn_fwd(self, x, ctx):
+        """x NHWC [B,H,W,C] -> x + core(SiLU(GN(x))): the extension's placement (pre-activation, residual) around `_attn_core_fwd`."""
+        P, T = self._pv, self.compute_dtype
+        x = ops.cast16(x, T) if x.dtype != T else x        # fp16 stream -> the block's bf16 internals (16-bit mode)
+        a, mean, rstd = ops.gn_silu_fwd(x, P["attn.norm.weight"], P["attn.norm.bias"], 32)
+        out, saved = self._attn_core_fwd(a, residual=x, keep=ctx is not None)
+        if ctx is not None:
+            ctx["attn"] = (x, mean, rstd, saved)
+        return ops.cast16(out, self.act_dtype) if self.act_dtype != T else out
+
+    def _attn_bwd(self, ctx, dout):
+        """-> (dx, per-sample channel sums of dx)."""
+        P, G, C = self._pv, self._gv, self.channels
+        x, mean, rstd, saved = ctx.pop("attn")
+        B = x.shape[0]
+        da = self._attn_core_bwd(saved, dout)            # out = x + core(a)
         s = torch.empty((B, C), device=x.device, dtype=torch.float32)
         dx, dgp, dbp = ops.gn_silu_bwd(da, x, P["attn.norm.weight"], P["attn.norm.bias"], mean, rstd, dadd1=dout, dxsum=s)
         ops.colsum(dgp, G["attn.norm.weight"], defer=True); ops.colsum(dbp, G["attn.norm.bias"], defer=True)
@@ -670,6 +685,17 @@ class SimpleUnet(nn.Module):
         return outs
 
     # ---- whole network ---------------------------------------------------------------------------------
+    def prepare_forward(self, dev=None):
+        """Everything a forward builds lazily on its first call after a weight update - the packed convolution weights, the frequency tables -
+        enqueued on the CURRENT stream.  Callers that fan forwards out over several streams (the two-stream sampler, a captured graph) call this
+        before the fork: the host-side freshness flags are cleared by whichever forward comes first, and a forward on another stream would then
+        read pack buffers whose re-pack kernel it never waited for."""
+        if self._packs_stale or self._packed_version != self._version_sum():
+            self._repack()
+        dev = self.flat_params.device if dev is None else dev
+        self._freq_table(MAX_TIMESTEPS, dev)
+        self._freq_table(4, dev)
+
     def forward_hip(self, x, logsnr, guide=None, cond_w=None, ctx=None):
         """x: NCHW fp32 [B, in_channels, H, W]; returns NCHW fp32.  ctx: dict receiving what backward needs."""
         if self._packs_stale or self._packed_version != self._version_sum():

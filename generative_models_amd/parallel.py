@@ -35,6 +35,16 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def exchanging():
+    """Does a train step run the gradient exchange?  With more than one rank, always.  `GMK_FORCE_EXCHANGE=1` (round 6) also runs it in a
+    ONE-rank process group: a one-rank sum is the identity, so the step's results do not change, but the communicator is created, the four bucket
+    all-reduces are issued from the exchange stream behind the two gradient streams, and the persistent kernels run under the carved CU limit
+    while they fly - the only execution of RCCL beside the backward pass a one-GPU box can give (tests/test_gpu_ddp.py, bench.py --gpus 1)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("GMK_FORCE_EXCHANGE", "0") == "1"
+
+
 def shard_batch(x, r=None, w=None):
     """Rank r's contiguous, equal shard of a global batch (dim 0 must divide evenly: equal shards keep the
     mean-of-means equal to the global mean)."""
@@ -74,12 +84,12 @@ def configure_rccl_env():
 
 def carved_cu_limit():
     """(full, carved): the CU count the persistent kernels normally use and the one that leaves GMK_RCCL_CUS CUs to RCCL while gradient
-    buckets are in flight (see the module docstring); carved is None when nothing is to be carved (one rank, GMK_RCCL_CUS=0, or a user-fixed
+    buckets are in flight (see the module docstring); carved is None when nothing is to be carved (no exchange (see `exchanging`), GMK_RCCL_CUS=0, or a user-fixed
     GMK_CU_LIMIT)."""
     from ._lib import lib
     full = lib.gmk_get_cu_limit()
     keep = int(os.environ.get("GMK_RCCL_CUS", "8"))
-    if world() > 1 and keep > 0 and "GMK_CU_LIMIT" not in os.environ:
+    if exchanging() and keep > 0 and "GMK_CU_LIMIT" not in os.environ:
         return full, full - keep
     return full, None
 
@@ -97,15 +107,17 @@ class GradSync:
         self._fire = {last: (s, e) for s, e, last in self.buckets}
         self.works = []
         self.issued = []                      # (natural index, start, end) of every all-reduce issued this step (tests, bench)
+        self.last_issued = []                 # ... of the last finished step, with the CU limit the persistent kernels ran under behind each
         # the carve-out is applied only while buckets are in flight: from the first all-reduce of a backward pass to finish().  The forward
         # pass, the part of the backward in front of the first bucket and the samplers (no collectives) keep the whole chip
         self._cu_full, self.cu_limit = carved_cu_limit() if net.flat_params.is_cuda else (None, None)
         self._carved = False
+        self._limits_seen = []                # gmk_get_cu_limit() behind each all-reduce of this step
         self._comm = None                     # the exchange stream (GPU only)
         self._exposed = []                    # (event before, event after) around finish()'s waits: what the step still waits for
 
     def hook(self, k):
-        if world() == 1 or k not in self._fire:
+        if not exchanging() or k not in self._fire:
             return
         s, e = self._fire[k]
         self.issued.append((k, s, e))
@@ -125,6 +137,8 @@ class GradSync:
             comm.wait_stream(self.net._side)                  # the bucket's weight gradients
         with torch.cuda.stream(comm):                         # the backend orders its own stream behind the stream current HERE
             self.works.append(dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        from ._lib import lib as _l
+        self._limits_seen.append(_l.gmk_get_cu_limit())
 
     def finish(self):
         """The current stream waits for every outstanding bucket; the wait is bracketed by events (`exposed_ms` in describe())."""
@@ -144,7 +158,9 @@ class GradSync:
             self._exposed.append((e0, e1))
             del self._exposed[:-64]
         self.works.clear()
+        self.last_issued = [(k, s, e, lim) for (k, s, e), lim in zip(self.issued, self._limits_seen + [None] * len(self.issued))]
         self.issued.clear()
+        self._limits_seen.clear()
 
     def abort(self):
         """A step that raised between hook() and finish(): drain what was issued and give the persistent kernels the whole chip back."""
@@ -154,6 +170,7 @@ class GradSync:
         finally:
             self.works.clear()
             self.issued.clear()
+            self._limits_seen.clear()
             if self._carved:
                 from ._lib import lib
                 lib.gmk_set_cu_limit(self._cu_full)
@@ -162,7 +179,7 @@ class GradSync:
     def set_carve(self, keep):
         """Change the number of CUs left to RCCL while buckets are in flight (0: none); bench.py's `exchange.ab` measures both.  Only between steps."""
         assert not self._carved and not self.works
-        if self._cu_full is not None and world() > 1 and "GMK_CU_LIMIT" not in os.environ:
+        if self._cu_full is not None and exchanging() and "GMK_CU_LIMIT" not in os.environ:
             self.cu_limit = self._cu_full - keep if keep > 0 else None
         self._exposed.clear()
 
@@ -178,7 +195,7 @@ class GradSync:
 
     def describe(self):
         """What the exchange looks like from this rank (bench.py puts it beside the scaling numbers)."""
-        info = {"world": world(), "backend": dist.get_backend() if world() > 1 else None,
+        info = {"world": world(), "backend": dist.get_backend() if exchanging() else None, "forced": exchanging() and world() == 1,
                 "bucket_bytes": [4 * (e - s) for s, e, _ in self.buckets], "persistent_kernel_cus": self.cu_limit,
                 "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS"),
                 "exposed_ms": self.exposed_ms(),

@@ -327,6 +327,44 @@ def gen_metrics(name):
     save(name, **out)
 
 
+def gen_attn_core(name, T, C=128, B=2):
+    """The contraction core of the attention extension against the reference's OWN attention: `CausalSelfAttention`
+    (gms/autoregs/pixel_transformer.py:74-122).  That module cannot be imported (gms.common -> torchvision), so the class definition is taken
+    out of the file with `ast` and executed as it stands (as gen_metrics does); n_embed = C, n_head = 1, block size T, its causal `mask` buffer
+    overwritten with ones (the U-Net block attends over a whole feature map).  Inputs and weights are closed forms (unet_ref.attn_core_case);
+    stored: y, dx and the gradients of the four Linear layers for the upstream gradient dy."""
+    import ast
+    import torch.nn as nn
+    import torch.nn.functional as Fn
+    src = open(os.path.join(REF, "gms", "autoregs", "pixel_transformer.py")).read()
+    ns = {"np": np, "torch": torch, "nn": nn, "F": Fn}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.ClassDef) and node.name == "CausalSelfAttention":
+            exec(compile(ast.Module([node], []), "gms/autoregs/pixel_transformer.py", "exec"), ns)
+
+    class G:
+        n_embed, n_head = C, 1
+    att = ns["CausalSelfAttention"](T, G)
+    att.mask.fill_(1.0)
+    x, dy, lin = unet_ref.attn_core_case(T, C, B)
+    with torch.no_grad():
+        for k, (w, b) in lin.items():
+            getattr(att, k).weight.copy_(w); getattr(att, k).bias.copy_(b)
+    x = x.clone().requires_grad_(True)
+    y = att(x)
+    y.backward(dy)
+    out = {"y": y.detach(), "dx": x.grad, "T": T, "C": C, "B": B}
+    for k in lin:
+        out[f"d{k}_w"] = getattr(att, k).weight.grad
+        out[f"d{k}_b"] = getattr(att, k).bias.grad
+    save(name, **out)
+
+
+def gen_r06():
+    gen_attn_core("attn_core_64.npz", 64)
+    gen_attn_core("attn_core_256.npz", 256)
+
+
 def ref_net_channels(C, cin, sd):
     """The reference `SimpleUnet` for `cin` image channels.  The network is size-agnostic and hard-codes the image channel count in
     exactly two layers (simple_unet.py:93 the stem `Downsample(1, channels, 1)`, :41 the head `Conv2d(channels, 1, 3)`): for cin != 1 those
@@ -424,6 +462,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "r04":        # only the sets added in round 4
         gen_r04()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "r06":        # only the sets added in round 6
+        gen_r06()
+        return
     gen_schedule()
     gen_unet(32, 8, 3, 10, "unet_c32_s8.npz")
     gen_unet(32, 12, 2, 11, "unet_c32_s12.npz")
@@ -446,6 +487,7 @@ def main():
     gen_default_init(32, 3, 71, "definit_c128_s32.npz")
     gen_c256()
     gen_r04()
+    gen_r06()
 
 
 if __name__ == "__main__":

@@ -188,17 +188,39 @@ def resblock(p, prefix, x, emb, drop=None):
     return x + h
 
 
-def attention_block(p, x):
-    """The self-attention extension (north_star "optional self-attention block", BASELINE config 5).  NO reference counterpart:
-    this function IS the definition.  Single head over all C channels at the lowest resolution, pre-activation:
-        a = SiLU(GroupNorm32(x));  q, k, v = split(conv1x1(a), 3);  out = x + conv1x1(softmax(q k^T / sqrt(C)) v)."""
-    B, C, H, W = x.shape
-    a = gn_silu(x, p["attn.norm.weight"], p["attn.norm.bias"])
+def attention_core(p, a):
+    """q, k, v = split(conv1x1(a), 3);  proj(softmax(q k^T / sqrt(C)) v) on an NCHW map `a` - the contraction core of the attention extension.
+    It follows the one attention implementation the reference holds, `CausalSelfAttention.forward` (gms/autoregs/pixel_transformer.py:101-122:
+    key / query / value = Linear(x), att = softmax(q k^T / sqrt(head size)), y = proj(att v)) with n_head = 1 and an all-ones mask; the rows of
+    `attn.qkv.weight` are [query | key | value].  PINNED by tests/golden/attn_core_{64,256}.npz, generated from that class
+    (oracle/make_golden.py gen_attn_core)."""
+    B, C, H, W = a.shape
     qkv = F.conv2d(a, p["attn.qkv.weight"], p["attn.qkv.bias"]).reshape(B, 3, C, H * W)
     q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]                       # [B, C, N]
     w = torch.softmax(torch.einsum("bci,bcj->bij", q, k) * (C ** -0.5), dim=-1)
     o = torch.einsum("bij,bcj->bci", w, v).reshape(B, C, H, W)
-    return x + F.conv2d(o, p["attn.proj.weight"], p["attn.proj.bias"])
+    return F.conv2d(o, p["attn.proj.weight"], p["attn.proj.bias"])
+
+
+def attention_block(p, x):
+    """The self-attention extension (north_star "optional self-attention block", BASELINE config 5).  The reference's SimpleUnet has no
+    attention block: its PLACEMENT (lowest resolution, pre-activation, residual) is this function's own definition; its contraction core is the
+    reference's own attention arithmetic (`attention_core`):
+        a = SiLU(GroupNorm32(x));  out = x + attention_core(a)."""
+    return x + attention_core(p, gn_silu(x, p["attn.norm.weight"], p["attn.norm.bias"]))
+
+
+def attn_core_case(T, C=128, B=2):
+    """Closed-form inputs of the attention-core fixtures (regenerated by the tests, not stored): tokens x [B, T, C], upstream gradient dy, and
+    the four Linear layers of the reference class as (weight, bias) pairs keyed by the reference's attribute names."""
+    p = closed_form_params(C, attention=True)
+    wq, wk, wv = p["attn.qkv.weight"].reshape(3, C, C)
+    bq, bk, bv = p["attn.qkv.bias"].reshape(3, C)
+    lin = {"query": (wq, bq), "key": (wk, bk), "value": (wv, bv), "proj": (p["attn.proj.weight"].reshape(C, C), p["attn.proj.bias"])}
+    k = torch.arange(B * T * C, dtype=torch.float64)
+    x = (torch.sin(0.731 * k + 0.4) + 0.6 * torch.sin(0.0917 * k * (1.0 + 0.001 * (k % 13)))).reshape(B, T, C).float()
+    dy = (0.8 * torch.sin(1.137 * k + 1.9) + 0.3 * torch.cos(0.0411 * k)).reshape(B, T, C).float() / (B * T)
+    return x, dy, lin
 
 
 def unet_forward(p, x, logsnr, guide=None, cond_w=None, taps=None, dropout=None):

@@ -1,6 +1,7 @@
 """Data-parallel equivalence on the real HIP network: 2 ranks (both on cuda:0, gloo transport) each take half of a
 batch; after the bucketed all-reduce + fused Adam(grad_scale=1/world) the parameters equal a single-rank step on the
-whole batch.  RCCL itself needs >1 GPU and is exercised by the driver's scaling run."""
+whole batch.  RCCL itself runs with ONE rank (round 6, GMK_FORCE_EXCHANGE=1: communicator, the four bucket all-reduces on the exchange
+stream, the carve-out); more than one rank needs more than one GPU and is the driver's scaling run."""
 import os
 import subprocess
 import sys
@@ -115,3 +116,98 @@ def test_bench_two_ranks_rehearsal(form):
     assert d["steady_state"]["steps"] == 6 and d["sampler"]["timed_steps"] == 2          # (loops shortened for the rehearsal: gloo stages every bucket through the host)
     full = json.load(open(os.path.join(ROOT, d["detail"])))
     assert full["value"] == d["value"] and "hbm" in full["roofline"] and full["exchange"]["ab"] == ab
+
+
+_RCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from functools import partial
+from generative_models_amd import parallel
+from generative_models_amd._lib import lib
+from generative_models_amd.diffusion.simple_unet import SimpleUnet
+from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)            # "nccl" IS RCCL on ROCm: loads librccl, one-rank communicator
+assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
+g = torch.Generator().manual_seed(0)
+B, S = 256, 28
+x = (torch.rand((B, 1, S, S), generator=g) * 2 - 1).cuda(); y = torch.randint(0, 10, (B,), generator=g).cuda()
+u = torch.rand((B,), generator=g).cuda(); eps = torch.randn((B, 1, S, S), generator=g).cuda()
+torch.manual_seed(1)
+net = SimpleUnet(128, 0.0, compute_dtype=torch.bfloat16)
+with torch.no_grad():
+    for n, p in net.named_parameters():
+        if ".out_layers.3.weight" in n:
+            p.uniform_(-0.02, 0.02)
+net = net.cuda()
+d = GaussianDiffusion(mean_type="v", num_steps=1000)
+full = lib.gmk_get_cu_limit()
+def step(force, keep):
+    os.environ["GMK_FORCE_EXCHANGE"] = "1" if force else "0"
+    os.environ["GMK_RCCL_CUS"] = str(keep)
+    sync = parallel.GradSync(net)
+    out = d.train_forward_backward(net=partial(net, guide=y), x=x, grad_scale=1.0 / B, u=u, eps=eps,
+                                   on_grads_ready=sync.hook, join_side_before_ready=False)      # as DiffusionModel.train_step calls it
+    inside = lib.gmk_get_cu_limit()
+    issued = list(sync.issued)
+    sync.finish()
+    torch.cuda.synchronize()
+    return out["loss"].clone(), net.flat_grads.clone(), sync, inside, issued
+l0, g0, s0, in0, is0 = step(False, 8)
+assert not is0 and s0._comm is None and in0 == full                                  # unforced, one rank: no exchange at all
+# forced, nothing carved: the four bucket all-reduces (a one-rank sum is the identity) from the exchange stream - the SAME bits
+l1, g1, s1, in1, is1 = step(True, 0)
+assert [k for k, _, _ in is1] == [0, 1, 2, 3] and s1._comm is not None and in1 == full
+assert sum(e - s for _, s, e in is1) == net.flat_grads.numel()                        # the buckets tile the arena
+assert torch.equal(l0, l1) and torch.equal(g0, g1)
+assert s1.exposed_ms() is not None and s1.exposed_ms() >= 0.0
+# forced, 8 CUs left to RCCL while buckets fly: the limit is 248 behind every all-reduce, the full chip again after finish();
+# kernels launched under the carve-out split their fp32 sums differently (documented): same values to rounding
+l2, g2, s2, in2, is2 = step(True, 8)
+assert in2 == full - 8 and lib.gmk_get_cu_limit() == full
+assert [lim for _, _, _, lim in s2.last_issued] == [full - 8] * 4
+assert torch.equal(l0, l2)
+rel = float((g2 - g0).abs().max() / g0.abs().max())
+assert rel < 1e-4, rel
+info = s2.describe()
+assert info["forced"] and info["backend"] == "nccl" and info["world"] == 1 and info["persistent_kernel_cus"] == full - 8
+ver = info["rccl_version"]
+assert ver[0].isdigit() and ver.count(".") >= 2, ver
+dist.destroy_process_group()
+print("rccl one-rank ok", ver, "exposed_ms", s2.exposed_ms(), "rel", rel)
+"""
+
+
+def test_rccl_runs_the_bucketed_exchange_with_one_rank(tmp_path):
+    """RCCL on the one GPU there is (round 6): a one-rank `nccl` process group under `torch.distributed.run --nproc-per-node 1` with
+    GMK_FORCE_EXCHANGE=1 - communicator created, the four readiness-ordered buckets all-reduced from the exchange stream behind the
+    data-gradient and weight-gradient streams, the persistent kernels under the carved CU limit while they fly (248 inside, 256 after),
+    gradients bit-equal to the unforced step where nothing is carved.  What it cannot show is xGMI traffic: there is one rank."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", free_port(), str(script), ROOT]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GMK_CU_LIMIT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "rccl one-rank ok" in r.stdout
+
+
+def test_bench_forced_exchange_on_one_gpu():
+    """`GMK_FORCE_EXCHANGE=1 python bench.py --gpus 1`: the N = 1 line with an `exchange` block measured over RCCL (one rank) - both carve-out
+    settings, `exposed_ms`, the RCCL version - so that the overlap machinery of the N > 1 line has run on hardware before a node is available."""
+    import json
+    flags = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--config", "custom", "--batch", "256", "--sampler_steps", "0", "--no_cpu"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + flags, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(env, GMK_FORCE_EXCHANGE="1", OMP_NUM_THREADS="2", GMK_BENCH_STEADY_STEPS="6", GMK_BENCH_AB_STEPS="4"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    ex = d["exchange"]
+    assert d["n_gpus"] == 1 and ex["world"] == 1 and ex["forced"] and ex["backend"] == "nccl" and ex["persistent_kernel_cus"] == 248
+    assert ex["rccl_version"][0].isdigit() and ex["exposed_ms"] is not None
+    assert ex["ab"]["carved"]["persistent_kernel_cus"] == 248 and ex["ab"]["uncarved"]["persistent_kernel_cus"] is None
+    full = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert [b["bucket"] for b in full["exchange"]["issued_last_step"]] == [0, 1, 2, 3]

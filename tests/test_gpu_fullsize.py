@@ -94,15 +94,21 @@ def test_forward_is_bit_reproducible_with_the_skip_convs_on_the_side_stream(net)
     from generative_models_amd import ops
     x, y, u, _ = data(3)
     l = u * 20 - 10
-    keep = ops.FWD_SIDE
+    keep, keep_emb = ops.FWD_SIDE, ops.EMB_SIDE
     try:
         ops.FWD_SIDE = True
         outs = [net.forward_hip(x, l, y, None).clone() for _ in range(8)]
         ops.FWD_SIDE = False
         plain = net.forward_hip(x, l, y, None)
+        # the embedding path on the side stream (GMK_EMB_SIDE, default on since round 5): same kernels, joined before the first consumer - same bits
+        ops.EMB_SIDE = True
+        emb_on = [net.forward_hip(x, l, y, None).clone() for _ in range(4)]
+        ops.EMB_SIDE = False
+        emb_off = net.forward_hip(x, l, y, None)
     finally:
-        ops.FWD_SIDE = keep
+        ops.FWD_SIDE, ops.EMB_SIDE = keep, keep_emb
     assert all(torch.equal(outs[0], o) for o in outs[1:]) and torch.equal(outs[0], plain)
+    assert all(torch.equal(emb_off, o) for o in emb_on) and torch.equal(emb_off, plain)
 
 
 def test_backward_is_bit_reproducible_with_the_weight_gradients_on_the_side_stream(net):
@@ -219,6 +225,48 @@ def test_sampler_on_two_streams_is_bit_identical(net, kind, cond_w):
     for a, b in zip(*outs):
         assert a.shape == b.shape and torch.equal(a, b)
     assert bool(torch.isfinite(outs[0][0]).all())
+    # ... and with the embedding path on the main stream instead of the side stream (GMK_EMB_SIDE=0) the two-stream images are the same bits again
+    from generative_models_amd import ops
+    keep = ops.EMB_SIDE
+    try:
+        ops.EMB_SIDE = not keep
+        d = GaussianDiffusion(mean_type="v", num_steps=4, sampler=kind, seed=11)
+        other = d.sample(net=partial(net, guide=y), init_x=eps, cond_w=cond_w, net_cond_w=None if cond_w is None else torch.full((B,), cond_w).cuda())
+    finally:
+        ops.EMB_SIDE = keep
+    for a, b in zip(outs[1], other):
+        assert torch.equal(a, b)
+
+
+def test_two_stream_sampler_sees_a_weight_update_made_right_before_it(net):
+    """The first forward after a weight update re-packs the convolution weights.  In the two-stream sampler that forward runs on chunk stream 0 and
+    clears the host-side flag; chunk stream 1 only waits for the stream that was current at the fork, so the re-pack has to be enqueued THERE, before
+    the fork (round 6; before, chunk 1's convolutions could read pack buffers whose re-pack kernel they had never waited for - hidden by host
+    issue latency).  A K = 2 sample right after a perturbation + mark_params_changed() must equal the one-stream sample of the same weights, and
+    differ from the sample of the old weights."""
+    from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    _, y, _, eps = data(5)
+    def run(streams):
+        d = GaussianDiffusion(mean_type="v", num_steps=2, sampler="ddim", seed=3)
+        d.SAMPLER_STREAMS = streams
+        return d.sample(net=partial(net, guide=y), init_x=eps, record=False)[0][-1]
+    before = run(1).clone()
+    name = "up.seq.5.out_layers.3.weight"
+    saved = net._pv[name].clone()
+    try:
+        for _ in range(3):                    # several updates in a row: every one has to be seen by both halves
+            with torch.no_grad():
+                net._pv[name].mul_(1.25)
+            net.mark_params_changed()
+            two = run(2).clone()
+            one = run(1)
+            assert torch.equal(two, one)
+            assert not torch.equal(two, before)
+            before = two
+    finally:
+        with torch.no_grad():
+            net._pv[name].copy_(saved)
+        net.mark_params_changed()
 
 
 def test_embedding_rows_do_not_depend_on_the_batch_size(net):

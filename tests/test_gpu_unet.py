@@ -538,6 +538,47 @@ def test_attention_extension_vs_oracle(dtype):
     assert len(SimpleUnet(128, 0.0).state_dict()) == 160
 
 
+@pytest.mark.parametrize("N", [64, 256])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "fp8"])
+def test_attention_core_vs_the_references_own_attention(golden, N, mode):
+    """Round 6: the HIP attention core (1x1 qkv convolution -> gmk_attention_fwd / gmk_attention_bwd -> 1x1 projection, the kernels of
+    BASELINE configs[4]'s block) against fixtures generated from the reference's OWN attention class (`CausalSelfAttention`,
+    gms/autoregs/pixel_transformer.py:74-122, n_head = 1, n_embed = 128, mask of ones; oracle/make_golden.py gen_attn_core): output, dx and the
+    gradients of all four Linear layers.  Bars: fp32 mode 1e-3; bf16 1e-2 on the output and 3e-2 on gradients (the 16-bit gradient bar of the
+    extension, tests above); fp8 QK^T / PV (forward only - the backward runs in bf16): 4e-2 on the output, stated here."""
+    from generative_models_amd.diffusion.simple_unet import SimpleUnet
+    from oracle import unet_ref as U
+    gd = golden(f"attn_core_{N}.npz")
+    C, B = int(gd["C"]), int(gd["B"])
+    S = int(round(N ** 0.5))
+    dtype = torch.float32 if mode == "fp32" else torch.bfloat16
+    x, dy, lin = U.attn_core_case(N, C, B)
+    params = U.closed_form_params(C, attention=True)
+    net = SimpleUnet(C, 0.0, compute_dtype=dtype, attention=2 if mode == "fp8" else 1); net.load_state_dict(params); net = net.cuda()
+    net.prepare_forward()
+    a = x.reshape(B, S, S, C).cuda().to(dtype).contiguous()                   # tokens [B, N, C] ARE the NHWC map
+    out, saved = net._attn_core_fwd(a, keep=True)
+    ytol = {"fp32": 1e-3, "bf16": 1e-2, "fp8": 4e-2}[mode]
+    e = rel_err(out.reshape(B, N, C), T(gd["y"]))
+    assert e < ytol, e
+    # the upstream gradient is scaled up for the 16-bit path (the fixture's dy is ~ 1 / (B N): fine in bf16's range, scaled for headroom anyway)
+    k = 256.0
+    da = net._attn_core_bwd(saved, (dy * k).reshape(B, S, S, C).cuda().to(dtype).contiguous())
+    from generative_models_amd import ops
+    ops.flush_colsums(); net._join_side(); torch.cuda.synchronize()
+    gtol = 1e-3 if mode == "fp32" else 3e-2
+    errs = {"dx": rel_err(da.reshape(B, N, C).float() / k, T(gd["dx"]))}
+    gw = net.grad("attn.qkv.weight").reshape(3, C, C) / k
+    gb = net.grad("attn.qkv.bias").reshape(3, C) / k
+    for i, name in enumerate(("query", "key", "value")):
+        errs[f"d{name}_w"] = rel_err(gw[i], T(gd[f"d{name}_w"]))
+        errs[f"d{name}_b"] = rel_err(gb[i], T(gd[f"d{name}_b"]))
+    errs["dproj_w"] = rel_err(net.grad("attn.proj.weight").reshape(C, C) / k, T(gd["dproj_w"]))
+    errs["dproj_b"] = rel_err(net.grad("attn.proj.bias") / k, T(gd["dproj_b"]))
+    print("attention core", N, mode, "y", e, errs)
+    assert max(errs.values()) < gtol, errs
+
+
 @pytest.mark.parametrize("compute_dtype", ["bf16", "fp32"])
 def test_training_learns_class_conditional_templates(compute_dtype):
     """End to end through the plugin surface only (train_step / sample): 200 steps on ten smooth class templates + noise.

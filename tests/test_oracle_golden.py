@@ -207,6 +207,43 @@ def test_attention_block_definition_matches_sdpa():
     assert len(U.param_spec(C)) == 160
 
 
+@pytest.mark.parametrize("N", [64, 256])
+def test_attention_core_is_pinned_to_the_references_own_attention(golden, N):
+    """Round 6: the contraction core of the attention extension (qkv -> softmax(q k^T / sqrt(C)) v -> proj) against the ONE attention
+    implementation the reference holds - `CausalSelfAttention` (gms/autoregs/pixel_transformer.py:74-122), n_head = 1, n_embed = 128, mask of
+    ones; fixtures generated from that class by oracle/make_golden.py gen_attn_core.  `oracle.unet_ref.attention_core` must reproduce its output
+    and, through autograd, dx and the gradients of all four Linear layers.  What stays the extension's own definition is the placement
+    (GroupNorm + SiLU in front, the residual, the level), which `attention_block` adds around this core."""
+    gd = golden(f"attn_core_{N}.npz")
+    C, B = int(gd["C"]), int(gd["B"])
+    S = int(round(N ** 0.5))
+    x, dy, lin = U.attn_core_case(N, C, B)
+    p = {"attn.qkv.weight": torch.cat([lin[k][0] for k in ("query", "key", "value")]).reshape(3 * C, C, 1, 1).clone().requires_grad_(True),
+         "attn.qkv.bias": torch.cat([lin[k][1] for k in ("query", "key", "value")]).clone().requires_grad_(True),
+         "attn.proj.weight": lin["proj"][0].reshape(C, C, 1, 1).clone().requires_grad_(True),
+         "attn.proj.bias": lin["proj"][1].clone().requires_grad_(True)}
+    full = U.closed_form_params(C, attention=True)
+    assert all(torch.equal(p[k].detach(), full[k]) for k in p)               # the fixture's weights ARE the oracle net's attention weights
+    a = x.transpose(1, 2).reshape(B, C, S, S).clone().requires_grad_(True)      # tokens [B, N, C] -> the NCHW map the block sees
+    y = U.attention_core(p, a)
+    close(y.reshape(B, C, N).transpose(1, 2), T(gd["y"]), 2e-5)
+    y.backward(dy.transpose(1, 2).reshape(B, C, S, S))
+    close(a.grad.reshape(B, C, N).transpose(1, 2), T(gd["dx"]), 2e-5)
+    gw = p["attn.qkv.weight"].grad.reshape(3, C, C)
+    gb = p["attn.qkv.bias"].grad.reshape(3, C)
+    for i, k in enumerate(("query", "key", "value")):
+        close(gw[i], T(gd[f"d{k}_w"]), 2e-5)
+        close(gb[i], T(gd[f"d{k}_b"]), 2e-5)
+    close(p["attn.proj.weight"].grad.reshape(C, C), T(gd["dproj_w"]), 2e-5)
+    close(p["attn.proj.bias"].grad, T(gd["dproj_b"]), 2e-5)
+    assert float(T(gd["dkey_w"]).abs().max()) > 0 and float(T(gd["y"]).std()) > 0.05
+    # the block = the extension's placement around that core
+    xb = torch.randn((B, C, S, S), generator=torch.Generator().manual_seed(N))
+    pd = {k: v.detach() for k, v in p.items()}
+    pd.update({"attn.norm.weight": full["attn.norm.weight"], "attn.norm.bias": full["attn.norm.bias"]})
+    assert torch.equal(U.attention_block(pd, xb), xb + U.attention_core(pd, U.gn_silu(xb, pd["attn.norm.weight"], pd["attn.norm.bias"])))
+
+
 @pytest.mark.parametrize("name,C", [("definit_c128_s28.npz", 128), ("definit_c128_s32.npz", 128), ("definit_c256_s16.npz", 256)])
 def test_default_init_goldens_pin_the_oracle(golden, name, C):
     """The default-init-scale set (oracle/make_golden.py:gen_default_init) the bf16 bar is held on: forward with / without
