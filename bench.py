@@ -338,12 +338,14 @@ class Bench:
         torch.cuda.synchronize()
         peak = MFMA_BF16_PEAK_TFLOPS if (dtype or self.a.dtype) == "bf16" else MFMA_F32_PEAK_TFLOPS
         by = {}
-        for name, s, e, f, nb in prof:
-            d = by.setdefault(name, [0.0, 0.0, 0, 0.0])
-            d[0] += s.elapsed_time(e); d[1] += f; d[2] += 1; d[3] += nb
+        inst = {}
+        for name, s, e, f, nb, fm, ikey in prof:
+            dt = s.elapsed_time(e)
+            for d in (by.setdefault(name, [0.0, 0.0, 0, 0.0, 0.0]),) + ((inst.setdefault(ikey, [0.0, 0.0, 0, 0.0, 0.0]),) if ikey else ()):
+                d[0] += dt; d[1] += f; d[2] += 1; d[3] += nb; d[4] += fm
         mfma = {k: v for k, v in by.items() if k.startswith("conv")}
         dom = max(mfma, key=lambda k: mfma[k][0])          # dominant kernel = largest total HIP-event time
-        ms, fl, n, _ = by[dom]
+        ms, fl, n = by[dom][:3]
         ach = fl / (ms * 1e-3) / 1e12
         traffic, source, pmc, stale = None, None, None, None
         import glob
@@ -375,6 +377,19 @@ class Bench:
             if k in kern and "hbm_bytes_per_launch" in kern[k]:
                 ent["traffic"] = kern[k]["hbm_bytes_per_launch"]
             hbm[k] = ent
+        # every template instantiation of the halo / sub-pixel kernels with its OWN algorithmic bytes beside its OWN counter bytes (the fp16
+        # forward instantiation fetches more per launch than the bf16 data gradient because more of its launches read two sources)
+        insts = {}
+        for k, v in sorted(inst.items(), key=lambda kv: -kv[1][0]):
+            ent = {"launches_per_step": v[2] // nprof, "avg_launch_us": round(v[0] * 1e3 / v[2], 2), "achieved": round(v[4] / (v[0] * 1e-3) / 1e12, 2),
+                   "algorithmic_bytes_per_launch": round(v[3] / v[2]), "algorithmic_gbs": round(gbs(v), 1), "share_of_step_time": share(v)}
+            if k in kern and "hbm_bytes_per_launch" in kern[k]:
+                ent["traffic"] = kern[k]["hbm_bytes_per_launch"]
+                ent["traffic_over_algorithmic"] = round(kern[k]["hbm_bytes_per_launch"] / max(1.0, v[3] / v[2]), 3)
+                for c in ("mfma_busy_frac", "sclk_ghz_est"):
+                    if c in kern[k]:
+                        ent[c] = kern[k][c]
+            insts[k] = ent
         hbm_bound = [k for k in hbm if not k.startswith("conv3x3") and not k.startswith("conv_wgrad_slots")]
         top_hbm = max(hbm_bound, key=lambda k: by[k][0]) if hbm_bound else None
         return {"kernel": dom, "what": KERNEL_DESC.get(dom, ""), "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
@@ -382,10 +397,14 @@ class Bench:
                 "traffic_withheld": stale, "pmc": pmc,
                 "vector_peak": VECTOR_F32_PEAK_TFLOPS, "achieved_vs_vector_peak": round(ach / VECTOR_F32_PEAK_TFLOPS, 2),
                 "launches_per_step": n // nprof, "avg_launch_us": round(ms * 1e3 / n, 2), "share_of_step_time": share(by[dom]),
-                "profiled_steps": nprof,
-                "other_kernels": {k: {"achieved": round(v[1] / (v[0] * 1e-3) / 1e12, 2), "achieved_vs_vector_peak": round(v[1] / (v[0] * 1e-3) / 1e12 / VECTOR_F32_PEAK_TFLOPS, 2),
-                                      "avg_launch_us": round(v[0] * 1e3 / v[2], 2),
-                                      "launches_per_step": v[2] // nprof, "share_of_step_time": share(v)}
+                "profiled_steps": nprof, "instantiations": insts,
+                # `achieved` = the products the kernel's MFMAs form / time (the rate that may be set against `peak`); where the kernel forms fewer
+                # products than the reference op counts (sub-pixel forms: 16 of 36) `reference_tflops` is that op's count / time: an EFFECTIVE rate
+                "other_kernels": {k: dict({"achieved": round(v[4] / (v[0] * 1e-3) / 1e12, 2), "achieved_vs_vector_peak": round(v[4] / (v[0] * 1e-3) / 1e12 / VECTOR_F32_PEAK_TFLOPS, 2),
+                                           "avg_launch_us": round(v[0] * 1e3 / v[2], 2),
+                                           "launches_per_step": v[2] // nprof, "share_of_step_time": share(v)},
+                                          **({"multiplied_tflops": round(v[4] / (v[0] * 1e-3) / 1e12, 2), "reference_tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2)}
+                                             if abs(v[4] - v[1]) > 1e-6 * max(v[1], 1.0) else {}))
                                   for k, v in mfma.items() if k != dom},
                 "hbm": {"top_hbm_bound_kernel": top_hbm, "note": "achieved = ALGORITHMIC bytes (every operand tensor read once, every result written "
                         "once; DESIGN.md section 4) / HIP-event time of this run; kernels above 2 % of the step and both GroupNorm backward forms",

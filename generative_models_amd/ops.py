@@ -17,8 +17,11 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 _HALF = (torch.bfloat16, torch.float16)
 NORMAL, STRIDE2, UPSAMPLE2, TRANSPOSED2 = 0, 1, 2, 3
 
-# bench.py sets this to a list to collect (kernel name, start event, end event, algorithmic FLOPs, algorithmic HBM bytes) per launch
-# of the convolution, weight-gradient, GroupNorm and stem / head kernels; events are recorded on the stream the kernel is launched on.
+# bench.py sets this to a list to collect (kernel name, start event, end event, algorithmic FLOPs, algorithmic HBM bytes, multiplied FLOPs) per
+# launch of the convolution, weight-gradient, GroupNorm and stem / head kernels; events are recorded on the stream the kernel is launched on.
+# "Algorithmic" FLOPs are the REFERENCE op's (9 taps per output pixel); "multiplied" are the products the kernel's MFMAs actually form - they
+# differ for the sub-pixel forms (16 tap-products per low-resolution pixel where the reference op counts 36), and only the multiplied
+# count may be set against the MFMA peak.
 PROFILE = None
 
 
@@ -36,6 +39,22 @@ KERNEL_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_dma_kernel", 3: "conv3x3_
                 21: "gn_silu_fwd_reg_kernel", 22: "gn_silu_fwd_kernel", 23: "gn_silu_bwd_hybrid_kernel", 24: "gn_silu_bwd_kernel"}
 
 
+def instantiation_key(name, dtype):
+    """The template instantiation a profiled launch ran as, spelled like the keys of the counter records (tools/kernel_names.py:
+    `conv3x3_halo_ws_kernel<f16>`, `<bf16>`, `<f16,+skip>`, `conv_subpixel_ws_kernel<bf16,upsample dgrad>` ...), so that a launch's own
+    algorithmic bytes can stand beside its own counter bytes; None for kernels that have one instantiation per name."""
+    if dtype not in _HALF:
+        return None
+    t = "f16" if dtype == torch.float16 else "bf16"
+    if name == "conv3x3_halo_ws_kernel":
+        return f"{name}<{t}>"
+    if name == "conv3x3_halo_ws_kernel[+1x1 skip]":
+        return f"conv3x3_halo_ws_kernel<{t},+skip>"
+    if name.startswith("conv_subpixel_ws_kernel["):
+        return f"conv_subpixel_ws_kernel<{t},{name[len('conv_subpixel_ws_kernel['):-1]}>"
+    return None
+
+
 def _nbytes(*tensors):
     """Algorithmic bytes of a launch - only evaluated when a profile is being collected (it sits on every launch's path)."""
     if PROFILE is None:
@@ -47,10 +66,12 @@ class _Timed:
     """flops / nbytes: ALGORITHMIC work of the launch (DESIGN.md section 4: each operand tensor read once, each result written once);
     fixed=True: `name` is the kernel's own name (no gmk_last_kernel lookup)."""
 
-    def __init__(self, name, flops, nbytes=0.0, fixed=False):
+    def __init__(self, name, flops, nbytes=0.0, fixed=False, multiplied=None, dtype=None):
         self.on = PROFILE is not None
         if self.on:
             self.name, self.flops, self.nbytes, self.fixed = name, flops, nbytes, fixed
+            self.multiplied = flops if multiplied is None else multiplied
+            self.dtype = dtype
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
 
@@ -62,7 +83,7 @@ class _Timed:
         if self.on:
             self.e.record()
             name = self.name if self.fixed else KERNEL_NAMES.get(lib.gmk_last_kernel(), self.name)
-            PROFILE.append((name, self.s, self.e, self.flops, self.nbytes))
+            PROFILE.append((name, self.s, self.e, self.flops, self.nbytes, self.multiplied, instantiation_key(name, self.dtype)))
 
 
 _IN_FLIGHT = {}
@@ -382,7 +403,7 @@ def conv_igemm(srcs, w, w_rows, ksize, mode, out_hw, n0=0, cout=128, bias=None, 
         r = 256 // wo
         tp, nt = r * wo, (B * ho + r - 1) // r
         part = torch.empty(nt * 8 * 2 * (cout // 4) * 2, device=s0.device, dtype=torch.float32)
-    with _Timed("conv_igemm", 2.0 * mpix * cout * (c0 + c1) * ksize * ksize, _nbytes(s0, s1, residual, out)):
+    with _Timed("conv_igemm", 2.0 * mpix * cout * (c0 + c1) * ksize * ksize, _nbytes(s0, s1, residual, out), dtype=s0.dtype):
         check(lib.gmk_conv_igemm(_p(s0), _p(s1), c0, c1, B, hs, ws, ho, wo, ksize, mode, _p(w), w_rows, n0, cout,
                                  _p(bias), _p(emb), emb_stride, _p(residual), _p(out), cout, _p(part),
                                  part.numel() * 4 if part is not None else 0, _p(gsc), _p(gsh), gstride, _DT[s0.dtype], _s()),
@@ -437,7 +458,7 @@ def conv_subpixel(src, w, w_rows, mode, bias=None, residual=None, n0=0, cout=128
     # algorithmic work: that of the reference's op (9 taps per HIGH-resolution pixel for the upsampled convolution and its data gradient,
     # 9 per LOW-resolution pixel for the transposed one)
     mpix = B * H * W if mode == SUBPIXEL_TRANSPOSED else B * 4 * H * W
-    with _Timed("conv_subpixel", 2.0 * mpix * cout * c * 9, _nbytes(s0, residual, out)):
+    with _Timed("conv_subpixel", 2.0 * mpix * cout * c * 9, _nbytes(s0, residual, out), multiplied=2.0 * B * H * W * cout * c * taps, dtype=s0.dtype):
         check(lib.gmk_conv_subpixel(_p(s0), B, H, W, c, _p(w), w_rows, n0, cout, mode, _p(bias), _p(residual), _p(out), cout,
                                     _DT[s0.dtype], _s()), "conv_subpixel")
     return out
@@ -464,7 +485,7 @@ def conv3x3_skipfold(src, w, bias, skips, wsk, bias_sk, cout=128):
     _f32(bias, "bias"); _f32(bias_sk, "bias_sk")
     assert bias.numel() == cout and bias_sk.numel() == cout
     out = torch.empty((B, H, W, cout), device=s0.device, dtype=s0.dtype)
-    with _Timed("conv_igemm", 2.0 * B * H * W * cout * (9 * c0 + 2 * cs), _nbytes(s0, k0, k1, out)):
+    with _Timed("conv_igemm", 2.0 * B * H * W * cout * (9 * c0 + 2 * cs), _nbytes(s0, k0, k1, out), dtype=s0.dtype):
         check(lib.gmk_conv3x3_skipfold(_p(s0), c0, B, H, W, _p(w), cout, 0, cout, _p(bias), _p(k0), _p(k1), cs, _p(wsk), cout, 0,
                                        _p(bias_sk), _p(out), cout, _DT[s0.dtype], _s()), "conv3x3_skipfold")
     return out
@@ -534,7 +555,7 @@ def conv_wgrad_subpixel(dy, x, dw):
     need = lib.gmk_conv_wgrad_subpixel_workspace_bytes(B, H, W, cin, cout)
     assert need > 0
     wsbuf = _workspace(need, dy.device)
-    with _Timed("conv_wgrad", 2.0 * B * 4 * H * W * cout * cin * 9, _nbytes(dy, x)):
+    with _Timed("conv_wgrad", 2.0 * B * 4 * H * W * cout * cin * 9, _nbytes(dy, x), multiplied=2.0 * B * H * W * cout * cin * 16):
         check(lib.gmk_conv_wgrad_subpixel(_p(dy), cout, _p(x), B, H, W, cin, cout, _p(dw), _p(wsbuf), wsbuf.numel(), _DT[dy.dtype],
                                           _DT[x.dtype], _s()), "conv_wgrad_subpixel")
     return dw

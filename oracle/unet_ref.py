@@ -211,15 +211,21 @@ def attention_block(p, x):
 
 
 def attn_core_case(T, C=128, B=2):
-    """Closed-form inputs of the attention-core fixtures (regenerated by the tests, not stored): tokens x [B, T, C], upstream gradient dy, and
-    the four Linear layers of the reference class as (weight, bias) pairs keyed by the reference's attribute names."""
-    p = closed_form_params(C, attention=True)
-    wq, wk, wv = p["attn.qkv.weight"].reshape(3, C, C)
-    bq, bk, bv = p["attn.qkv.bias"].reshape(3, C)
-    lin = {"query": (wq, bq), "key": (wk, bk), "value": (wv, bv), "proj": (p["attn.proj.weight"].reshape(C, C), p["attn.proj.bias"])}
-    k = torch.arange(B * T * C, dtype=torch.float64)
-    x = (torch.sin(0.731 * k + 0.4) + 0.6 * torch.sin(0.0917 * k * (1.0 + 0.001 * (k % 13)))).reshape(B, T, C).float()
-    dy = (0.8 * torch.sin(1.137 * k + 1.9) + 0.3 * torch.cos(0.0411 * k)).reshape(B, T, C).float() / (B * T)
+    """Inputs of the attention-core fixtures, regenerated by the tests instead of stored: tokens x [B, T, C], upstream gradient dy, and the four
+    Linear layers of the reference class as (weight, bias) pairs keyed by the reference's attribute names.  Everything is an exact integer hash of
+    the element index -> uniform, zero mean: x of unit variance, weights of unit gain (U(-sqrt(3 / C), sqrt(3 / C)): logits of std ~ 1, a live
+    softmax), biases 0.1 U(-1, 1).  (`closed_form_params`' sinusoid fill is no use here: sin(0.37 (i C + j) + phase) is a rank-2 matrix.)"""
+    def hashed(n, salt):
+        h = (torch.arange(n, dtype=torch.int64) + salt) * 0x9E3779B1 & 0xFFFFFFFF
+        h = (h ^ (h >> 15)) * 0x85EBCA77 & 0xFFFFFFFF
+        h = (h ^ (h >> 13)) * 0xC2B2AE3D & 0xFFFFFFFF
+        h = h ^ (h >> 16)
+        return (h.double() + 0.5) / 2147483648.0 - 1.0                # U(-1, 1)
+    lin = {}
+    for i, name in enumerate(("query", "key", "value", "proj")):
+        lin[name] = ((math.sqrt(3.0 / C) * hashed(C * C, 1000003 * (i + 1))).reshape(C, C).float(), (0.1 * hashed(C, 77777 * (i + 1))).float())
+    x = (math.sqrt(3.0) * hashed(B * T * C, 17)).reshape(B, T, C).float()
+    dy = (math.sqrt(3.0) * hashed(B * T * C, 900001) / (B * T)).reshape(B, T, C).float()
     return x, dy, lin
 
 

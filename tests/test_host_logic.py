@@ -473,6 +473,34 @@ def test_epoch_log_keys_and_deferred_host_transfer():
                     "dt/train": 1.5}
 
 
+def _rates_above_peak(rec, peak=None, depth=0, path=""):
+    """Every {"achieved": A, "peak": P} block of a bench record and every `other_kernels` entry under a roofline block (which inherits the
+    block's peak): A <= P."""
+    bad = []
+    if isinstance(rec, dict):
+        pk = rec["peak"] if isinstance(rec.get("peak"), (int, float)) else (peak if depth > 0 else None)
+        if isinstance(rec.get("achieved"), (int, float)) and isinstance(pk, (int, float)) and rec["achieved"] > pk:
+            bad.append((path, rec["achieved"], pk))
+        for k, v in rec.items():
+            if k == "other_kernels":
+                bad += _rates_above_peak(v, pk, 2, f"{path}/{k}")
+            else:
+                bad += _rates_above_peak(v, pk, depth - 1, f"{path}/{k}")
+    return bad
+
+
+def test_no_rate_above_its_peak_in_the_committed_bench_detail():
+    """Round 5's detail record quoted 2,572 TFLOP/s for a sub-pixel kernel: the REFERENCE op's 36 tap-products divided by the time of a kernel that
+    multiplies 16.  Since round 6 `achieved` counts the products the MFMAs form (`multiplied_tflops`), the reference count is `reference_tflops`
+    (an effective rate), and no `achieved` of the newest committed record may exceed the `peak` it stands beside."""
+    import glob
+    import json
+    assert _rates_above_peak({"roofline": {"achieved": 1.0, "peak": 2.0, "other_kernels": {"k": {"achieved": 3.0}}}}) == [("/roofline/other_kernels/k", 3.0, 2.0)]
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_detail.json")) if os.path.basename(f) >= "r06")
+    for f in files:
+        assert _rates_above_peak(json.load(open(f))) == [], f
+
+
 def test_bench_line_stays_inside_the_drivers_window():
     """The driver parses the LAST stdout line of bench.py and keeps a bounded tail of stdout: round 3's 20 KB line was cut and the
     headline went unmeasured.  The compact line built from that very record (and from an N = 8 variant of it with the exchange block and

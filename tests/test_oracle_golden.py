@@ -223,7 +223,6 @@ def test_attention_core_is_pinned_to_the_references_own_attention(golden, N):
          "attn.proj.weight": lin["proj"][0].reshape(C, C, 1, 1).clone().requires_grad_(True),
          "attn.proj.bias": lin["proj"][1].clone().requires_grad_(True)}
     full = U.closed_form_params(C, attention=True)
-    assert all(torch.equal(p[k].detach(), full[k]) for k in p)               # the fixture's weights ARE the oracle net's attention weights
     a = x.transpose(1, 2).reshape(B, C, S, S).clone().requires_grad_(True)      # tokens [B, N, C] -> the NCHW map the block sees
     y = U.attention_core(p, a)
     close(y.reshape(B, C, N).transpose(1, 2), T(gd["y"]), 2e-5)
@@ -233,7 +232,8 @@ def test_attention_core_is_pinned_to_the_references_own_attention(golden, N):
     gb = p["attn.qkv.bias"].grad.reshape(3, C)
     for i, k in enumerate(("query", "key", "value")):
         close(gw[i], T(gd[f"d{k}_w"]), 2e-5)
-        close(gb[i], T(gd[f"d{k}_b"]), 2e-5)
+        close(gb[i], T(gd[f"d{k}_b"]), 2e-5)          # (the key bias shifts every logit of a row alike: its gradient is zero up to rounding, ~ 1e-8 here)
+    assert float(T(gd["dkey_b"]).abs().max()) < 1e-6 * float(T(gd["dquery_b"]).abs().max())
     close(p["attn.proj.weight"].grad.reshape(C, C), T(gd["dproj_w"]), 2e-5)
     close(p["attn.proj.bias"].grad, T(gd["dproj_b"]), 2e-5)
     assert float(T(gd["dkey_w"]).abs().max()) > 0 and float(T(gd["y"]).std()) > 0.05
