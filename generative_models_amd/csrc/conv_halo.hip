@@ -60,6 +60,7 @@ struct HaloParams {
     const void* sk0; const void* sk1; const void* wsk; const float* bias2;
     int cs, sk_ktot, nsk0;                     // channels per skip source (128), total skip K (2 cs), first weight row
     unsigned nbs, nbws;                        // bytes of one skip source / of the skip weight pack
+    unsigned* stamps;                          // development (kStamp instantiations, gmk_dev_set_stamp_buffer): per-workgroup cycle sums per K-step
 };
 
 // first of the two 8-KiB LDS slots (pixels 0..127 / 128..255) that hold dense sub-phase m (0..3) of a halo phase's four: slots of the
@@ -201,6 +202,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     };
 
     f32x16 acc[2][2];     // [j: channel tile][i: pixel tile]
+    // a tile's accumulators START from the bias (as in the wave-specialised consumers, whose first MFMA takes it as its C operand: the two
+    // kernels stay bit-identical, tests/test_gpu_ops.py::test_halo_tail_runs_as_half_jobs); 32 values per lane, kept for the whole launch
+    float bzv[2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) load4(p.bias + nblk + wn * 64 + j * 32 + 8 * q4 + 4 * h, t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bzv[j][4 * q4 + e] = t[e];
+        }
     const int swz = (r >> 1) & 7;
     const int b_off = kWOFF + (wn * 64 + r) * 128;
 
@@ -277,16 +290,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                 const int cb = nblk + wn * 64 + j * 32;
                 float v[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = acc[j][i][e];
-                if (p.bias) {
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        float t[4];
-                        load4(p.bias + cb + 8 * q4 + 4 * h, t);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[4 * q4 + e] += t[e];
-                    }
-                }
+                for (int e = 0; e < 16; ++e) v[e] = acc[j][i][e];          // (the bias is in the accumulators)
                 if (p.emb) {
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[j][i][e] = bzv[j][e];
         for (int ph = 0; ph < nph; ++ph) {
             const bool last_ph = ph + 1 == nph;
             if (last_ph) resolve_fill(tile + gridDim.x);        // the next fills belong to the next tile (or are zeros)
@@ -458,9 +462,13 @@ template <int N> struct IntTag { static constexpr int value = N; };
 // 64-byte rows: lane (row = lane >> 2, chunk = lane & 3) of a DMA instruction writes 16 rows of 64 B; physical chunk c of row n holds logical
 // chunk c ^ ((n >> 2) & 3), so the 16 rows a ds_read_b128 lane group touches (consecutive n, one logical chunk) cover all 64 banks.
 // No residual in this form (the skip convolution is the residual); half jobs as in the plain kernel (64 weight rows per step).
-template <typename T, bool kPrefetchW, int kShape = 32, bool kFuse = false, bool kSkip = false>
+// kStamp (development, tools/step_stamps.py): wave 4 (a producer) and wave 0 (a consumer) of every workgroup sum, per K-step index, the shader
+// cycles (s_memtime) they spend (producer) issuing / in the counted vmcnt wait / in the barrier, (consumer) working / in the barrier, and
+// write the sums to p.stamps[workgroup][2][64] at the end: who waits for whom in each step.  Product launches use kStamp = false.
+template <typename T, bool kPrefetchW, int kShape = 32, bool kFuse = false, bool kSkip = false, bool kStamp = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParams p) {
     static_assert(!kSkip || (kPrefetchW && kShape == 16 && !kFuse), "the folded skip convolution is built on the plain 16x16x32 form");
+    static_assert(!kStamp || (kPrefetchW && kShape == 16 && !kFuse), "stamps exist for the shipped 16x16x32 forms only");
     typedef typename Frag16<T>::type frag_t;
     typedef typename Frag16<T>::half_type half_t;
     constexpr int ES = 2;
@@ -475,6 +483,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
     constexpr unsigned kBadPix = 0x00FFFFFFu;
     constexpr unsigned kBadOff = 0xFFFFFF00u;
     if ((int)blockIdx.x >= p.ntiles && (int)blockIdx.x >= p.nhalf) return;
+    if constexpr (kStamp) {          // (experiment, GMK_DEV_VARIANT=22: every second workgroup of an XCD starts ~ half a tile late, so that the epilogues' store bursts of the two halves of the chip do not coincide)
+        if (p.variant == 22 && ((blockIdx.x >> 3) & 1)) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            while (__builtin_readcyclecounter() - t0 < 18000ull) __builtin_amdgcn_s_sleep(8);
+        }
+    }
     // Jobs of this workgroup, in order: the whole tiles g, g + G, ... below nfull, then - for the first nhalf workgroups - one
     // HALF job: channel half (g & 1) of tile nfull + g/2, computed by all four consumers as 64 pixels x 64 channels each.
     // The host sets nhalf = 2 x (ntiles mod G) when that remainder fits (<= G/2): the last, partly filled round of whole tiles
@@ -825,6 +839,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             if (ch < 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __builtin_amdgcn_s_barrier();                      // start-up barrier: weight tile 0 and the first halo half are in LDS
+            unsigned st_iss[13] = {}, st_wait[13] = {}, st_bar[13] = {};
+            unsigned long long st_prev = 0, st_t0 = 0, st_t1 = 0;
             for (int k = 0; k < njobs; ++k) {
                 const int ntile = job_tile(k + 1), nch = job_half(k + 1);
                 resolve_dense(tile);
@@ -839,8 +855,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 #pragma unroll
                     for (int i = 0; i < 13; ++i) {
                         // pixel-piece instructions of the previous step may still fly; its weights (for step i + 1) and everything older have landed
+                        if constexpr (kStamp) { st_t0 = __builtin_readcyclecounter(); if (st_prev) st_iss[i] += (unsigned)(st_t0 - st_prev); }
                         wait_vm(i == 0 ? 0 : i == 4 ? 2 : (i == 1 || i == 2 || i == 3 || i == 6 || i == 8 || i == 10 || i == 12) ? 4 : 0);
+                        if constexpr (kStamp) st_t1 = __builtin_readcyclecounter();
                         __builtin_amdgcn_s_barrier();
+                        if constexpr (kStamp) { st_prev = __builtin_readcyclecounter(); st_wait[i] += (unsigned)(st_t1 - st_t0); st_bar[i] += (unsigned)(st_prev - st_t1); }
                         issue_weights(sq, ph, i + 2, ch, nch);
                         if (i == 0) issue_dense(fb, skip_slot(0), 4 * ph + 0);
                         if (i == 1) issue_dense(fb, skip_slot(1), 4 * ph + 1);
@@ -856,6 +875,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 tile = ntile; ch = nch;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the speculative DMA before the LDS is released
+            if constexpr (kStamp) {
+                if (pw == ((p.variant >= 30 && p.variant <= 33) ? p.variant - 30 : 0) && lane == 0 && p.stamps) {
+                    unsigned* o = p.stamps + (size_t)blockIdx.x * 128;
+#pragma unroll
+                    for (int i = 0; i < 13; ++i) { o[i] = st_iss[i]; o[16 + i] = st_wait[i]; o[32 + i] = st_bar[i]; }
+                    o[48] = (unsigned)njobs;
+                }
+            }
             return;
         }
         const __amdgpu_buffer_rsrc_t rsr =
@@ -888,6 +915,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         if (ch < 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // start-up barrier: weight tile 0 is in LDS
+        unsigned st_iss[9] = {}, st_wait[9] = {}, st_bar[9] = {};
+        unsigned long long st_prev = 0, st_t0 = 0, st_t1 = 0;
         for (int k = 0; k < njobs; ++k) {
             const int ntile = job_tile(k + 1), nch = job_half(k + 1);
             for (int ph = 0; ph < nph; ++ph) {
@@ -895,6 +924,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 const int ph_next = last_ph ? 0 : ph + 1;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
+                    if constexpr (kStamp) { st_t0 = __builtin_readcyclecounter(); if (st_prev) st_iss[tap] += (unsigned)(st_t0 - st_prev); }
                     // at barrier q the weight tile of step q+1 (the first 4 ops of step q-1) must have landed — the consumers read its
                     // first fragments before barrier q+1; only the 2 halo pieces issued behind it may still fly.  Tap 0 also needs
                     // the phase's whole halo (all older).
@@ -908,7 +938,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         else if (tap == 1 || tap == 8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     }
+                    if constexpr (kStamp) st_t1 = __builtin_readcyclecounter();
                     __builtin_amdgcn_s_barrier();
+                    if constexpr (kStamp) { st_prev = __builtin_readcyclecounter(); st_wait[tap] += (unsigned)(st_t1 - st_t0); st_bar[tap] += (unsigned)(st_prev - st_t1); }
                     if (tap < 7) issue_w(sq, tap + 2, ph, ch);
                     else issue_w(sq, tap - 7, ph_next, last_ph ? nch : ch);      // the first two weight tiles of the next job
                     if (tap < 7) {
@@ -938,6 +970,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             if (hand && ch < 0 && tile < p.ntiles) resolve_res(tile);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the speculative DMA before the LDS is released
+        if constexpr (kStamp) {
+            if (pw == ((p.variant >= 30 && p.variant <= 33) ? p.variant - 30 : 0) && lane == 0 && p.stamps) {
+                unsigned* o = p.stamps + (size_t)blockIdx.x * 128;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { o[i] = st_iss[i]; o[16 + i] = st_wait[i]; o[32 + i] = st_bar[i]; }
+                o[48] = (unsigned)(njobs * nph);
+            }
+        }
         return;
     }
 
@@ -956,18 +996,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         const __amdgpu_buffer_rsrc_t rsr =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.out), 0, (int)p.nbo, 0x00020000);
         const int pxbase = wave * 64;
-        int rit[4], px_x[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ml = pxbase + i * 16 + r16;
-            rit[i] = div_small(ml, p.inv_w);
-            px_x[i] = ml - rit[i] * W;
-        }
         int cslot[4], cn[4];
         auto resolve_centres = [&](int tile) {
             const int gr0 = tile * p.R;
             const int b0 = gr0 / H;
             const int y0 = gr0 - b0 * H;
+            // (row / column of this lane's pixels: recomputed per tile from an opaque copy of the lane index - as loop invariants they were spilled
+            // and reloaded from scratch in the middle of the epilogue's stores, see there)
+            int lane_c = lane;
+            asm volatile("" : "+v"(lane_c));
+            int rit[4], px_x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ml = pxbase + i * 16 + (lane_c & 15);
+                rit[i] = div_small(ml, p.inv_w);
+                px_x[i] = ml - rit[i] * W;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int t = y0 + rit[i];
@@ -987,6 +1031,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         frag_t px[2][4], wt[2][2];
         int rowb[4], sw[4];
         int st = 0, hbuf = 0;
+        unsigned sc_work[13] = {}, sc_bar[13] = {}, sc_epi[3] = {};
+        unsigned long long sc_prev = 0;
+        // barrier of K-step `idx` (taps 0..8, dense sub-phases 9..12): kStamp sums the cycles from the previous barrier's exit to this one's entry and in it
+        auto step_barrier = [&](int idx) __attribute__((always_inline)) {
+            if constexpr (kStamp) {
+                const unsigned long long a = __builtin_readcyclecounter();
+                if (sc_prev) sc_work[idx] += (unsigned)(a - sc_prev);
+                __builtin_amdgcn_s_barrier();
+                sc_prev = __builtin_readcyclecounter();
+                sc_bar[idx] += (unsigned)(sc_prev - a);
+            } else {
+                __builtin_amdgcn_s_barrier();
+            }
+        };
         auto load_wt = [&](int stg, int k2, int pair, int set) {
             const char* Wb = smem + stg * kWST + b_off + pair * 4096;
             const int coff = ((k2 * 4 + q) ^ swz) << 4;
@@ -1005,7 +1063,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             wt[set][0] = *reinterpret_cast<const frag_t*>(Wb);
             wt[set][1] = *reinterpret_cast<const frag_t*>(Wb + 1024);
         };
-        auto run_job = [&](auto ncb_tag, int tile, int chalf, int next_boff) {
+        // This block's 128 bias values (+ the folded skip convolution's own, simple_unet.py:177-179) live in TWO registers per consumer wave for
+        // the whole launch: lane l holds channels nblk + l and nblk + 64 + l.  A tile's accumulator-layout copy (lane (r16, q): channels
+        // 16 cb + 4 q .. + 3 of block cb) is gathered from them by 32 ds_bpermute_b32 - no memory instruction: the per-tile global loads this
+        // replaces took 540 (8 loads) / 2,500 (16 loads, folded kernel) cycles of a tile's epilogue to ISSUE behind the producers' DMA and
+        // the output stores (round 6, tools/step_stamps.py).
+        float bl0 = 0.f, bl1 = 0.f;
+        if (p.bias) { bl0 = p.bias[nblk + lane]; bl1 = p.bias[nblk + 64 + lane]; }
+        if constexpr (kSkip) { bl0 += p.bias2[nblk + lane]; bl1 += p.bias2[nblk + 64 + lane]; }
+        f32x4 bz[8];              // bias of the NEXT job's channel blocks in the accumulator layout (see mfma_group)
+        auto load_bias = [&](int chalf) __attribute__((always_inline)) {      // chalf: channel half of the job the values are for (-1: whole job)
+            int lane_b = lane;
+            asm volatile("" : "+v"(lane_b));          // (recomputed per tile, not kept live or spilled across the K loop: see the epilogue)
+            const int qa = (lane_b >> 4) << 4;        // byte address of source lane 4 q
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const float src = (chalf >= 0 ? chalf : (cb >> 2)) ? bl1 : bl0;      // (a half job has four blocks: 4..7 repeat them, unused)
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    t[e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(qa + 4 * (16 * (cb & 3) + e), __builtin_bit_cast(int, src)));
+                bz[cb] = (f32x4){t[0], t[1], t[2], t[3]};
+            }
+        };
+        auto run_job = [&](auto ncb_tag, int tile, int chalf, int next_boff, int next_chalf) {
             constexpr int NCB = decltype(ncb_tag)::value;          // 8: whole job, 4: half job
             constexpr int NG = NCB / 2;                            // groups (channel-block pairs) per k2 half
             auto addr = [&](int tap) {
@@ -1024,21 +1105,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 for (int i = i0; i < i1; ++i)
                     px[set][i] = *reinterpret_cast<const frag_t*>(Hb + rowb[i] + (((k2 * 4 + q) ^ sw[i]) << 4));
             };
+            // A tile's first MFMA into an accumulator takes the channel block's BIAS as its C operand (lane (r16, q) holds channels 4 q .. 4 q + 3
+            // of its pixels: the same four values for every pixel block) - the epilogue then has no bias loads to wait for and no adds (round 6:
+            // the bias round trip was 1,250 of a 32 x 32 tile's 37,000 cycles, tools/step_stamps.py).  bz is gathered at the END of the previous
+            // tile's epilogue (load_bias), or in the prologue; zeros when there is no bias.
             auto mfma_group = [&](int pair, int wset, int pset, auto fresh_tag) __attribute__((always_inline)) {
                 constexpr bool kFresh = decltype(fresh_tag)::value != 0;
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        acc[2 * pair + j][i] = mfma_16x16x32<T>(wt[wset][j], px[pset][i], kFresh ? z : acc[2 * pair + j][i]);
+                        acc[2 * pair + j][i] = mfma_16x16x32<T>(wt[wset][j], px[pset][i], kFresh ? bz[2 * pair + j] : acc[2 * pair + j][i]);
             };
             auto phase = [&](auto first_tag, int ph) __attribute__((always_inline)) {
                 constexpr int kFirst = decltype(first_tag)::value;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const bool dense_after = kSkip && tap >= 3 && tap <= 6;      // a dense sub-phase of the folded skip convolution follows this tap
-                    __builtin_amdgcn_s_barrier();
+                    step_barrier(tap);
                     if (tap == 0) { addr(0); load_px(hbuf, 0, 0, 0, 4); }      // the phase's halo only became valid with this barrier
                     if (!kPrefetchW) load_wt(st, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -1089,7 +1173,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                             // rows sit in the half-buffer this phase is filling.  4 pixel fragments (this wave's 64 pixels, one k chunk per lane)
                             // behind the barrier, then 4 groups of 8 MFMAs (2 channel blocks x 4 pixel blocks) with the next group's weight
                             // fragments read underneath; the last group brings the next tap's addresses, pixel and weight fragments.
-                            __builtin_amdgcn_s_barrier();
+                            step_barrier(9 + tap - 3);
                             {
                                 int o = d_off;
                                 asm volatile("" : "+v"(o));          // per-step addresses stay out of loop-invariant hoisting (registers)
@@ -1139,6 +1223,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             phase(IntTag<1>{}, 0);
             for (int ph = 1; ph < nph; ++ph) phase(IntTag<0>{}, ph);
             asm volatile("" ::: "memory");
+            unsigned long long se0 = 0, se1 = 0;
+            if constexpr (kStamp) {          // the last step's MFMAs have been issued; reading an accumulator waits for them
+                float t = acc[7][3][3];
+                asm volatile("v_mov_b32 %0, %0" : "+v"(t));
+                acc[7][3][3] = t;
+                se0 = __builtin_readcyclecounter();
+                sc_epi[0] += (unsigned)(se0 - sc_prev);
+            }
+            // Everything the epilogue derives from the lane index is RECOMPUTED here from an opaque copy of it: left to itself the compiler hoists
+            // those loop invariants (pixel offsets, LDS read addresses of the handed-over residual, channel offsets) in front of the job loop,
+            // spills them (the K loop has no registers to spare) and reloads them from scratch in the middle of the epilogue - and a scratch
+            // reload sits in the same in-order vmcnt queue as the output stores, so each reload waited for the stores in front of it to be
+            // ACKNOWLEDGED (round 6, tools/step_stamps.py: 5,000 of a 32 x 32 tile's 37,000 cycles were conversion + store issue; 3,500 with the stores dropped).
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int r16e = lane_e & 15, qe = lane_e >> 4;
             // residual hand-over (see the producers): units 0..6 of the tile's residual arrive in the halo buffer this job's last phase
             // just finished with; unit 7 (channels 112..127) is loaded from memory here, ahead of the two barriers that hide its latency
             constexpr bool kHandJob = kPrefetchW && !kFuse && NCB == 8;
@@ -1148,49 +1248,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             if (hand) {
 #pragma unroll
                 for (int ip = 0; ip < 2; ++ip) {
-                    const int ml = pxbase + (2 * ip + (q & 1)) * 16 + r16;
+                    const int ml = pxbase + (2 * ip + (qe & 1)) * 16 + r16e;
                     const int m = tile * p.TP + ml;
-                    const unsigned off = (ml < p.TP && m < p.M) ? (unsigned)m * (unsigned)p.out_cstride * ES + (unsigned)(nblk + (q >> 1) * 8 + 7 * 16) * ES : kBadOff;
+                    const unsigned off = (ml < p.TP && m < p.M) ? (unsigned)m * (unsigned)p.out_cstride * ES + (unsigned)(nblk + (qe >> 1) * 8 + 7 * 16) * ES : kBadOff;
                     r7[ip] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, off, 0, 0));
                 }
                 __builtin_amdgcn_s_barrier();            // A
                 __builtin_amdgcn_s_barrier();            // B
             }
-            // ---- epilogue: lane (r16, q) holds channels 16 cb + 4 q .. + 3 of pixel 16 i + r16.  One v_permlane16_swap per dword between
+            // ---- epilogue: lane (r16e, qe) holds channels 16 cb + 4 qe .. + 3 of pixel 16 i + r16e.  One v_permlane16_swap per dword between
             // the packed values of pixel blocks (i, i + 1) leaves every lane with 8 consecutive channels (16 bytes) of ONE pixel: even
-            // rows (q = 0, 2) pixel block i, odd rows pixel block i + 1, channel offset 8 (q >> 1).  Loads (bias once per tile, residual as
-            // 16-byte loads at the store addresses, swapped back into the accumulator layout) are issued ahead of their use.
+            // rows (qe = 0, 2) pixel block i, odd rows pixel block i + 1, channel offset 8 (qe >> 1).  The bias is already in the accumulators
+            // (mfma_group); the residual comes as 16-byte loads at the store addresses, swapped back into the accumulator layout.
             const int cbase = nblk + (chalf >= 0 ? chalf * 64 : 0);
-            float bz[NCB][4];
-            if (p.bias) {
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) load4(p.bias + cbase + cb * 16 + 4 * q, bz[cb]);
+            if constexpr (kStamp) {          // (the hand-over barriers, if any)
+                se1 = __builtin_readcyclecounter();
+                sc_epi[1] += (unsigned)(se1 - se0);
             }
-            if constexpr (kSkip) {          // the skip convolution's own bias (simple_unet.py:177-179)
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) {
-                    float t2[4];
-                    load4(p.bias2 + cbase + cb * 16 + 4 * q, t2);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bz[cb][e] += t2[e];
-                }
-            }
+            const bool no_store = kStamp && p.variant == 21;          // (experiment: the epilogue without its HBM writes)
 #pragma unroll
             for (int ip = 0; ip < 2; ++ip) {
-                const int ml = pxbase + (2 * ip + (q & 1)) * 16 + r16;          // the pixel this lane stores after the swap
+                const int ml = pxbase + (2 * ip + (qe & 1)) * 16 + r16e;          // the pixel this lane stores after the swap
                 const int m = tile * p.TP + ml;
                 const bool live = ml < p.TP && m < p.M;
-                const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES + (unsigned)(cbase + (q >> 1) * 8) * ES;
-                const float* embp = nullptr;
-                if (p.emb) {      // (not used by the U-Net any more: conv1's bias + embedding ride with the consuming GroupNorm)
-                    const int ml0 = pxbase + (2 * ip) * 16 + r16, ml1 = ml0 + 16;
-                    (void)ml0; (void)ml1;
-                }
+                const unsigned row_b = (unsigned)m * (unsigned)p.out_cstride * ES + (unsigned)(cbase + (qe >> 1) * 8) * ES;
                 u32x4 rres[NCB];
                 if (hand) {
 #pragma unroll
                     for (int cb = 0; cb < NCB - 1; ++cb)
-                        rres[cb] = *reinterpret_cast<const u32x4*>(Rl + cb * 8192 + ml * 32 + (q >> 1) * 16);
+                        rres[cb] = *reinterpret_cast<const u32x4*>(Rl + cb * 8192 + ml * 32 + (qe >> 1) * 16);
                     rres[NCB - 1] = r7[ip];
                 } else if (p.residual) {
 #pragma unroll
@@ -1202,18 +1288,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     float v0[4], v1[4];         // pixel blocks 2 ip and 2 ip + 1 in the accumulator layout
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v0[e] = acc[cb][2 * ip][e]; v1[e] = acc[cb][2 * ip + 1][e]; }
-                    if (p.bias) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v0[e] += bz[cb][e]; v1[e] += bz[cb][e]; }
-                    }
-                    if (p.emb) {
-                        const int m0 = tile * p.TP + pxbase + (2 * ip) * 16 + r16, m1 = m0 + 16;
-                        float t0[4], t1[4];
-                        load4(p.emb + (int64_t)((m0 < p.M ? m0 : 0) / (H * W)) * p.emb_stride + cbase + cb * 16 + 4 * q, t0);
-                        load4(p.emb + (int64_t)((m1 < p.M ? m1 : 0) / (H * W)) * p.emb_stride + cbase + cb * 16 + 4 * q, t1);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v0[e] += t0[e]; v1[e] += t1[e]; }
-                    }
                     if (p.residual) {
                         const u32x4 R = rres[cb];
                         const auto s0 = __builtin_amdgcn_permlane16_swap(R[0], R[2], false, false);
@@ -1228,10 +1302,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     const auto s0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
                     const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rso, live ? row_b + (unsigned)(cb * 16) * ES : kBadOff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rso, live && !no_store ? row_b + (unsigned)(cb * 16) * ES : kBadOff, 0, 0);
                 }
-                (void)embp;
             }
+            load_bias(next_chalf);          // the NEXT job's bias in the accumulator layout (first used by its first MFMAs)
+            if constexpr (kStamp) sc_epi[2] += (unsigned)(__builtin_readcyclecounter() - se1);      // conversion + store issue + the bias gather
         };
 
         {
@@ -1239,15 +1314,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             b_off = kWOFF + ((hc0 >= 0 ? hc0 * 64 : 0) + r16) * 128;
         }
         resolve_centres(job_tile(0));
+        load_bias(job_half(0));
         __builtin_amdgcn_s_barrier();                          // start-up barrier: weight tile 0 is in LDS
         if (kPrefetchW) load_wt(0, 0, 0, 0);
         for (int k = 0; k < njobs; ++k) {
             const int tile = job_tile(k), hc = job_half(k), ntile = job_tile(k + 1), nhc = job_half(k + 1);
             const int next_boff = kWOFF + ((nhc >= 0 ? nhc * 64 : 0) + r16) * 128;
-            if (hc < 0) run_job(IntTag<8>{}, tile, hc, next_boff);
-            else run_job(IntTag<4>{}, tile, hc, next_boff);
+            if (hc < 0) run_job(IntTag<8>{}, tile, hc, next_boff, nhc);
+            else run_job(IntTag<4>{}, tile, hc, next_boff, nhc);
             resolve_centres(ntile);
             asm volatile("" ::: "memory");
+        }
+        if constexpr (kStamp) {
+            if (wave == ((p.variant >= 30 && p.variant <= 33) ? p.variant - 30 : 0) && lane == 0 && p.stamps) {
+                unsigned* o = p.stamps + (size_t)blockIdx.x * 128 + 64;
+#pragma unroll
+                for (int i = 0; i < 13; ++i) { o[i] = sc_work[i]; o[16 + i] = sc_bar[i]; }
+                o[32] = sc_epi[0]; o[33] = sc_epi[1]; o[34] = sc_epi[2]; o[35] = (unsigned)njobs;
+            }
         }
         return;
     }
@@ -1557,6 +1641,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 
 }  // namespace
 
+// development: the buffer the kStamp instantiations write their per-K-step cycle sums to (tools/step_stamps.py); while it is set the
+// wave-specialised 16x16x32 launches (plain and folded) run their stamped instantiation
+static unsigned* g_stamps = nullptr;
+static int64_t g_stamp_bytes = 0;
+extern "C" int gmk_dev_set_stamp_buffer(void* buf, int64_t bytes) { g_stamps = (unsigned*)buf; g_stamp_bytes = bytes; return 0; }
+
 // The ONE eligibility rule of the halo kernels (gmk_conv3x3_halo_try launches by it, gmk_conv_gn_fusable answers by it): geometry of
 // the tiling, LDS capacity, 32-bit buffer offsets, enough tiles to fill the chip; fused_gn adds the conditions of the in-kernel
 // GroupNorm-apply (plain 3x3 only, a tile of R rows of the global row list touches at most two samples).
@@ -1608,7 +1698,7 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     p.M = (int)M;
     p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1; p.nbw = (unsigned)nbw; p.nbo = (unsigned)nbo;
     p.gn_scale = gn_scale; p.gn_shift = gn_shift; p.gn_stride = gn_stride;
-    p.stats = nullptr; p.stats_groups = out_cstride / 4;
+    p.stats = nullptr; p.stats_groups = out_cstride / 4; p.stamps = nullptr;
     p.variant = gmk_kernel_choice(3, "GMK_DEV_VARIANT") & 0xFF;      // code variant (A/B switches, see below)
     if (stats && cout == out_cstride && stats_bytes >= ntiles * 8 * 2 * (int64_t)(out_cstride / 4) * 2 * 4 && H * W >= 32) p.stats = stats;
     p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 2); p.inv_w = 1.0f / (float)W;
@@ -1632,7 +1722,9 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     // kind: 0 the 8-compute-wave kernel (variants 1, 3, or statistics wanted), 1 fused GroupNorm-apply + SiLU in the producer waves
     // (tables from gmk_gn_stats), 2 variant 4 (no weight prefetch), 3 the wave-specialised kernel
     const bool regfill = p.variant == 11 && !gn_scale && !p.stats && !upsample;      // experiment: halo pieces through registers, no transform
-    const int kind = (gn_scale || regfill) ? 1 : (p.variant == 4 && !p.stats) ? 2 : (!p.stats && (use16 || (p.variant != 1 && p.variant != 3))) ? 3 : 0;
+    // (an `emb` addend in the epilogue - not used by the U-Net any more: conv1's bias + embedding ride with the consuming GroupNorm - is served by
+    // the 8-compute-wave kernel only since round 6: the wave-specialised consumers' epilogue carries no per-sample loads)
+    const int kind = emb ? 0 : (gn_scale || regfill) ? 1 : (p.variant == 4 && !p.stats) ? 2 : (!p.stats && (use16 || (p.variant != 1 && p.variant != 3))) ? 3 : 0;
     auto launch = [&](auto tag) {
         typedef decltype(tag) T;
         if (kind == 1) {
@@ -1640,7 +1732,10 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
             else conv3x3_halo_ws_kernel<T, true, 32, true><<<grid, 512, 0, stream>>>(p);
         } else if (kind == 2) conv3x3_halo_ws_kernel<T, false><<<grid, 512, 0, stream>>>(p);
         else if (kind == 3) {
-            if (use16) conv3x3_halo_ws_kernel<T, true, 16><<<grid, 512, 0, stream>>>(p);
+            if (use16 && g_stamps && g_stamp_bytes >= (int64_t)grid.x * 512) {
+                p.stamps = g_stamps;
+                conv3x3_halo_ws_kernel<T, true, 16, false, false, true><<<grid, 512, 0, stream>>>(p);
+            } else if (use16) conv3x3_halo_ws_kernel<T, true, 16><<<grid, 512, 0, stream>>>(p);
             else conv3x3_halo_ws_kernel<T, true, 32><<<grid, 512, 0, stream>>>(p);
         } else conv3x3_halo_kernel<T><<<grid, 512, 0, stream>>>(p);
     };
@@ -1694,7 +1789,11 @@ extern "C" int gmk_conv3x3_skipfold(const void* src, int c0, int B, int H, int W
         if (g.ntiles > G && rem > 0 && 2 * rem <= G && p.variant != 6) { p.nfull = (int)g.ntiles - rem; p.nhalf = 2 * rem; }
         else if (2 * g.ntiles <= ncu && p.variant != 6 && p.variant != 8) { p.nfull = 0; p.nhalf = 2 * (int)g.ntiles; grid.x = (unsigned)p.nhalf; }
     }
-    if (dtype == GMK_F16) conv3x3_halo_ws_kernel<f16_t, true, 16, false, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+    if (g_stamps && g_stamp_bytes >= (int64_t)grid.x * 512) {      // development: the stamped instantiation (tools/step_stamps.py)
+        p.stamps = g_stamps;
+        if (dtype == GMK_F16) conv3x3_halo_ws_kernel<f16_t, true, 16, false, true, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+        else conv3x3_halo_ws_kernel<bf16_t, true, 16, false, true, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+    } else if (dtype == GMK_F16) conv3x3_halo_ws_kernel<f16_t, true, 16, false, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
     else conv3x3_halo_ws_kernel<bf16_t, true, 16, false, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
     gmk_note_kernel(7);
     return gmk_check_launch("gmk_conv3x3_skipfold");

@@ -43,6 +43,10 @@ int gmk_set_kernel_choice(int conv, int wgrad, int gn);
 /* development aid: a free integer (GMK_DEV_VARIANT) that experimental code paths may read for in-process A/B runs
  * (tools/step_ab.py); 0 / unset = the shipped behaviour */
 int gmk_set_dev_variant(int v);
+/* development aid (tools/step_stamps.py): while a device buffer of at least 512 bytes per workgroup is set, the wave-specialised 3x3 halo
+ * launches (gmk_conv_igemm's 16-bit stride-1 3x3 path, gmk_conv3x3_skipfold) run an instrumented instantiation whose wave 4 (producer) and
+ * wave 0 (consumer) write per-K-step shader-cycle sums [workgroup][2][64] into it; buf = NULL returns to the shipped kernels */
+int gmk_dev_set_stamp_buffer(void* buf, int64_t bytes);
 /* number of CUs the persistent convolution kernels may occupy (8..256, default 256 = the whole chip).  New with the build (the
  * reference has no multi-GPU path): data-parallel runs leave a few CUs to RCCL's all-reduce kernels, which otherwise queue
  * behind a chip-filling persistent grid */
