@@ -465,9 +465,26 @@ template <int N> struct IntTag { static constexpr int value = N; };
 // kStamp (development, tools/step_stamps.py): wave 4 (a producer) and wave 0 (a consumer) of every workgroup sum, per K-step index, the shader
 // cycles (s_memtime) they spend (producer) issuing / in the counted vmcnt wait / in the barrier, (consumer) working / in the barrier, and
 // write the sums to p.stamps[workgroup][2][64] at the end: who waits for whom in each step.  Product launches use kStamp = false.
-template <typename T, bool kPrefetchW, int kShape = 32, bool kFuse = false, bool kSkip = false, bool kStamp = false>
+//
+// kMerge (round 6; kSkip kernels whose tile needs at most 384 halo slots = 6 fill pieces: 32 x 32 and 16 x 16): the eight dense sub-phases run
+// INSIDE the K-step of the tap in front of them - 9 barriers per phase instead of 13.  The step stamps (tools/step_stamps.py) showed a K-step
+// costing ~ 1,650 cycles whatever its MFMA work (512 or 1,024 cycles): barrier jitter and the fragment-read latency exposed behind every
+// barrier, not the arithmetic.  What made the extra barriers necessary was the weight ring (three 16-KiB slots: tap q, tap q + 1 prefetched,
+// tap q + 2 in flight - no room for a dense tile); with 6-piece halos the SEVENTH 8-KiB piece of each half-buffer is free, and the dense weight
+// tiles (8 KiB) alternate between the two of them: e0, e2 in the piece of the buffer being filled, e1, e3 in that of the buffer being read.
+//   K-steps of phase ph:   t0 t1 t2 [t3 e0] [t4 e1] [t5 e2] [t6 e3] t7 t8
+//   issued in            t0: W(e0), E0 -> pieces 0,1   t1: E1 -> 2,3   t2: E2 -> 4,5   t3: W(e1)   t4: W(e2), E3 -> 0,1 (e0 is done)
+//                        t5: W(e3), NEXT[2,3]   t6: NEXT[4,5]   t7: NEXT[0,1]      (+ the tap weights of the step after next in every step)
+// Tap weights first, dense weights second, pixel pieces last in every step: only the step's four pixel instructions may still fly at the next
+// barrier (`vmcnt(4)`; `vmcnt(0)` at t0 and at t4, whose dense weights were issued one step earlier).  In the consumers the dense fragments take the
+// fragment set that held the tap's first k half (free after its first four groups), so the sets swap roles behind every dense sub-phase.
+// kRes: -1 the residual's presence is a run-time property of the launch (p.residual); 0 / 1 compiled in: the 16x16x32 consumers' epilogue
+// then has no branch per 16-byte store (the blocks of a tile interleave freely); the launcher picks 0 / 1 for the plain form, 0 for the folded.
+template <typename T, bool kPrefetchW, int kShape = 32, bool kFuse = false, bool kSkip = false, bool kStamp = false, bool kMerge = false, int kRes = -1>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParams p) {
+    static_assert(!(kSkip && kRes > 0), "the folded skip convolution has no residual (the skip convolution is the residual)");
     static_assert(!kSkip || (kPrefetchW && kShape == 16 && !kFuse), "the folded skip convolution is built on the plain 16x16x32 form");
+    static_assert(!kMerge || kSkip, "merged dense sub-phases belong to the folded skip convolution");
     static_assert(!kStamp || (kPrefetchW && kShape == 16 && !kFuse), "stamps exist for the shipped 16x16x32 forms only");
     typedef typename Frag16<T>::type frag_t;
     typedef typename Frag16<T>::half_type half_t;
@@ -806,18 +823,86 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 #pragma unroll
             for (int c = 0; c < 2; ++c)
                 wdh[c] = (unsigned)(p.nsk0 + nblk + c * 64 + 16 * pw + drow) * (unsigned)p.sk_ktot * ES + dchunk;
-            auto issue_wd = [&](int stage, int k, int c) {      // c < 0: all 128 rows (2 instructions), else the 64 rows of channel half c (1)
+            // dense weight tile k into LDS at byte offset `base` (ring slot `stage`: kWOFF + stage * kWST; merged form: piece 6 of a half-buffer)
+            auto issue_wd_at = [&](int base, int k, int c) {      // c < 0: all 128 rows (2 instructions), else the 64 rows of channel half c (1)
                 if (c < 0) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + (32 * pw + 16 * u) * 64);
+                        GMK_LDS char* dst = (GMK_LDS char*)(smem + base + (32 * pw + 16 * u) * 64);
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rswk, (GMK_LDS void*)dst, 16, wdo[u], (unsigned)k * 64u, 0, 0);
                     }
                 } else {
-                    GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + (c * 64 + 16 * pw) * 64);
+                    GMK_LDS char* dst = (GMK_LDS char*)(smem + base + (c * 64 + 16 * pw) * 64);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rswk, (GMK_LDS void*)dst, 16, c ? wdh[1] : wdh[0], (unsigned)k * 64u, 0, 0);
                 }
             };
+            auto issue_wd = [&](int stage, int k, int c) { issue_wd_at(kWOFF + stage * kWST, k, c); };
+            if constexpr (kMerge) {
+                // ------------------------------------------------------------------------------ merged form: 9 K-steps per phase (see the kernel's header)
+                auto wait4 = [&](bool all) __attribute__((always_inline)) {
+                    if (all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                };
+                int sq = 2;
+                int tile = job_tile(0), ch = job_half(0);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { resolve_piece(tile, j); issue_fill(0, 0, j); }
+                issue_w(0, 0, 0, ch);
+                issue_w(1, 1, 0, ch);
+                if (ch < 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                      // start-up barrier: weight tile 0 and the first halo half are in LDS
+                unsigned st_iss[13] = {}, st_wait[13] = {}, st_bar[13] = {};
+                unsigned long long st_prev = 0, st_t0 = 0, st_t1 = 0;
+                for (int k = 0; k < njobs; ++k) {
+                    const int ntile = job_tile(k + 1), nch = job_half(k + 1);
+                    resolve_dense(tile);
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph) {
+                        const int fb = ph ^ 1, hb = ph;            // the half-buffer this phase fills / reads
+                        auto next_piece = [&](int j) __attribute__((always_inline)) {
+                            if (ph == 1) resolve_piece(ntile, j);
+                            issue_fill(fb, ph ^ 1, j);
+                        };
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) {
+                            if constexpr (kStamp) { st_t0 = __builtin_readcyclecounter(); if (st_prev) st_iss[i] += (unsigned)(st_t0 - st_prev); }
+                            wait4(i == 0 || i == 4);
+                            if constexpr (kStamp) st_t1 = __builtin_readcyclecounter();
+                            __builtin_amdgcn_s_barrier();
+                            if constexpr (kStamp) { st_prev = __builtin_readcyclecounter(); st_wait[i] += (unsigned)(st_t1 - st_t0); st_bar[i] += (unsigned)(st_prev - st_t1); }
+                            // tap weights of the step after next (the first two of the next phase / the next job behind taps 7 and 8)
+                            if (i < 7) issue_w(sq, i + 2, ph, ch);
+                            else issue_w(sq, i - 7, ph ^ 1, ph == 1 ? nch : ch);
+                            // dense weight tiles: piece 6 of the filling (e0, e2) / of the reading (e1, e3) half-buffer
+                            if (i == 0) issue_wd_at(fb * kHB + 6 * 8192, 4 * ph + 0, ch);
+                            if (i == 3) issue_wd_at(hb * kHB + 6 * 8192, 4 * ph + 1, ch);
+                            if (i == 4) issue_wd_at(fb * kHB + 6 * 8192, 4 * ph + 2, ch);
+                            if (i == 5) issue_wd_at(hb * kHB + 6 * 8192, 4 * ph + 3, ch);
+                            // pixel pieces
+                            if (i == 0) issue_dense(fb, 0, 4 * ph + 0);
+                            if (i == 1) issue_dense(fb, 2, 4 * ph + 1);
+                            if (i == 2) issue_dense(fb, 4, 4 * ph + 2);
+                            if (i == 4) issue_dense(fb, 0, 4 * ph + 3);
+                            if (i == 5) { next_piece(2); next_piece(3); }
+                            if (i == 6) { next_piece(4); next_piece(5); }
+                            if (i == 7) { next_piece(0); next_piece(1); }
+                            sq = sq == 2 ? 0 : sq + 1;
+                        }
+                    }
+                    tile = ntile; ch = nch;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the speculative DMA before the LDS is released
+                if constexpr (kStamp) {
+                    if (pw == ((p.variant >= 30 && p.variant <= 33) ? p.variant - 30 : 0) && lane == 0 && p.stamps) {
+                        unsigned* o = p.stamps + (size_t)blockIdx.x * 128;
+#pragma unroll
+                        for (int i = 0; i < 13; ++i) { o[i] = st_iss[i]; o[16 + i] = st_wait[i]; o[32 + i] = st_bar[i]; }
+                        o[48] = (unsigned)njobs;
+                    }
+                }
+                return;
+            }
             // weight tile of step i (0..12, or 13 / 14 = steps 0 / 1 of the following phase) of phase ph: steps 4, 6, 8, 10 are the dense ones;
             // c / cn: channel half of this job / of the job whose phase 0 follows this job's phase 1 (-1: whole job)
             auto issue_weights = [&](int stage, int ph, int i, int c, int cn) __attribute__((always_inline)) {
@@ -1056,13 +1141,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         const int d_off = (((wave & 1) * 64 + r16) << 6) + ((q ^ ((r16 >> 2) & 3)) << 4);
         const int dw_off = kWOFF + (r16 << 6) + ((q ^ ((r16 >> 2) & 3)) << 4);
         int dw_half = 0;                                                           // byte offset of the job's channel half in a dense weight tile
-        auto load_wt_d = [&](int stg, int pair, int set) {                         // channel blocks 2 pair, 2 pair + 1 of a dense weight tile
-            int o = dw_off;
+        auto load_wt_d_at = [&](int base, int pair, int set) {                    // channel blocks 2 pair, 2 pair + 1 of the dense weight tile at LDS byte `base`
+            int o = dw_off - kWOFF;
             asm volatile("" : "+v"(o));
-            const char* Wb = smem + stg * kWST + dw_half + pair * 2048 + o;
+            const char* Wb = smem + base + dw_half + pair * 2048 + o;
             wt[set][0] = *reinterpret_cast<const frag_t*>(Wb);
             wt[set][1] = *reinterpret_cast<const frag_t*>(Wb + 1024);
         };
+        auto load_wt_d = [&](int stg, int pair, int set) { load_wt_d_at(kWOFF + stg * kWST, pair, set); };
         // This block's 128 bias values (+ the folded skip convolution's own, simple_unet.py:177-179) live in TWO registers per consumer wave for
         // the whole launch: lane l holds channels nblk + l and nblk + 64 + l.  A tile's accumulator-layout copy (lane (r16, q): channels
         // 16 cb + 4 q .. + 3 of block cb) is gathered from them by 32 ds_bpermute_b32 - no memory instruction: the per-tile global loads this
@@ -1122,6 +1208,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const bool dense_after = kSkip && tap >= 3 && tap <= 6;      // a dense sub-phase of the folded skip convolution follows this tap
+                    // merged form: the fragment set that holds this tap's first k half (the other one holds the second); the sets swap roles behind
+                    // every dense sub-phase, whose fragments take the first-half set once its four groups are done
+                    const int f = (kMerge && (tap == 4 || tap == 6)) ? 1 : 0;
+                    // LDS byte offset of the dense weight tile of sub-phase tap - 3 (merged form): piece 6 of the filling / reading half-buffer
+                    const int dwb = (((tap - 3) & 1) ? hbuf : (hbuf ^ 1)) * kHB + 6 * 8192;
                     step_barrier(tap);
                     if (tap == 0) { addr(0); load_px(hbuf, 0, 0, 0, 4); }      // the phase's halo only became valid with this barrier
                     if (!kPrefetchW) load_wt(st, 0, 0, 0);
@@ -1134,18 +1225,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         // fragments during the first half's last two groups; in the tap's last group the next tap's addresses and
                         // first pixel fragments (same halo) and the next step's first weight fragments (landed at this barrier)
                         if (!last) load_wt(st, (g + 1) / NG, (g + 1) % NG, (g + 1) & 1);
-                        if (k2 == 0 && pair == NG - 2) load_px(hbuf, 1, 1, 0, 2);
-                        if (k2 == 0 && pair == NG - 1) load_px(hbuf, 1, 1, 2, 4);
+                        if (k2 == 0 && pair == NG - 2) load_px(hbuf, 1, f ^ 1, 0, 2);
+                        if (k2 == 0 && pair == NG - 1) load_px(hbuf, 1, f ^ 1, 2, 4);
                         if (last) {
                             st = st == 2 ? 0 : st + 1;
                             if (tap < 8 && !dense_after) { addr(tap + 1); load_px(hbuf, 0, 0, 0, 4); }
                             if (tap == 8 && ph + 1 == nph) b_off = next_boff;
-                            if (dense_after) load_wt_d(st, 0, 0);      // the dense step's first weight fragments (landed at this barrier)
+                            if (dense_after && kMerge) {
+                                // the dense sub-phase's pixel fragments (landed at this step's barrier) and first weight fragments
+                                int o = d_off;
+                                asm volatile("" : "+v"(o));          // per-step addresses stay out of loop-invariant hoisting (registers)
+                                const char* Eb = smem + (hbuf ^ 1) * kHB + ((tap == 3 || tap == 6 ? 0 : tap == 4 ? 2 : 4) + hfs) * 8192 + o;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) px[f][i] = *reinterpret_cast<const frag_t*>(Eb + i * 1024);
+                                load_wt_d_at(dwb, 0, 0);
+                            } else if (dense_after) load_wt_d(st, 0, 0);      // the dense step's first weight fragments (landed at this barrier)
                             else if (kPrefetchW) load_wt(st, 0, 0, 0);
                         }
-                        if (kFirst && tap == 0 && k2 == 0) mfma_group(pair, g & 1, k2, IntTag<1>{}); else mfma_group(pair, g & 1, k2, IntTag<0>{});
+                        if (kFirst && tap == 0 && k2 == 0) mfma_group(pair, g & 1, k2 ^ f, IntTag<1>{}); else mfma_group(pair, g & 1, k2 ^ f, IntTag<0>{});
                         // one read per MFMA where there are reads to hide; the address VALU of the tap's last group rides along
-                        if (last && tap < 8 && !dense_after) {
+                        if (last && dense_after && kMerge) {
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        } else if (last && tap < 8 && !dense_after) {
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1173,8 +1279,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                             // rows sit in the half-buffer this phase is filling.  4 pixel fragments (this wave's 64 pixels, one k chunk per lane)
                             // behind the barrier, then 4 groups of 8 MFMAs (2 channel blocks x 4 pixel blocks) with the next group's weight
                             // fragments read underneath; the last group brings the next tap's addresses, pixel and weight fragments.
-                            step_barrier(9 + tap - 3);
-                            {
+                            if constexpr (!kMerge) {
+                                step_barrier(9 + tap - 3);
                                 int o = d_off;
                                 asm volatile("" : "+v"(o));          // per-step addresses stay out of loop-invariant hoisting (registers)
                                 const char* Eb = smem + (hbuf ^ 1) * kHB + (skip_slot(tap - 3) + hfs) * 8192 + o;
@@ -1185,13 +1291,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 #pragma unroll
                             for (int g = 0; g < NG; ++g) {                   // NG channel-block pairs: 4 (whole job) or 2 (half job)
                                 const bool last = g == NG - 1;
-                                if (!last) load_wt_d(st, g + 1, (g + 1) & 1);
+                                if (!last) { if (kMerge) load_wt_d_at(dwb, g + 1, (g + 1) & 1); else load_wt_d(st, g + 1, (g + 1) & 1); }
                                 else {
-                                    st = st == 2 ? 0 : st + 1;
-                                    addr(tap + 1); load_px(hbuf, 0, 0, 0, 4);
+                                    if (!kMerge) st = st == 2 ? 0 : st + 1;      // (merged form: the dense tile is not in the ring)
+                                    addr(tap + 1); load_px(hbuf, 0, kMerge ? f ^ 1 : 0, 0, 4);
                                     load_wt(st, 0, 0, 0);
                                 }
-                                mfma_group(g, g & 1, 1, IntTag<0>{});
+                                mfma_group(g, g & 1, kMerge ? f : 1, IntTag<0>{});
                                 if (last) {
 #pragma unroll
                                     for (int k = 0; k < 4; ++k) {
@@ -1242,7 +1348,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             // residual hand-over (see the producers): units 0..6 of the tile's residual arrive in the halo buffer this job's last phase
             // just finished with; unit 7 (channels 112..127) is loaded from memory here, ahead of the two barriers that hide its latency
             constexpr bool kHandJob = kPrefetchW && !kFuse && NCB == 8;
-            const bool hand = kHandJob && p.residual != nullptr && p.variant != 7;
+            bool has_res = p.residual != nullptr;
+            if constexpr (kRes >= 0) has_res = kRes != 0;
+            const bool hand = kHandJob && has_res && p.variant != 7;
             u32x4 r7[2];
             const char* Rl = smem + (hbuf ^ 1) * kHB;
             if (hand) {
@@ -1278,7 +1386,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     for (int cb = 0; cb < NCB - 1; ++cb)
                         rres[cb] = *reinterpret_cast<const u32x4*>(Rl + cb * 8192 + ml * 32 + (qe >> 1) * 16);
                     rres[NCB - 1] = r7[ip];
-                } else if (p.residual) {
+                } else if (has_res) {
 #pragma unroll
                     for (int cb = 0; cb < NCB; ++cb)
                         rres[cb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, live ? row_b + (unsigned)(cb * 16) * ES : kBadOff, 0, 0));
@@ -1288,7 +1396,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     float v0[4], v1[4];         // pixel blocks 2 ip and 2 ip + 1 in the accumulator layout
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v0[e] = acc[cb][2 * ip][e]; v1[e] = acc[cb][2 * ip + 1][e]; }
-                    if (p.residual) {
+                    if (has_res) {
                         const u32x4 R = rres[cb];
                         const auto s0 = __builtin_amdgcn_permlane16_swap(R[0], R[2], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(R[1], R[3], false, false);
@@ -1672,7 +1780,7 @@ int gmk_halo_geometry(int B, int H, int W, int c0, int c1, int w_rows, int cout,
     if (ntiles < min_tiles) return 0;                         // not enough tiles to fill the chip: im2col kernels
     if (fused_gn && (upsample || R > H)) return 0;
     if (g) {
-        g->R = R; g->TP = R * W; g->rows_total = rows_total; g->M = M; g->ntiles = ntiles;
+        g->R = R; g->TP = R * W; g->slots = ner * (W + 2); g->rows_total = rows_total; g->M = M; g->ntiles = ntiles;
         g->nb0 = nb0; g->nb1 = nb1; g->nbw = nbw; g->nbo = nbo;
     }
     return 1;
@@ -1735,7 +1843,8 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
             if (use16 && g_stamps && g_stamp_bytes >= (int64_t)grid.x * 512) {
                 p.stamps = g_stamps;
                 conv3x3_halo_ws_kernel<T, true, 16, false, false, true><<<grid, 512, 0, stream>>>(p);
-            } else if (use16) conv3x3_halo_ws_kernel<T, true, 16><<<grid, 512, 0, stream>>>(p);
+            } else if (use16 && residual) conv3x3_halo_ws_kernel<T, true, 16, false, false, false, false, 1><<<grid, 512, 0, stream>>>(p);
+            else if (use16) conv3x3_halo_ws_kernel<T, true, 16, false, false, false, false, 0><<<grid, 512, 0, stream>>>(p);
             else conv3x3_halo_ws_kernel<T, true, 32><<<grid, 512, 0, stream>>>(p);
         } else conv3x3_halo_kernel<T><<<grid, 512, 0, stream>>>(p);
     };
@@ -1789,12 +1898,19 @@ extern "C" int gmk_conv3x3_skipfold(const void* src, int c0, int B, int H, int W
         if (g.ntiles > G && rem > 0 && 2 * rem <= G && p.variant != 6) { p.nfull = (int)g.ntiles - rem; p.nhalf = 2 * rem; }
         else if (2 * g.ntiles <= ncu && p.variant != 6 && p.variant != 8) { p.nfull = 0; p.nhalf = 2 * (int)g.ntiles; grid.x = (unsigned)p.nhalf; }
     }
-    if (g_stamps && g_stamp_bytes >= (int64_t)grid.x * 512) {      // development: the stamped instantiation (tools/step_stamps.py)
-        p.stamps = g_stamps;
-        if (dtype == GMK_F16) conv3x3_halo_ws_kernel<f16_t, true, 16, false, true, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
-        else conv3x3_halo_ws_kernel<bf16_t, true, 16, false, true, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
-    } else if (dtype == GMK_F16) conv3x3_halo_ws_kernel<f16_t, true, 16, false, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
-    else conv3x3_halo_ws_kernel<bf16_t, true, 16, false, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+    // merged dense sub-phases (9 barriers per phase) where a tile's halo fits 6 of the 7 fill pieces: 32 x 32, 16 x 16 (GMK_DEV_VARIANT=12: the A/B switch)
+    const bool merge = g.slots <= 384 && p.variant != 12;
+    const bool stamp = g_stamps && g_stamp_bytes >= (int64_t)grid.x * 512;      // development: the stamped instantiations (tools/step_stamps.py)
+    if (stamp) p.stamps = g_stamps;
+    auto launch = [&](auto tag) {
+        typedef decltype(tag) T;
+        if (merge && stamp) conv3x3_halo_ws_kernel<T, true, 16, false, true, true, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+        else if (merge) conv3x3_halo_ws_kernel<T, true, 16, false, true, false, true, 0><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+        else if (stamp) conv3x3_halo_ws_kernel<T, true, 16, false, true, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+        else conv3x3_halo_ws_kernel<T, true, 16, false, true, false, false, 0><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+    };
+    if (dtype == GMK_F16) launch(f16_t{});
+    else launch(bf16_t{});
     gmk_note_kernel(7);
     return gmk_check_launch("gmk_conv3x3_skipfold");
 }

@@ -48,7 +48,7 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
                          void* out, int out_cstride, int min_tiles, int upsample, float* stats, int64_t stats_bytes,
                          const float* gn_scale, const float* gn_shift, int gn_stride, int dtype, hipStream_t stream);
 
-struct HaloGeometry { int R, TP; int64_t rows_total, M, ntiles, nb0, nb1, nbw, nbo; };
+struct HaloGeometry { int R, TP, slots; int64_t rows_total, M, ntiles, nb0, nb1, nbw, nbo; };      // slots: halo slots a tile uses (<= 448)
 int gmk_halo_geometry(int B, int H, int W, int c0, int c1, int w_rows, int cout, int out_cstride, int min_tiles, int upsample,
                       int fused_gn, HaloGeometry* g);      // conv_halo.hip: 1 if the halo kernels take this problem (g filled), else 0
 

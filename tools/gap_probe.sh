@@ -2,7 +2,7 @@
 # Idle time between consecutive kernels of the sampler loop (kernel trace of tools/sampler_probe.py): usage tools/gap_probe.sh cfg1 [steps]
 CFG=${1:-cfg1}; N=${2:-30}
 OUT=/tmp/gmk_gap; KEEP=gpurun_out/gap; mkdir -p $OUT $KEEP
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+REPO="$(cd "$(dirname "$0")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp; cd "$REPO"
 rocprofv3 --kernel-trace --output-format csv -d $OUT/$CFG -o gap -- python tools/sampler_probe.py $CFG $N > $OUT/$CFG.log 2>&1 || exit 1
 python - <<PY
 import csv, glob

@@ -10,12 +10,12 @@ def instantiation(name):
     if not base.startswith("conv3x3_halo") and not base.startswith("conv_subpixel"):
         return None
     if name.startswith("_Z"):
-        m = re.search(r"kernelI(DF16_|DF16b)((?:L[bi]\d+E)*)E", name)
+        m = re.search(r"kernelI(DF16_|DF16b)((?:L[bi]n?\d+E)*)E", name)
         if not m:
             return None
         typ = "f16" if m.group(1) == "DF16_" else "bf16"
-        args = re.findall(r"L([bi])(\d+)E", m.group(2))
-        vals = [int(v) for _, v in args]
+        args = re.findall(r"L([bi])(n?)(\d+)E", m.group(2))
+        vals = [-int(v) if neg else int(v) for _, neg, v in args]
     else:
         m = re.search(r"kernel<(.*)>\(", name)
         if not m:
@@ -24,15 +24,17 @@ def instantiation(name):
         typ = "bf16" if "_Accum" in body or "bfloat" in body or "__bf16" in body else "f16"
         vals = [1 if t.strip() == "true" else 0 if t.strip() == "false" else int(t) for t in body.split(",") if t.strip() in ("true", "false") or t.strip().lstrip("-").isdigit()]
     tags = [typ]
-    if base == "conv3x3_halo_ws_kernel":          # <T, kPrefetchW, kShape, kFuse, kSkip>
+    if base == "conv3x3_halo_ws_kernel":          # <T, kPrefetchW, kShape, kFuse, kSkip, kStamp, kMerge, kRes> (the merged / unmerged folded forms and the
+                                                  # residual / no-residual plain forms share a key: same work per launch)
         if len(vals) >= 3 and vals[2]:
             tags.append("+gn")
         if len(vals) >= 4 and vals[3]:
             tags.append("+skip")
     elif base == "conv_subpixel_ws_kernel":       # <T, kMode>
         # rocprofv3's demangler garbles the FIRST literal behind a bf16 type argument ("<bool _Accum, int, E>": the value of Li1E is lost, while
-        # Li2E stays mangled and is parsed above): the product launches bf16 instances of modes 1 and 2 only, so a bf16 name without a value is mode 1
-        tags.append({0: "upsample", 1: "transposed", 2: "upsample dgrad"}.get(vals[0] if vals else (1 if typ == "bf16" else -1), "?"))
+        # Li2E stays mangled and is parsed above).  The counter passes therefore run with --mangled-kernels since round 6 (tools/profile_r06.sh);
+        # a demangled bf16 name without a value stays "?" instead of being guessed (it was taken for mode 1, wrong for bf16 activations)
+        tags.append({0: "upsample", 1: "transposed", 2: "upsample dgrad"}.get(vals[0] if vals else -1, "?"))
     else:
         tags += [str(v) for v in vals]
     return f"{base}<{','.join(tags)}>"
