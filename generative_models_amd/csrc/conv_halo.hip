@@ -480,11 +480,21 @@ template <int N> struct IntTag { static constexpr int value = N; };
 // fragment set that held the tap's first k half (free after its first four groups), so the sets swap roles behind every dense sub-phase.
 // kRes: -1 the residual's presence is a run-time property of the launch (p.residual); 0 / 1 compiled in: the 16x16x32 consumers' epilogue
 // then has no branch per 16-byte store (the blocks of a tile interleave freely); the launcher picks 0 / 1 for the plain form, 0 for the folded.
-template <typename T, bool kPrefetchW, int kShape = 32, bool kFuse = false, bool kSkip = false, bool kStamp = false, bool kMerge = false, int kRes = -1>
+// kRing4 (round 6; plain form without a residual whose tile needs at most 384 halo slots): the two halo half-buffers shrink to 6 pieces (48 KiB)
+// and the freed 16 KiB become a FOURTH weight-ring slot; the producers issue the weight tile of step q + 3 in step q.  With three slots
+// (tap q being read, q + 1 landed for the consumers' prefetch, q + 2 in flight) the tile issued in step q - 1 had to LAND before barrier q + 1:
+// the producers spent 150 - 370 cycles of every 1,650-cycle K-step in that wait and reached the barrier about as late as the consumers, so
+// every step paid for the slower of the two (tools/step_stamps.py).  With four slots a weight tile has two steps to land, the producers'
+// step is their issue time alone, and the barrier waits for the consumers only.
+template <typename T, bool kPrefetchW, int kShape = 32, bool kFuse = false, bool kSkip = false, bool kStamp = false, bool kMerge = false, int kRes = -1, bool kRing4 = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParams p) {
     static_assert(!(kSkip && kRes > 0), "the folded skip convolution has no residual (the skip convolution is the residual)");
     static_assert(!kSkip || (kPrefetchW && kShape == 16 && !kFuse), "the folded skip convolution is built on the plain 16x16x32 form");
     static_assert(!kMerge || kSkip, "merged dense sub-phases belong to the folded skip convolution");
+    static_assert(!kRing4 || (kPrefetchW && kShape == 16 && !kFuse && !kSkip && kRes == 0), "the four-slot weight ring is built for the plain 16x16x32 form without a residual");
+    constexpr int HB = kRing4 ? 6 * 8192 : kHB;          // bytes of a halo half-buffer
+    constexpr int WOFF = 2 * HB;                         // the weight ring behind them
+    constexpr int RING = kRing4 ? 4 : 3;                 // its slots (WOFF + RING * kWST = 160 KiB either way)
     static_assert(!kStamp || (kPrefetchW && kShape == 16 && !kFuse), "stamps exist for the shipped 16x16x32 forms only");
     typedef typename Frag16<T>::type frag_t;
     typedef typename Frag16<T>::half_type half_t;
@@ -593,7 +603,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             const unsigned koff_b = (unsigned)(second ? kelem - p.c0 : kelem) * ES;      // scalar: rides in the instruction's soffset
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                GMK_LDS char* dst = (GMK_LDS char*)(smem + hbuf * kHB + j * 8192 + (pw * 2 + u) * 1024);
+                GMK_LDS char* dst = (GMK_LDS char*)(smem + hbuf * HB + j * 8192 + (pw * 2 + u) * 1024);
                 if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (GMK_LDS void*)dst, 16, hvoff[j][u], koff_b, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (GMK_LDS void*)dst, 16, hvoff[j][u], koff_b, 0, 0);
             }
@@ -601,12 +611,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         auto issue_w = [&](int stage, int tap, int ph, int c) {      // c < 0: all 128 rows (4 instructions), else rows of channel half c (2)
             const unsigned wk = (unsigned)tap * p.w_tap_stride_b + ((unsigned)ph << 7);      // scalar: soffset
             if (c < 0) {
-                GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + pw * 4096);
+                GMK_LDS char* dst = (GMK_LDS char*)(smem + WOFF + stage * kWST + pw * 4096);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(dst + u * 1024), 16, w_off[u], wk, 0, 0);
             } else {
-                GMK_LDS char* dst = (GMK_LDS char*)(smem + kWOFF + stage * kWST + (c * 64 + 16 * pw) * 128);
+                GMK_LDS char* dst = (GMK_LDS char*)(smem + WOFF + stage * kWST + (c * 64 + 16 * pw) * 128);
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (GMK_LDS void*)(dst + u * 1024), 16, c ? wh_off1[u] : wh_off0[u], wk, 0, 0);
@@ -702,7 +712,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         else if (m1 == mv) o = xform(L[set][u], hp, IntTag<1>{});
                         else o = xform(L[set][u], hp, IntTag<2>{});
                     }
-                    char* dst = smem + hb * kHB + j * 8192 + (pw * 2 + u) * 1024 + lrow * 128 + (((hp >> 24) & 7u) << 4);
+                    char* dst = smem + hb * HB + j * 8192 + (pw * 2 + u) * 1024 + lrow * 128 + (((hp >> 24) & 7u) << 4);
                     *reinterpret_cast<u32x4*>(dst) = o;
                 }
             };
@@ -774,7 +784,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                             __builtin_amdgcn_sched_barrier(0);
                             store_piece(hbuf ^ 1, tap - 2, (tap - 2) % 3);
                         }
-                        sq = sq == 2 ? 0 : sq + 1;
+                        sq = sq == RING - 1 ? 0 : sq + 1;
                     }
                     hbuf ^= 1;
                 }
@@ -814,7 +824,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        GMK_LDS char* dst = (GMK_LDS char*)(smem + fb * kHB + (slot + hf) * 8192 + (32 * pw + 16 * u) * 64);
+                        GMK_LDS char* dst = (GMK_LDS char*)(smem + fb * HB + (slot + hf) * 8192 + (32 * pw + 16 * u) * 64);
                         if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk1, (GMK_LDS void*)dst, 16, dv[hf][u], koff_b, 0, 0);
                         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk0, (GMK_LDS void*)dst, 16, dv[hf][u], koff_b, 0, 0);
                     }
@@ -823,7 +833,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 #pragma unroll
             for (int c = 0; c < 2; ++c)
                 wdh[c] = (unsigned)(p.nsk0 + nblk + c * 64 + 16 * pw + drow) * (unsigned)p.sk_ktot * ES + dchunk;
-            // dense weight tile k into LDS at byte offset `base` (ring slot `stage`: kWOFF + stage * kWST; merged form: piece 6 of a half-buffer)
+            // dense weight tile k into LDS at byte offset `base` (ring slot `stage`: WOFF + stage * kWST; merged form: piece 6 of a half-buffer)
             auto issue_wd_at = [&](int base, int k, int c) {      // c < 0: all 128 rows (2 instructions), else the 64 rows of channel half c (1)
                 if (c < 0) {
 #pragma unroll
@@ -836,7 +846,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rswk, (GMK_LDS void*)dst, 16, c ? wdh[1] : wdh[0], (unsigned)k * 64u, 0, 0);
                 }
             };
-            auto issue_wd = [&](int stage, int k, int c) { issue_wd_at(kWOFF + stage * kWST, k, c); };
+            auto issue_wd = [&](int stage, int k, int c) { issue_wd_at(WOFF + stage * kWST, k, c); };
             if constexpr (kMerge) {
                 // ------------------------------------------------------------------------------ merged form: 9 K-steps per phase (see the kernel's header)
                 auto wait4 = [&](bool all) __attribute__((always_inline)) {
@@ -875,10 +885,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                             if (i < 7) issue_w(sq, i + 2, ph, ch);
                             else issue_w(sq, i - 7, ph ^ 1, ph == 1 ? nch : ch);
                             // dense weight tiles: piece 6 of the filling (e0, e2) / of the reading (e1, e3) half-buffer
-                            if (i == 0) issue_wd_at(fb * kHB + 6 * 8192, 4 * ph + 0, ch);
-                            if (i == 3) issue_wd_at(hb * kHB + 6 * 8192, 4 * ph + 1, ch);
-                            if (i == 4) issue_wd_at(fb * kHB + 6 * 8192, 4 * ph + 2, ch);
-                            if (i == 5) issue_wd_at(hb * kHB + 6 * 8192, 4 * ph + 3, ch);
+                            if (i == 0) issue_wd_at(fb * HB + 6 * 8192, 4 * ph + 0, ch);
+                            if (i == 3) issue_wd_at(hb * HB + 6 * 8192, 4 * ph + 1, ch);
+                            if (i == 4) issue_wd_at(fb * HB + 6 * 8192, 4 * ph + 2, ch);
+                            if (i == 5) issue_wd_at(hb * HB + 6 * 8192, 4 * ph + 3, ch);
                             // pixel pieces
                             if (i == 0) issue_dense(fb, 0, 4 * ph + 0);
                             if (i == 1) issue_dense(fb, 2, 4 * ph + 1);
@@ -887,7 +897,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                             if (i == 5) { next_piece(2); next_piece(3); }
                             if (i == 6) { next_piece(4); next_piece(5); }
                             if (i == 7) { next_piece(0); next_piece(1); }
-                            sq = sq == 2 ? 0 : sq + 1;
+                            sq = sq == RING - 1 ? 0 : sq + 1;
                         }
                     }
                     tile = ntile; ch = nch;
@@ -954,7 +964,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         if (i == 7) { next_piece(2); next_piece(3); }
                         if (i == 9) { next_piece(4); next_piece(5); }
                         if (i == 11) { next_piece(0); next_piece(1); }
-                        sq = sq == 2 ? 0 : sq + 1;
+                        sq = sq == RING - 1 ? 0 : sq + 1;
                     }
                 }
                 tile = ntile; ch = nch;
@@ -966,6 +976,67 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 #pragma unroll
                     for (int i = 0; i < 13; ++i) { o[i] = st_iss[i]; o[16 + i] = st_wait[i]; o[32 + i] = st_bar[i]; }
                     o[48] = (unsigned)njobs;
+                }
+            }
+            return;
+        }
+        if constexpr (kRing4) {
+            // ---------------------------------------------------------------------------------------------------- four-slot weight ring (see the header)
+            // In step q: the weight tile of step q + 3 (the first three of the next phase / job behind taps 6, 7, 8), then one of the next phase's SIX
+            // halo pieces behind taps 0..5.  At barrier q everything but step q - 1's own instructions has landed: its weight tile (4 instructions,
+            // 2 for a half job) and its halo piece (2) may still fly.
+            auto wait_prev = [&](int nw, bool piece) __attribute__((always_inline)) {
+                if (piece) { if (nw == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                else { if (nw == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+            };
+            int sq = 3, hbuf = 0;
+            int tile = job_tile(0), ch = job_half(0);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { resolve_piece(tile, j); issue_fill(0, 0, j); }
+            issue_w(0, 0, 0, ch);
+            issue_w(1, 1, 0, ch);
+            issue_w(2, 2, 0, ch);
+            if (ch < 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // start-up barrier: weight tile 0 and the first halo half are in LDS
+            unsigned st_iss[9] = {}, st_wait[9] = {}, st_bar[9] = {};
+            unsigned long long st_prev = 0, st_t0 = 0, st_t1 = 0;
+            for (int k = 0; k < njobs; ++k) {
+                const int ntile = job_tile(k + 1), nch = job_half(k + 1);
+                for (int ph = 0; ph < nph; ++ph) {
+                    const bool last_ph = ph + 1 == nph;
+                    const int ph_next = last_ph ? 0 : ph + 1;
+                    const int chn = last_ph ? nch : ch;         // the job the next phase belongs to
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        if constexpr (kStamp) { st_t0 = __builtin_readcyclecounter(); if (st_prev) st_iss[tap] += (unsigned)(st_t0 - st_prev); }
+                        // the previous step issued: taps 0..5 a tile of THIS job + a piece; tap 6, 7 (seen at taps 7, 8) a tile of the next phase's job;
+                        // tap 8 of the previous phase (seen at tap 0) the third tile of this phase: this job's
+                        if (tap == 0) wait_prev(ch < 0 ? 4 : 2, false);
+                        else if (tap <= 6) wait_prev(ch < 0 ? 4 : 2, true);
+                        else wait_prev(chn < 0 ? 4 : 2, false);
+                        if constexpr (kStamp) st_t1 = __builtin_readcyclecounter();
+                        __builtin_amdgcn_s_barrier();
+                        if constexpr (kStamp) { st_prev = __builtin_readcyclecounter(); st_wait[tap] += (unsigned)(st_t1 - st_t0); st_bar[tap] += (unsigned)(st_prev - st_t1); }
+                        if (tap < 6) issue_w(sq, tap + 3, ph, ch);
+                        else issue_w(sq, tap - 6, ph_next, chn);
+                        if (tap < 6) {
+                            if (last_ph) resolve_piece(ntile, tap);                  // the next fills belong to the next job's tile (or are zeros)
+                            issue_fill(hbuf ^ 1, ph_next, tap);
+                        }
+                        sq = sq == RING - 1 ? 0 : sq + 1;
+                    }
+                    hbuf ^= 1;
+                }
+                tile = ntile; ch = nch;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the speculative DMA before the LDS is released
+            if constexpr (kStamp) {
+                if (pw == ((p.variant >= 30 && p.variant <= 33) ? p.variant - 30 : 0) && lane == 0 && p.stamps) {
+                    unsigned* o = p.stamps + (size_t)blockIdx.x * 128;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) { o[i] = st_iss[i]; o[16 + i] = st_wait[i]; o[32 + i] = st_bar[i]; }
+                    o[48] = (unsigned)(njobs * nph);
                 }
             }
             return;
@@ -1039,7 +1110,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     }
                     if (tap == 8 && handing) {
                         __builtin_amdgcn_s_barrier();                              // A: the consumers have read this phase's halo for the last time
-                        GMK_LDS char* dst = (GMK_LDS char*)(smem + hbuf * kHB + pw * 2048 + lane * 16);
+                        GMK_LDS char* dst = (GMK_LDS char*)(smem + hbuf * HB + pw * 2048 + lane * 16);
 #pragma unroll
                         for (int t = 0; t < 7; ++t)
 #pragma unroll
@@ -1047,7 +1118,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();                              // B: the residual tile is in LDS
                     }
-                    sq = sq == 2 ? 0 : sq + 1;
+                    sq = sq == RING - 1 ? 0 : sq + 1;
                 }
                 hbuf ^= 1;
             }
@@ -1139,16 +1210,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         // folded skip convolution: 64-byte rows (32 channels); this lane's byte offset inside a half-piece / a dense weight tile
         const int hfs = __builtin_amdgcn_readfirstlane(wave) >> 1;                 // which 128-pixel half this wave's pixels are in
         const int d_off = (((wave & 1) * 64 + r16) << 6) + ((q ^ ((r16 >> 2) & 3)) << 4);
-        const int dw_off = kWOFF + (r16 << 6) + ((q ^ ((r16 >> 2) & 3)) << 4);
+        const int dw_off = WOFF + (r16 << 6) + ((q ^ ((r16 >> 2) & 3)) << 4);
         int dw_half = 0;                                                           // byte offset of the job's channel half in a dense weight tile
         auto load_wt_d_at = [&](int base, int pair, int set) {                    // channel blocks 2 pair, 2 pair + 1 of the dense weight tile at LDS byte `base`
-            int o = dw_off - kWOFF;
+            int o = dw_off - WOFF;
             asm volatile("" : "+v"(o));
             const char* Wb = smem + base + dw_half + pair * 2048 + o;
             wt[set][0] = *reinterpret_cast<const frag_t*>(Wb);
             wt[set][1] = *reinterpret_cast<const frag_t*>(Wb + 1024);
         };
-        auto load_wt_d = [&](int stg, int pair, int set) { load_wt_d_at(kWOFF + stg * kWST, pair, set); };
+        auto load_wt_d = [&](int stg, int pair, int set) { load_wt_d_at(WOFF + stg * kWST, pair, set); };
         // This block's 128 bias values (+ the folded skip convolution's own, simple_unet.py:177-179) live in TWO registers per consumer wave for
         // the whole launch: lane l holds channels nblk + l and nblk + 64 + l.  A tile's accumulator-layout copy (lane (r16, q): channels
         // 16 cb + 4 q .. + 3 of block cb) is gathered from them by 32 ds_bpermute_b32 - no memory instruction: the per-tile global loads this
@@ -1186,7 +1257,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 }
             };
             auto load_px = [&](int hb, int k2, int set, int i0, int i1) {
-                const char* Hb = smem + hb * kHB;
+                const char* Hb = smem + hb * HB;
 #pragma unroll
                 for (int i = i0; i < i1; ++i)
                     px[set][i] = *reinterpret_cast<const frag_t*>(Hb + rowb[i] + (((k2 * 4 + q) ^ sw[i]) << 4));
@@ -1212,7 +1283,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                     // every dense sub-phase, whose fragments take the first-half set once its four groups are done
                     const int f = (kMerge && (tap == 4 || tap == 6)) ? 1 : 0;
                     // LDS byte offset of the dense weight tile of sub-phase tap - 3 (merged form): piece 6 of the filling / reading half-buffer
-                    const int dwb = (((tap - 3) & 1) ? hbuf : (hbuf ^ 1)) * kHB + 6 * 8192;
+                    const int dwb = (((tap - 3) & 1) ? hbuf : (hbuf ^ 1)) * HB + 6 * 8192;
                     step_barrier(tap);
                     if (tap == 0) { addr(0); load_px(hbuf, 0, 0, 0, 4); }      // the phase's halo only became valid with this barrier
                     if (!kPrefetchW) load_wt(st, 0, 0, 0);
@@ -1228,14 +1299,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                         if (k2 == 0 && pair == NG - 2) load_px(hbuf, 1, f ^ 1, 0, 2);
                         if (k2 == 0 && pair == NG - 1) load_px(hbuf, 1, f ^ 1, 2, 4);
                         if (last) {
-                            st = st == 2 ? 0 : st + 1;
+                            st = st == RING - 1 ? 0 : st + 1;
                             if (tap < 8 && !dense_after) { addr(tap + 1); load_px(hbuf, 0, 0, 0, 4); }
                             if (tap == 8 && ph + 1 == nph) b_off = next_boff;
                             if (dense_after && kMerge) {
                                 // the dense sub-phase's pixel fragments (landed at this step's barrier) and first weight fragments
                                 int o = d_off;
                                 asm volatile("" : "+v"(o));          // per-step addresses stay out of loop-invariant hoisting (registers)
-                                const char* Eb = smem + (hbuf ^ 1) * kHB + ((tap == 3 || tap == 6 ? 0 : tap == 4 ? 2 : 4) + hfs) * 8192 + o;
+                                const char* Eb = smem + (hbuf ^ 1) * HB + ((tap == 3 || tap == 6 ? 0 : tap == 4 ? 2 : 4) + hfs) * 8192 + o;
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) px[f][i] = *reinterpret_cast<const frag_t*>(Eb + i * 1024);
                                 load_wt_d_at(dwb, 0, 0);
@@ -1283,7 +1354,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                                 step_barrier(9 + tap - 3);
                                 int o = d_off;
                                 asm volatile("" : "+v"(o));          // per-step addresses stay out of loop-invariant hoisting (registers)
-                                const char* Eb = smem + (hbuf ^ 1) * kHB + (skip_slot(tap - 3) + hfs) * 8192 + o;
+                                const char* Eb = smem + (hbuf ^ 1) * HB + (skip_slot(tap - 3) + hfs) * 8192 + o;
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) px[1][i] = *reinterpret_cast<const frag_t*>(Eb + i * 1024);
                             }
@@ -1293,7 +1364,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                                 const bool last = g == NG - 1;
                                 if (!last) { if (kMerge) load_wt_d_at(dwb, g + 1, (g + 1) & 1); else load_wt_d(st, g + 1, (g + 1) & 1); }
                                 else {
-                                    if (!kMerge) st = st == 2 ? 0 : st + 1;      // (merged form: the dense tile is not in the ring)
+                                    if (!kMerge) st = st == RING - 1 ? 0 : st + 1;      // (merged form: the dense tile is not in the ring)
                                     addr(tap + 1); load_px(hbuf, 0, kMerge ? f ^ 1 : 0, 0, 4);
                                     load_wt(st, 0, 0, 0);
                                 }
@@ -1352,7 +1423,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             if constexpr (kRes >= 0) has_res = kRes != 0;
             const bool hand = kHandJob && has_res && p.variant != 7;
             u32x4 r7[2];
-            const char* Rl = smem + (hbuf ^ 1) * kHB;
+            const char* Rl = smem + (hbuf ^ 1) * HB;
             if (hand) {
 #pragma unroll
                 for (int ip = 0; ip < 2; ++ip) {
@@ -1419,7 +1490,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
 
         {
             const int hc0 = job_half(0);
-            b_off = kWOFF + ((hc0 >= 0 ? hc0 * 64 : 0) + r16) * 128;
+            b_off = WOFF + ((hc0 >= 0 ? hc0 * 64 : 0) + r16) * 128;
         }
         resolve_centres(job_tile(0));
         load_bias(job_half(0));
@@ -1427,7 +1498,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         if (kPrefetchW) load_wt(0, 0, 0, 0);
         for (int k = 0; k < njobs; ++k) {
             const int tile = job_tile(k), hc = job_half(k), ntile = job_tile(k + 1), nhc = job_half(k + 1);
-            const int next_boff = kWOFF + ((nhc >= 0 ? nhc * 64 : 0) + r16) * 128;
+            const int next_boff = WOFF + ((nhc >= 0 ? nhc * 64 : 0) + r16) * 128;
             if (hc < 0) run_job(IntTag<8>{}, tile, hc, next_boff, nhc);
             else run_job(IntTag<4>{}, tile, hc, next_boff, nhc);
             resolve_centres(ntile);
@@ -1501,7 +1572,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
     auto run_job = [&](auto ni_tag, int tile, int next_boff) {
         constexpr int NI = decltype(ni_tag)::value;
         auto pre = [&](int hb, int tap) {             // addresses of `tap` + its group-0 pixel fragments -> set 0
-            const char* Hb = smem + hb * kHB;
+            const char* Hb = smem + hb * HB;
             const int tapoff = (tap / 3 - 1) * WE + (tap % 3 - 1), tapoff_n = (tap / 3 - 1) * W + (tap % 3 - 1);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -1515,7 +1586,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 px[0][i] = *reinterpret_cast<const frag_t*>(Hb + rowb[i] + ((h ^ sw[i]) << 4));
         };
         auto load_px = [&](int hb, int kg, int set) {
-            const char* Hb = smem + hb * kHB;
+            const char* Hb = smem + hb * HB;
 #pragma unroll
             for (int i = 0; i < NI; ++i)
                 px[set][i] = *reinterpret_cast<const frag_t*>(Hb + rowb[i] + (((kg * 2 + h) ^ sw[i]) << 4));
@@ -1691,7 +1762,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 mfma_group(0, IntTag<0>{});
                 interleave_reads();
                 __builtin_amdgcn_sched_barrier(0);
-                st = st == 2 ? 0 : st + 1;
+                st = st == RING - 1 ? 0 : st + 1;
                 if (tap < 8) pre(hbuf, tap + 1);      // next tap's addresses + group-0 pixels, under the last MFMA group
                 if (tap == 8 && ph + 1 == nph) b_off = next_boff;      // the next step belongs to the next job (other channel half?)
                 if (kPrefetchW) load_wt(st, 0, 0);    // ... and the next step's first weight fragments (tile landed at this step's barrier)
@@ -1707,7 +1778,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
         if (hand) {
             // units 0..6 of the tile's residual arrive in the halo buffer the last phase just finished with; unit 7 (channels 112..127: this
             // wave's j = 1, qq = 1 if it owns channel half 1) is loaded here, ahead of the two barriers that hide its latency
-            Rl = smem + (hbuf ^ 1) * kHB;
+            Rl = smem + (hbuf ^ 1) * HB;
             if (cwe == 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1726,7 +1797,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
     };
 
     set_geometry(job_half(0));
-    b_off = kWOFF + (cwe * 64 + r) * 128;
+    b_off = WOFF + (cwe * 64 + r) * 128;
     resolve_centres(job_tile(0));
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1738,7 +1809,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
     if (kPrefetchW) load_wt(0, 0, 0);
     for (int k = 0; k < njobs; ++k) {
         const int tile = job_tile(k), hc = job_half(k), ntile = job_tile(k + 1), nhc = job_half(k + 1);
-        const int next_boff = kWOFF + ((nhc >= 0 ? nhc : cw) * 64 + r) * 128;
+        const int next_boff = WOFF + ((nhc >= 0 ? nhc : cw) * 64 + r) * 128;
         if (hc < 0) run_job(IntTag<4>{}, tile, next_boff);
         else run_job(IntTag<2>{}, tile, next_boff);
         if (nhc != hc) set_geometry(nhc);                  // whole -> half happens at most once, before the last job
@@ -1840,10 +1911,14 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
             else conv3x3_halo_ws_kernel<T, true, 32, true><<<grid, 512, 0, stream>>>(p);
         } else if (kind == 2) conv3x3_halo_ws_kernel<T, false><<<grid, 512, 0, stream>>>(p);
         else if (kind == 3) {
+            // four-slot weight ring (6-piece halos) where a tile fits 384 slots and there is no residual: 32 x 32, 16 x 16, 14 x 14 (GMK_DEV_VARIANT=13: the A/B switch)
+            const bool ring4 = use16 && !residual && g.slots <= 384 && p.variant != 13;
             if (use16 && g_stamps && g_stamp_bytes >= (int64_t)grid.x * 512) {
                 p.stamps = g_stamps;
-                conv3x3_halo_ws_kernel<T, true, 16, false, false, true><<<grid, 512, 0, stream>>>(p);
-            } else if (use16 && residual) conv3x3_halo_ws_kernel<T, true, 16, false, false, false, false, 1><<<grid, 512, 0, stream>>>(p);
+                if (ring4) conv3x3_halo_ws_kernel<T, true, 16, false, false, true, false, 0, true><<<grid, 512, 0, stream>>>(p);
+                else conv3x3_halo_ws_kernel<T, true, 16, false, false, true><<<grid, 512, 0, stream>>>(p);
+            } else if (ring4) conv3x3_halo_ws_kernel<T, true, 16, false, false, false, false, 0, true><<<grid, 512, 0, stream>>>(p);
+            else if (use16 && residual) conv3x3_halo_ws_kernel<T, true, 16, false, false, false, false, 1><<<grid, 512, 0, stream>>>(p);
             else if (use16) conv3x3_halo_ws_kernel<T, true, 16, false, false, false, false, 0><<<grid, 512, 0, stream>>>(p);
             else conv3x3_halo_ws_kernel<T, true, 32><<<grid, 512, 0, stream>>>(p);
         } else conv3x3_halo_kernel<T><<<grid, 512, 0, stream>>>(p);
