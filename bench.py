@@ -79,6 +79,16 @@ KERNEL_DESC = {
     "sumpool2x2_kernel": "backward of the nearest x2 upsample", "chansum_kernel": "per-sample channel sums (bias / embedding gradients)"}
 
 
+def fp32_mode():
+    """(label, MFMA peak in TFLOP/s) of the fp32 mode's convolutions: exact v_mfma_f32_32x32x2_f32 chains by default; with GMK_FP32_SPLIT=1 /
+    gmk_set_fp32_exact(0) (round 6) each fp32 product is hi hi + hi lo + lo hi of bf16 halves on the bf16 matrix cores (three MFMAs per product: a
+    third of the dense bf16 peak)."""
+    from generative_models_amd._lib import lib
+    if lib.gmk_fp32_split():
+        return "fp32 storage, 3x bf16 MFMA (hi / lo split, fp32 accumulation)", round(MFMA_BF16_PEAK_TFLOPS / 3, 1)
+    return "fp32 storage, exact-fp32 MFMA", MFMA_F32_PEAK_TFLOPS
+
+
 def kernel_hash():
     """sha1 over the kernel sources: stamps the PMC traffic file so that a bench line never quotes counters of other kernels."""
     import glob
@@ -336,7 +346,7 @@ class Bench:
         if not prof:
             return None
         torch.cuda.synchronize()
-        peak = MFMA_BF16_PEAK_TFLOPS if (dtype or self.a.dtype) == "bf16" else MFMA_F32_PEAK_TFLOPS
+        peak = MFMA_BF16_PEAK_TFLOPS if (dtype or self.a.dtype) == "bf16" else fp32_mode()[1]
         by = {}
         inst = {}
         for name, s, e, f, nb, fm, ikey in prof:
@@ -525,14 +535,20 @@ class Bench:
         head = self.run_config(plan[0][0], plan[0][1], a.steps, a.warmup, True)
         others = {k: self.run_config(k, spec, max(a.steps, 50), max(a.warmup, 10), False) for k, spec in plan[1:]}
         if a.config == "auto" and self.world == 1 and a.others and a.dtype == "bf16":
-            # what the north_star's 1e-3 bar costs: the headline workload in the fp32 mode (fp32 storage, exact-fp32 MFMA chains, peak 157 TFLOP/s),
-            # a short loop - 3 warm-up + 10 timed steps, no sampler
-            try:                     # an optional record must never cost the headline line
-                others["cfg2_fp32"] = self.run_config("cfg2", CONFIGS["cfg2"], 10, 3, False, dtype="fp32", sampler=False)
-                others["cfg2_fp32"]["dtype"] = "fp32"
-            except Exception as exc:
-                torch.cuda.empty_cache()
-                others["cfg2_fp32"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            # what the north_star's 1e-3 bar costs: the headline workload in the fp32 mode - exact fp32 MFMA chains (peak 157 TFLOP/s: the parity
+            # mode), and the round-6 fast form (products as three bf16 MFMAs of hi / lo halves, peak 2,500 / 3 TFLOP/s); short loops - 3 warm-up +
+            # 10 timed steps, no sampler
+            from generative_models_amd._lib import lib
+            for key, exact in (("cfg2_fp32", 1), ("cfg2_fp32_split", 0)):
+                try:                     # an optional record must never cost the headline line
+                    lib.gmk_set_fp32_exact(exact)
+                    others[key] = self.run_config("cfg2", CONFIGS["cfg2"], 10, 3, False, dtype="fp32", sampler=False)
+                    others[key]["dtype"] = fp32_mode()[0]
+                except Exception as exc:
+                    torch.cuda.empty_cache()
+                    others[key] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                finally:
+                    lib.gmk_set_fp32_exact(1)
         cpu = None
         if self.rank == 0 and self.world == 1 and not a.no_cpu:
             cpu = cpu_baseline(a.cpu_seconds, plan[0][1][1], plan[0][1][0])
@@ -542,7 +558,7 @@ class Bench:
         if self.rank == 0:
             act = os.environ.get("GMK_ACT_DTYPE", "fp16")
             dtype_label = "fp32" if a.dtype == "fp32" else ("bf16" if act == "bf16" else "fp16_fwd+bf16_bwd")
-            precision = {"fp32": "fp32 storage, exact-fp32 MFMA", "bf16": "bf16 storage of activations, weight packs and gradients; fp32 accumulation, fp32 master weights",
+            precision = {"fp32": fp32_mode()[0], "bf16": "bf16 storage of activations, weight packs and gradients; fp32 accumulation, fp32 master weights",
                          "fp16_fwd+bf16_bwd": "16-bit storage throughout: forward activations and forward weight packs fp16 (v_mfma_*_f16; the "
                          "reference's forward runs under fp16 autocast), gradients and data-gradient packs bf16 (v_mfma_*_bf16, no loss scaling); "
                          "fp32 accumulation, fp32 master weights, fp32 Adam"}[dtype_label]

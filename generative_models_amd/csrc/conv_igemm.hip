@@ -104,8 +104,28 @@ struct ConvParams {
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
-template <typename T>
+// ---- fp32 storage on the bf16 matrix cores (round 6): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (both round-to-nearest: |x - hi - lo| <=
+// 2^-17 |x|), a product a . b as hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the dropped lo lo term is <= 2^-16
+// of the product).  Three bf16 MFMAs of 16 k each replace eight exact-fp32 MFMAs of 2 k: 96 instead of 512 matrix-core cycles per 16 k and
+// 32 x 32 tile: 1e-5-class results at a fifth of the exact chain's matrix time.  Opt-in (GMK_FP32_SPLIT=1 / gmk_set_fp32_exact(0)): the default fp32
+// mode keeps the exact chains (v_mfma_f32_32x32x2_f32), which the ill-conditioned closed-form reference vectors need for the 1e-3 bar.
+__device__ __forceinline__ void split_bf16(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bf16_t h0 = (bf16_t)a[e], h1 = (bf16_t)b[e];
+        hi[e] = h0; hi[4 + e] = h1;
+        lo[e] = (bf16_t)(a[e] - (float)h0); lo[4 + e] = (bf16_t)(b[e] - (float)h1);
+    }
+}
+__device__ __forceinline__ f32x16 mfma_split(const bf16x8 ahi, const bf16x8 alo, const bf16x8 bhi, const bf16x8 blo, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, c, 0, 0, 0);      // the small terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, c, 0, 0, 0);
+}
+
+template <typename T, bool kSplit = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
+    static_assert(!kSplit || sizeof(T) == 4, "the hi / lo split is the fp32 mode's");
     constexpr int ES = sizeof(T);
     fp16_saturating_stores<T>();
     constexpr int KCH = 128 / ES;          // elements per 128-byte K chunk
@@ -224,6 +244,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = mfma_32x32x16<T>(a[i], b[j], acc[i][j]);
+            } else if constexpr (kSplit) {
+                // two 16-k sub-steps per pass (kg = 0, 2 of the four); lane (r, h) takes the chunks 4 (kg / 2) + 2 h, + 1 of its row: 8 consecutive k
+                if (kg & 1) continue;
+                const int c0 = (((kg * 2) + 2 * h) ^ swz) << 4, c1 = (((kg * 2) + 2 * h + 1) ^ swz) << 4;
+                bf16x8 ahi[2], alo[2], bhi[2], blo[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    split_bf16(*reinterpret_cast<const f32x4*>(Ab + a_off + i * 4096 + c0), *reinterpret_cast<const f32x4*>(Ab + a_off + i * 4096 + c1), ahi[i], alo[i]);
+                    bhi[i] = *reinterpret_cast<const bf16x8*>(Bb + b_off + i * 4096 + c0);          // the weight pack is stored split (store_pack)
+                    blo[i] = *reinterpret_cast<const bf16x8*>(Bb + b_off + i * 4096 + c1);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = mfma_split(ahi[i], alo[i], bhi[j], blo[j], acc[i][j]);
             } else {
                 f32x4 a[2], b[2];
                 a[0] = *reinterpret_cast<const f32x4*>(Ab + a_off + coff);
@@ -310,8 +346,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 // out-of-range offset so the instruction is always issued), hence the first two K-steps after an epilogue wait with
 // vmcnt(6 + kEpiStores) and every other one with vmcnt(6).
 // ------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool kSplit = false>
 __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams p) {
+    static_assert(!kSplit || sizeof(T) == 4, "the hi / lo split is the fp32 mode's");
     constexpr int ES = sizeof(T);
     fp16_saturating_stores<T>();
     constexpr int KCH = 128 / ES;
@@ -422,6 +459,22 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvParams
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
                         acc[j][i] = mfma_32x32x16<T>(wt[j], px[i], acc[j][i]);
+            } else if constexpr (kSplit) {
+                // (see split_bf16) two 16-k sub-steps per K-step; lane (r, h) takes the chunks 4 (kg / 2) + 2 h, + 1 of its row: 8 consecutive k
+                if (kg & 1) continue;
+                const int c0 = (((kg * 2) + 2 * h) ^ swz) << 4, c1 = (((kg * 2) + 2 * h + 1) ^ swz) << 4;
+                bf16x8 phi[2], plo[2], whi[2], wlo[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    split_bf16(*reinterpret_cast<const f32x4*>(Sb + a_off + i * 4096 + c0), *reinterpret_cast<const f32x4*>(Sb + a_off + i * 4096 + c1), phi[i], plo[i]);
+                    whi[i] = *reinterpret_cast<const bf16x8*>(Sb + b_off + i * 4096 + c0);          // the weight pack is stored split (store_pack)
+                    wlo[i] = *reinterpret_cast<const bf16x8*>(Sb + b_off + i * 4096 + c1);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[j][i] = mfma_split(whi[j], wlo[j], phi[i], plo[i], acc[j][i]);
             } else {
                 f32x4 px[2], wt[2];
                 px[0] = *reinterpret_cast<const f32x4*>(Sb + a_off + coff);
@@ -626,9 +679,10 @@ struct WgradParams {
 // T: type of dy (and of the MFMA operands); TX: storage type of the activation operand.  TX = f16_t with T = bf16_t is the train
 // step's case (fp16 forward activations, bf16 gradients): the gathered activation vectors are re-rounded to bf16 in the staging
 // registers (the value set of bf16 x bf16 products the MFMA needs; 3 VALU per dword, next to 16-byte loads), nothing else changes.
-template <typename T, typename TX = T>
+template <typename T, typename TX = T, bool kSplit = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
     static_assert(sizeof(T) == sizeof(TX), "mixed operand widths");
+    static_assert(!kSplit || sizeof(T) == 4, "the hi / lo split is the fp32 mode's");
     constexpr int ES = sizeof(T);
     constexpr int KP = ES == 2 ? 64 : 32;  // pixels per K-step (a 16 KB tile of 128 channels)
     constexpr int ROWB = 128 * ES;         // bytes per pixel row of a tile (128 channels)
@@ -678,7 +732,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     for (int i = 0; i < 4; ++i) {
         const int row = srow + RSTEP * i;
         if constexpr (ES == 2) lds_w[i] = row * 256 + ((((sc >> 2) ^ (row & 3)) << 2 | (sc & 3)) << 4);
-        else lds_w[i] = row * 512 + sc * 16;
+        else if constexpr (kSplit) {
+            // split form: the tile is staged as TWO bf16 tiles (hi at +0, lo at +8 KiB) in the 16-bit path's layout - 256-byte pixel rows, window
+            // swizzle - so the K loop is that path's transposed reads with no arithmetic; this thread's 4 channels are half of a 16-byte chunk
+            const int c16 = sc >> 1;
+            lds_w[i] = row * 256 + ((((c16 >> 2) ^ (row & 3)) << 2 | (c16 & 3)) << 4) + (sc & 1) * 8;
+        } else lds_w[i] = row * 512 + sc * 16;
     }
     // two K-steps of operands in flight per thread (register sets ks & 1; one step ahead: 2 - 3 % slower on the 1x1 launches)
     u32x4 ryy[2][4], rxx[2][4];
@@ -703,6 +762,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         }
     };
     auto write_step = [&](int buf, u32x4 (&ry)[4], u32x4 (&rx)[4]) {
+        if constexpr (kSplit) {
+            // x = hi + lo, hi = bf16(x), lo = bf16(x - hi): converted ONCE per element here (every element is read by two waves in the K loop)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 vy = __builtin_bit_cast(f32x4, ry[i]), vx = __builtin_bit_cast(f32x4, rx[i]);
+                bf16x4 yh, yl, xh, xl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    yh[e] = (bf16_t)vy[e]; yl[e] = (bf16_t)(vy[e] - (float)yh[e]);
+                    xh[e] = (bf16_t)vx[e]; xl[e] = (bf16_t)(vx[e] - (float)xh[e]);
+                }
+                *reinterpret_cast<bf16x4*>(Ys + buf * 16384 + lds_w[i]) = yh;
+                *reinterpret_cast<bf16x4*>(Ys + buf * 16384 + 8192 + lds_w[i]) = yl;
+                *reinterpret_cast<bf16x4*>(Xs + buf * 16384 + lds_w[i]) = xh;
+                *reinterpret_cast<bf16x4*>(Xs + buf * 16384 + 8192 + lds_w[i]) = xl;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<u32x4*>(Ys + buf * 16384 + lds_w[i]) = ry[i];
@@ -769,6 +846,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else if constexpr (kSplit) {
+            // (see split_bf16) the tile is staged as bf16 hi / lo tiles in the 16-bit path's layout (write_step): two 16-pixel sub-steps of that
+            // path's transposed reads, three bf16 MFMAs per tile pair
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            auto tr_read = [&](const char* base, int off) -> bf16x8 {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)(base + off));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)(base + off + 4 * 256));
+                const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                return __builtin_bit_cast(bf16x8, t);
+            };
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 ahi[2], alo[2], bhi[2], blo[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int pxl = kk * 16 + 8 * hh + q;
+                    const int wa = (((wm * 2 + i) ^ q) << 6) + 32 * cblk + 8 * pp;
+                    const int wb = (((wn * 2 + i) ^ q) << 6) + 32 * cblk + 8 * pp;
+                    ahi[i] = tr_read(Yb, pxl * 256 + wa); alo[i] = tr_read(Yb + 8192, pxl * 256 + wa);
+                    bhi[i] = tr_read(Xb, pxl * 256 + wb); blo[i] = tr_read(Xb + 8192, pxl * 256 + wb);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = mfma_split(ahi[i], alo[i], bhi[j], blo[j], acc[i][j]);
             }
         } else {
 #pragma unroll 4
@@ -855,10 +959,26 @@ static void launch_wgrad_reduce(const float* slab, float* dw, int nsplit, int ta
     else wgrad_reduce_kernel<4><<<blocks, 256, 0, stream>>>(slab, dw, nsplit, taps, cout, ktot);
 }
 
+// One element of an fp32 pack.  Plain: the fp32 value at position `pos`.  Split (the fp32 mode's default since round 6, see split_bf16): every
+// group of 8 consecutive k (32 bytes) holds its eight bf16 hi parts in the first 16 bytes and its eight bf16 lo parts in the second - exactly
+// the two 16-byte chunks a lane of the split kernels reads for one MFMA operand, so the weight fragments need no arithmetic at all.
+template <typename T>
+__device__ __forceinline__ void store_pack(T* base, int64_t pos, float v, bool split) {
+    if constexpr (sizeof(T) == 4) {
+        if (split) {
+            const bf16_t hi = (bf16_t)v, lo = (bf16_t)(v - (float)hi);
+            bf16_t* g = reinterpret_cast<bf16_t*>(base + (pos & ~(int64_t)7));
+            g[pos & 7] = hi; g[8 + (pos & 7)] = lo;
+            return;
+        }
+    }
+    base[pos] = (T)v;
+}
+
 // w [Cout][Cin][k][k] fp32 -> w_fwd [tap][Cout][Cin], w_dgrad [taps-1-tap][Cin][Cout]
 template <typename T, typename TF = T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, TF* __restrict__ wf,
-                                                         T* __restrict__ wd, int cout, int cin, int taps) {
+                                                         T* __restrict__ wd, int cout, int cin, int taps, bool split = false) {
     const int64_t n = (int64_t)cout * cin * taps;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
@@ -866,8 +986,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     const int64_t t2 = idx / taps;
     const int ci = (int)(t2 % cin);
     const int co = (int)(t2 / cin);
-    if (wf) wf[((int64_t)tap * cout + co) * cin + ci] = (TF)w[idx];
-    if (wd) wd[((int64_t)(taps - 1 - tap) * cin + ci) * cout + co] = (T)w[idx];
+    if (wf) store_pack(wf, ((int64_t)tap * cout + co) * cin + ci, w[idx], split);
+    if (wd) store_pack(wd, ((int64_t)(taps - 1 - tap) * cin + ci) * cout + co, w[idx], split);
 }
 
 // every convolution of the net in one launch: entry e packs arena[w_off ..] into packs[f_off ..] / packs[d_off ..]
@@ -877,7 +997,7 @@ struct PackTable {
     unsigned long long fwd_f16;          // bit e: entry e's forward pack is fp16 (16-bit packs only; the data-gradient pack is always T)
 };
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const float* __restrict__ arena, T* __restrict__ packs, const PackTable t) {
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const float* __restrict__ arena, T* __restrict__ packs, const PackTable t, bool split = false) {
     const int e = blockIdx.y;
     const int cout = t.cout[e], cin = t.cin[e], taps = t.taps[e];
     const int n = cout * cin * taps;
@@ -889,10 +1009,9 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const float* __
         const int tap = idx % taps;
         const int t2 = idx / taps;
         const int ci = t2 % cin, co = t2 / cin;
-        const T v = (T)w[idx];
         if (f16) reinterpret_cast<f16_t*>(wf)[(tap * cout + co) * cin + ci] = (f16_t)w[idx];
-        else wf[(tap * cout + co) * cin + ci] = v;
-        wd[((taps - 1 - tap) * cin + ci) * cout + co] = v;
+        else store_pack(wf, (int64_t)(tap * cout + co) * cin + ci, w[idx], split);
+        store_pack(wd, (int64_t)((taps - 1 - tap) * cin + ci) * cout + co, w[idx], split);
     }
 }
 
@@ -942,7 +1061,7 @@ extern "C" int gmk_pack_conv_weight(const float* w, void* w_fwd, void* w_dgrad, 
                                                                            taps);
     else if (dtype == GMK_F32)
         pack_weight_kernel<float><<<blocks, 256, 0, gmk_stream(stream)>>>(w, (float*)w_fwd, (float*)w_dgrad, cout, cin,
-                                                                         taps);
+                                                                         taps, fp32_split() && cin % 8 == 0 && cout % 8 == 0);
     else
         GMK_REQUIRE(false, "gmk_pack_conv_weight: bad dtype %d", dtype);
     return gmk_check_launch("gmk_pack_conv_weight");
@@ -972,7 +1091,7 @@ extern "C" int gmk_pack_conv_weights_multi(const float* arena, void* packs, int 
     if (bx > 256) bx = 256;
     const dim3 grid(bx, count);
     if (dtype == GMK_BF16) pack_weights_multi_kernel<bf16_t><<<grid, 256, 0, gmk_stream(stream)>>>(arena, (bf16_t*)packs, t);
-    else if (dtype == GMK_F32) pack_weights_multi_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(arena, (float*)packs, t);
+    else if (dtype == GMK_F32) pack_weights_multi_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(arena, (float*)packs, t, fp32_split());
     else GMK_REQUIRE(false, "gmk_pack_conv_weights_multi: bad dtype %d", dtype);
     return gmk_check_launch("gmk_pack_conv_weights_multi");
 }
@@ -1047,6 +1166,7 @@ static int conv_igemm_impl(const void* src0, const void* src1, int c0, int c1, i
                 dim3 grid(ntiles < ncu ? ntiles : ncu, cout / kBN);
                 if (dtype == GMK_BF16) conv_igemm_dma_kernel<bf16_t><<<grid, 512, 0, gmk_stream(stream)>>>(q);
                 else if (dtype == GMK_F16) conv_igemm_dma_kernel<f16_t><<<grid, 512, 0, gmk_stream(stream)>>>(q);
+                else if (fp32_split()) conv_igemm_dma_kernel<float, true><<<grid, 512, 0, gmk_stream(stream)>>>(q);
                 else conv_igemm_dma_kernel<float><<<grid, 512, 0, gmk_stream(stream)>>>(q);
             }
             return gmk_check_launch("gmk_conv_igemm(stride-2 dgrad phases)");
@@ -1075,11 +1195,13 @@ static int conv_igemm_impl(const void* src0, const void* src1, int c0, int c1, i
         dim3 grid(ntiles < ncu ? ntiles : ncu, cout / kBN);
         if (dtype == GMK_BF16) conv_igemm_dma_kernel<bf16_t><<<grid, 512, 0, gmk_stream(stream)>>>(p);
         else if (dtype == GMK_F16) conv_igemm_dma_kernel<f16_t><<<grid, 512, 0, gmk_stream(stream)>>>(p);
+        else if (fp32_split()) conv_igemm_dma_kernel<float, true><<<grid, 512, 0, gmk_stream(stream)>>>(p);
         else conv_igemm_dma_kernel<float><<<grid, 512, 0, gmk_stream(stream)>>>(p);
     } else {
         dim3 grid((p.M + kBM - 1) / kBM, cout / kBN);
         if (dtype == GMK_BF16) conv_igemm_kernel<bf16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
         else if (dtype == GMK_F16) conv_igemm_kernel<f16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
+        else if (fp32_split()) conv_igemm_kernel<float, true><<<grid, 256, 0, gmk_stream(stream)>>>(p);
         else conv_igemm_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(p);
     }
     return gmk_check_launch("gmk_conv_igemm");
@@ -1172,6 +1294,7 @@ extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, 
     dim3 grid((ns + 7) / 8 * 8 * taps * (cout / 128) * (p.ktot / 128));
     if (dtype == GMK_BF16 && xf16) conv_wgrad_kernel<bf16_t, f16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
     else if (dtype == GMK_BF16) conv_wgrad_kernel<bf16_t><<<grid, 256, 0, gmk_stream(stream)>>>(p);
+    else if (fp32_split()) conv_wgrad_kernel<float, float, true><<<grid, 256, 0, gmk_stream(stream)>>>(p);
     else conv_wgrad_kernel<float><<<grid, 256, 0, gmk_stream(stream)>>>(p);
     int rc = gmk_check_launch("gmk_conv_wgrad");
     if (rc) return rc;

@@ -61,3 +61,16 @@ int gmk_cu_limit(void) {
 }
 extern "C" int gmk_get_cu_limit(void) { return gmk_cu_limit(); }
 
+// fp32 mode arithmetic of the convolutions and weight gradients: exact fp32 MFMA chains (default: the parity mode) or, with
+// GMK_FP32_SPLIT=1 / gmk_set_fp32_exact(0), operands split into bf16 hi + lo and three bf16 MFMAs per product (round 6; conv_igemm.hip split_bf16)
+static int g_fp32_exact = -1;
+extern "C" int gmk_set_fp32_exact(int exact) { g_fp32_exact = exact ? 1 : 0; return 0; }
+bool fp32_split(void) {
+    if (g_fp32_exact < 0) {
+        const char* v = getenv("GMK_FP32_SPLIT");
+        g_fp32_exact = (v && atoi(v) != 0) ? 0 : 1;
+    }
+    return g_fp32_exact == 0;
+}
+extern "C" int gmk_fp32_split(void) { return fp32_split() ? 1 : 0; }
+

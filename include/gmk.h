@@ -52,6 +52,13 @@ int gmk_dev_set_stamp_buffer(void* buf, int64_t bytes);
  * behind a chip-filling persistent grid */
 int gmk_set_cu_limit(int n);
 int gmk_get_cu_limit(void);
+/* fp32 mode (dtype GMK_F32: the reference's own precision, gms/main.py:161-168 runs the test loss in fp32).  Default: exact fp32 MFMA chains
+ * (v_mfma_f32_32x32x2_f32) - the parity mode, 1e-3 on every reference vector including the ill-conditioned closed-form set.  Round 6 adds a
+ * fast form, gmk_set_fp32_exact(0) / GMK_FP32_SPLIT=1: the convolutions and weight gradients split each fp32 operand into bf16 hi + lo and form
+ * a product as hi hi + hi lo + lo hi on the bf16 matrix cores with fp32 accumulation (~ 1e-5 per product, a fifth of the exact chains' matrix
+ * time; the fp32 weight packs are then stored split, so re-pack after switching).  gmk_fp32_split() says which is active. */
+int gmk_set_fp32_exact(int exact);
+int gmk_fp32_split(void);
 /* number of bytes of scratch gmk_conv_wgrad needs for the given problem (split-K slabs) */
 int64_t gmk_conv_wgrad_workspace_bytes(int64_t n_pixels, int taps, int cout, int ktot);
 

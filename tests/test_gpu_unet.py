@@ -87,6 +87,75 @@ def test_default_init_goldens(golden, dtype, name, C):
             assert rel_err(net.grad(k[6:]), T(g[k])) < tol, k
 
 
+@pytest.mark.parametrize("name,C", [("definit_c128_s28.npz", 128), ("definit_c128_s32.npz", 128), ("definit_c256_s16.npz", 256)])
+def test_fp32_split_mode_vs_default_init_goldens(golden, name, C):
+    """Round 6: the fp32 mode's FAST form (gmk_set_fp32_exact(0) / GMK_FP32_SPLIT=1: every convolution and weight-gradient product as bf16
+    hi hi + hi lo + lo hi on the bf16 matrix cores, fp32 accumulation, fp32 storage) against the reference-pinned vectors at default-init scale:
+    forward, per-sample loss, every gradient norm and the stored gradients at the SAME 1e-3 bar as the exact mode (measured ~ 1e-5: printed).
+    The exact chains stay the default of `--dtype fp32`: on the ill-conditioned closed-form set (heavy cancellation by design) the split form
+    measures up to ~ 1e-3 on single gradients and 2e-2 on the guided chain's first step - see test_fp32_split_mode_error_level_on_the_closed_form_set."""
+    from generative_models_amd._lib import lib
+    from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    from generative_models_amd.diffusion.simple_unet import SimpleUnet
+    from oracle import unet_ref as U
+    g = golden(name)
+    params = U.reference_init_params(C, 1, seed=int(g["init_seed"]), zero_out_layers=False)
+    tol = 1e-3
+    try:
+        lib.gmk_set_fp32_exact(0)
+        assert lib.gmk_fp32_split() == 1
+        net = SimpleUnet(C, 0.0, compute_dtype=torch.float32); net.load_state_dict(params, strict=True); net = net.cuda()
+        z, l, y = T(g["z"]).cuda(), T(g["logsnr"]).cuda(), T(g["guide"]).cuda()
+        with torch.no_grad():
+            e1, e2 = rel_err(net(z, l, guide=y), T(g["v"])), rel_err(net(z, l), T(g["v_noguide"]))
+        assert e1 < tol and e2 < tol, (e1, e2)
+        diff = GaussianDiffusion(mean_type="v", num_steps=250)
+        x0, u, eps = (T(g[k]).cuda() for k in ("x0", "u", "eps"))
+        B = x0.shape[0]
+        out = diff.train_forward_backward(net=partial(net, guide=y), x=x0, grad_scale=1.0 / B, u=u, eps=eps)
+        e3 = rel_err(out["loss"], T(g["loss_b"]))
+        assert e3 < tol, e3
+        names = [str(n) for n in g["grad_names"]]
+        norms = torch.stack([net.grad(n).norm() for n in names]).cpu()
+        ref = T(g["grad_norms"])
+        ok = (norms - ref).abs() <= tol * ref.abs() + 1e-3 * tol * ref.abs().max()
+        assert bool(ok.all()), [(names[i], float(norms[i]), float(ref[i])) for i in (~ok).nonzero().flatten()[:8]]
+        eg = max(rel_err(net.grad(k[6:]), T(g[k])) for k in g.files if k.startswith("grad__"))
+        assert eg < tol, eg
+        print(f"fp32 split mode [{name}]: forward {e1:.2e} / {e2:.2e}, loss {e3:.2e}, worst gradient norm {float(((norms - ref).abs() / ref.abs().clamp_min(1e-12)).max()):.2e}, "
+              f"stored gradients {eg:.2e} (bar 1e-3)")
+    finally:
+        lib.gmk_set_fp32_exact(1)
+
+
+def test_fp32_split_mode_error_level_on_the_closed_form_set(golden):
+    """The same fast form on the closed-form (bug-exposing, heavily cancelling) vectors at C = 128: forward within 1e-3, the training loss within 1e-3,
+    stored gradients within 1e-2 (measured and printed; the exact mode holds all of them to 1e-3, which is why it stays the default)."""
+    from generative_models_amd._lib import lib
+    from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    try:
+        lib.gmk_set_fp32_exact(0)
+        g = golden("unet_c128_s28.npz")
+        net, _ = make_net(torch.float32, C=128)
+        z, l, y = T(g["z"]).cuda(), T(g["logsnr"]).cuda(), T(g["guide"]).cuda()
+        with torch.no_grad():
+            ef = max(rel_err(net(z, l, guide=y), T(g["v"])), rel_err(net(z, l), T(g["v_noguide"])))
+        g = golden("train_c128_s28.npz")
+        net, _ = make_net(torch.float32, C=128)
+        diff = GaussianDiffusion(mean_type="v", num_steps=250)
+        x0, y, u, eps = (T(g[k]).cuda() for k in ("x0", "y", "u", "eps"))
+        out = diff.train_forward_backward(net=partial(net, guide=y), x=x0, grad_scale=1.0 / x0.shape[0], u=u, eps=eps)
+        el = rel_err(out["loss"], T(g["loss_b"]))
+        names = [str(n) for n in g["grad_names"]]
+        ref = T(g["grad_norms"])
+        live = {n: float(r) > 1e-4 * float(ref.max()) for n, r in zip(names, ref)}
+        eg = max(rel_err(net.grad(k[6:]), T(g[k])) for k in g.files if k.startswith("grad__") and live[k[6:]])
+        print(f"fp32 split mode on the closed-form set (C = 128, 28 x 28): forward {ef:.2e}, loss {el:.2e}, stored gradients {eg:.2e}")
+        assert ef < 1e-3 and el < 1e-3 and eg < 1e-2, (ef, el, eg)
+    finally:
+        lib.gmk_set_fp32_exact(1)
+
+
 def test_state_dict_roundtrip_and_arena():
     from oracle import unet_ref as U
     net, params = make_net(torch.float32)
