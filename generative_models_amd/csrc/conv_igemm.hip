@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     // the first of them pulls a line into that XCD's L2 and the others find it there, and because a workgroup that hits runs ahead until it
     // misses, they fall into step.  (As a (split, tap, block) grid they were `nsplit` ids apart: same XCD, but out of step by more than the
     // L2 holds - the K = 256 skip convolution fetched dY twice, the stride-2 im2col form most lines several times: FETCH_SIZE of
-    // tools/wgrad_im2col_ab.py's mix 1,997 -> 1,348 MB per launch, 3 - 8 % of the time at 64 x 64 / 28 x 28 and of the stride-2 launches.)
+    // round 4's im2col weight-gradient mix (docs/EXPERIMENTS.md 7b.14) 1,997 -> 1,348 MB per launch, 3 - 8 % of the time at 64 x 64 / 28 x 28 and of the stride-2 launches.)
     // (One workgroup for BOTH input blocks of the skip convolution, dY staged once - 96 KiB of LDS, one workgroup per CU - was built and
     // measured 3 - 5 % slower than two workgroups that meet in L2.)
     const int ncib = p.ktot / 128;
@@ -1135,7 +1135,7 @@ static int conv_igemm_impl(const void* src0, const void* src1, int c0, int c1, i
     // The transposed form in its sub-pixel shape (conv_subpixel.hip, round 5): output parities meet 1 / 2 / 2 / 4 of the 9 taps over the gradient's
     // own grid, the halo of a low-resolution tile stays in LDS for all four parities - the zero-stuffed form below multiplies 27 of 36 tap-images by zero.
     if (stuffed && force == 0 && gmk_is16(dtype) && ksize == 3 && c0 == 128 && c1 == 0 && cout == 128 && !emb && !gn_scale && !gn_stats && !out2 &&
-        ho == 2 * hs && wo == 2 * ws && gmk_conv_subpixel_ok(B, hs, ws, c0, cout, dtype))
+        ho == 2 * hs && wo == 2 * ws && n0 >= 0 && n0 + cout <= w_rows && gmk_conv_subpixel_takes(B, hs, ws, c0, cout, w_rows, 9, out_cstride, dtype))
         return gmk_conv_subpixel(src0, B, hs, ws, c0, w, w_rows, n0, cout, GMK_SUBPIXEL_TRANSPOSED, bias, residual, out, out_cstride, dtype, stream);
     if ((force == 0 || force == 3) && gmk_is16(dtype) && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2 || stuffed) && ksize == 3) {
         const int rc = gmk_conv3x3_halo_try(src0, src1, c0, c1, B, ho, wo, w, w_rows, n0, cout, bias, emb, emb_stride, residual,
@@ -1150,7 +1150,7 @@ static int conv_igemm_impl(const void* src0, const void* src1, int c0, int c1, i
     // the LDS-DMA kernel, each a 1- / 2- / 2- / 4-tap convolution over the gradient's own grid with a stride-2 scatter of its rows
     // (make_phase_gather): 9 / 4 tap-images of MFMA work where the masked im2col gather does 9.  At the train step's sizes the zero-stuffed
     // halo form stays in front (536 vs 565 us at 16x16 -> 32x32, B = 2048, with the residual: each phase launch walks every DRAM page
-    // of the output and of the residual for a quarter of their bytes; without a residual the phases win, 393 vs 462 us; tools/tconv_ab.py).
+    // of the output and of the residual for a quarter of their bytes; without a residual the phases win, 393 vs 462 us; docs/EXPERIMENTS.md 7b.9).
     if (stuffed && force != 1 && !out2 && !gn_scale && !gn_stats) {
         const int64_t nbo = (int64_t)B * ho * wo * out_cstride * es;
         if (nb0 < lim && nb1 < lim && nbw < lim && nbo < lim && (int64_t)B * hs * ws < 0x00FFFFFF && (int64_t)c0 * es <= 4096 &&

@@ -501,6 +501,16 @@ extern "C" int gmk_conv_subpixel_ok(int B, int H, int W, int cin, int cout, int 
     return subpixel_geometry(B, H, W, cin, cout, cout, 16, cout, &g);
 }
 
+// the same answer for the EXACT launch a caller is about to make (its own weight-row count and output stride enter the byte limits): what
+// gmk_conv_igemm's dispatch asks, so that a shape the launch would refuse falls through to the other kernels instead of failing the call
+int gmk_conv_subpixel_takes(int B, int H, int W, int cin, int cout, int w_rows, int ntaps, int out_cstride, int dtype) {
+    const int force = gmk_kernel_choice(0, "GMK_CONV_KERNEL");
+    if ((force != 0 && force != 3) || !subpixel_enabled() || !gmk_is16(dtype)) return 0;
+    if (w_rows < cout || out_cstride < cout) return 0;
+    HaloGeometry g;
+    return subpixel_geometry(B, H, W, cin, cout, w_rows, ntaps, out_cstride, &g);
+}
+
 extern "C" int gmk_pack_upsample_weight(const float* w, void* w_sub, void* w_sub_dgrad, int cout, int cin, int dtype, int dgrad_dtype, void* stream) {
     GMK_REQUIRE(w && (w_sub || w_sub_dgrad) && cout > 0 && cin > 0, "gmk_pack_upsample_weight: bad arguments");
     GMK_REQUIRE(gmk_is16(dtype) && gmk_is16(dgrad_dtype), "gmk_pack_upsample_weight: 16-bit packs only (dtypes %d, %d)", dtype, dgrad_dtype);

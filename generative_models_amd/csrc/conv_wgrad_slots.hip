@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
             // line by two workgroups both reach the memory side, register loads are merged by the L2 (tools/fetch_probe.hip: counter / bytes 1.0
             // against 0.5).  With dY by `buffer_load ... lds` the kernel fetched X + 2 dY = 1.5 x its algorithmic bytes; through the same
             // register pipeline as X (loaded five blocks ahead, written to the dY ring two blocks ahead, no conversion) the corrected FETCH_SIZE of
-            // the large launches drops by 37 % (2,092 -> 1,323 MB on tools/wgrad_y_ab.py's mix) and the kernel runs 0.5 - 2.8 % faster, the
+            // the large launches drops by 37 % (2,092 -> 1,323 MB on round 4's four-shape mix, docs/EXPERIMENTS.md 7b.14) and the kernel runs 0.5 - 2.8 % faster, the
             // same bits in LDS (the DMA form was A/B'd behind a runtime switch and then removed: one more compare in the step loop for nothing).
             const unsigned long long ybase = (unsigned long long)p.dy;
             const i32x4 ydesc = {(int)(unsigned)ybase, (int)((unsigned)(ybase >> 32) & 0xFFFFu), (int)p.nbdy, 0x00020000};
@@ -595,7 +595,7 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
     p.variant = gmk_kernel_choice(3, "GMK_DEV_VARIANT") & 0xFF;
     dim3 grid(ns, ktot / 64, cout / 128);
     // forced: 0 automatic = 3 the wave-specialised kernel (1.37 - 1.58 x the 8-compute-wave kernel at every shape of the train step:
-    // tools/wgrad_bench.py); 2 the 8-compute-wave kernel (A/B)
+    // docs/EXPERIMENTS.md 7b.11); 2 the 8-compute-wave kernel (A/B)
     const bool ws = forced != 2;
     if (ws) {
         int ns3 = gmk_cu_limit() / ((cout / 64) * (ktot / 64));

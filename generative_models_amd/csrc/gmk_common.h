@@ -27,7 +27,8 @@ int gmk_kernel_choice(int which, const char* env);   // 0 conv (GMK_CONV_KERNEL)
 int gmk_conv1x1_pair_stream_try(const void* src, int64_t npix, const void* w_rows256, void* out_a, void* out_b, int dtype, hipStream_t stream);   // conv1x1_stream.hip
 int gmk_conv1x1_wgrad_stream_try(const void* dy, int dy_cstride, const void* src0, const void* src1, int64_t npix, float* slab, int64_t slab_bytes,
                                  bool x_f16, hipStream_t stream);        // conv1x1_stream.hip: > 0 = slabs written
-bool fp32_split(void);                // fp32 mode: operands as bf16 hi + lo on the bf16 matrix cores (default) or exact fp32 MFMA chains (GMK_FP32_EXACT=1)
+int gmk_conv_subpixel_takes(int B, int H, int W, int cin, int cout, int w_rows, int ntaps, int out_cstride, int dtype);      // conv_subpixel.hip
+bool fp32_split(void);                // fp32 mode: exact fp32 MFMA chains (default) or operands as bf16 hi + lo on the bf16 matrix cores (GMK_FP32_SPLIT=1 / gmk_set_fp32_exact(0))
 int gmk_cu_limit(void);                   // workgroups a persistent kernel may occupy (gmk_set_cu_limit / GMK_CU_LIMIT, default 256)
 void gmk_note_kernel(int id);             // 1 conv_igemm_kernel, 2 conv_igemm_dma_kernel, 3 conv3x3_halo_kernel,
                                           // 4 conv3x3_halo_ws_kernel, 5 halo kernel on a zero-stuffed source, 6 stride-2 dgrad as four phase launches of the LDS-DMA kernel, 7 halo kernel with the folded 1x1 skip

@@ -853,7 +853,7 @@ int gn_slab_channels(int mode, int C, int G, int HW, int elem_bytes, bool backwa
     int CS = C;
     if (mode == 3) CS = 32;
     else if (mode == 4) CS = 64;
-    else if (mode != 1) CS = backward && (int64_t)HW * C * elem_bytes > 65536 ? 32 : C;   // measured: tools/gn_bench.py
+    else if (mode != 1) CS = backward && (int64_t)HW * C * elem_bytes > 65536 ? 32 : C;   // measured: docs/EXPERIMENTS.md 7b.5
     if (CS > C || C % CS || CS % cpg || (CS & 7) || kThreads % (CS >> 3)) CS = C;
     return CS;
 }

@@ -285,8 +285,15 @@ class SimpleUnet(nn.Module):
         """Weight gradient of `Upsample` on the side stream: the sub-pixel slot correlation where the kernel takes the shape."""
         B, H, W, c = x.shape
         dw = self._gv[name + ".weight"]
-        if self._up_packs is not None and ops.conv_wgrad_subpixel_ok(B, H, W, c, dy.dtype):
-            self._on_side(lambda: ops.conv_wgrad_subpixel(dy, x, dw), (dy, x))
+        if self._up_packs is not None:
+            # the kernel's plan (split count, workspace) depends on the CU limit in force where it is LAUNCHED - the side stream's under a partitioned
+            # backward pass - so the eligibility question is asked there too, and the other form is the fallback in the same scope
+            def run():
+                if ops.conv_wgrad_subpixel_ok(B, H, W, c, dy.dtype):
+                    ops.conv_wgrad_subpixel(dy, x, dw)
+                else:
+                    ops.conv_wgrad(dy, [x], 3, ops.UPSAMPLE2, dw)
+            self._on_side(run, (dy, x))
             return dw
         return self._wgrad(dy, [x], 3, ops.UPSAMPLE2, dw)
 

@@ -109,7 +109,7 @@ def dt_code(dtype):
 
 
 # The current HIP stream's raw handle.  torch.cuda.current_stream() builds a Stream object and walks torch's device-index helpers (an
-# os.environ lookup among them) on every call - a quarter of the host time of a small-batch step with ~ 350 launches (tools/host_profile.py);
+# os.environ lookup among them) on every call - a quarter of the host time of a small-batch step with ~ 350 launches (a host profile of round 3 (docs/EXPERIMENTS.md));
 # the raw getter is the same value through one C call.
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
@@ -192,7 +192,7 @@ def pack_conv_weights_multi(arena, packs, table, fwd_f16=None):
 # 27.19 ms/step), and with it a sample's result depends (in the last bits) on which tile neighbours it had.
 GN_STATS = False
 GN_FUSE = os.environ.get("GMK_GN_FUSE", "1") != "0"            # inference: GroupNorm-apply + SiLU inside the consuming convolution (simple_unet._res_fwd)
-# ... where it pays (tools/fuse_ab.py, B x HW = 1 M pixels): at 64 x 64 the statistics-only launch + fused convolution take 1,497 us against
+# ... where it pays (round 3's fused-GroupNorm A/B, docs/EXPERIMENTS.md 7b.7, B x HW = 1 M pixels): at 64 x 64 the statistics-only launch + fused convolution take 1,497 us against
 # 1,658 us for GroupNorm + convolution (-10 %); at 32 x 32 / 28 x 28 the producer waves' transform (224 VALU issue slots per K-step
 # against the ~190 the consumer's MFMA stream leaves free on the shared SIMD) costs what the normalised tensor's round trip saved
 # (758 vs 747 us, 351 vs 341 us), at 16 x 16 more.  GMK_GN_FUSE_MIN_HW overrides the threshold.

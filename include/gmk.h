@@ -41,7 +41,7 @@ int gmk_last_kernel(void);
 /* development aid: force kernel variants (0 = automatic; see GMK_CONV_KERNEL / GMK_WGRAD_KERNEL / GMK_GN_KERNEL); -1 = unset */
 int gmk_set_kernel_choice(int conv, int wgrad, int gn);
 /* development aid: a free integer (GMK_DEV_VARIANT) that experimental code paths may read for in-process A/B runs
- * (tools/step_ab.py); 0 / unset = the shipped behaviour */
+ * (tools/small_batch_probe.py, tools/step_stamps.py); 0 / unset = the shipped behaviour */
 int gmk_set_dev_variant(int v);
 /* development aid (tools/step_stamps.py): while a device buffer of at least 512 bytes per workgroup is set, the wave-specialised 3x3 halo
  * launches (gmk_conv_igemm's 16-bit stride-1 3x3 path, gmk_conv3x3_skipfold) run an instrumented instantiation whose wave 4 (producer) and

@@ -584,7 +584,7 @@ def test_fused_attention_forward(ops, N, fp8):
     """gmk_attention_fwd (BASELINE config 5: 256 tokens x 128 channels; 64 tokens at 32 x 32 inputs): o and the optional P against
     softmax(q k^T / sqrt(C)) v in fp32 on the same bf16 inputs, and against the three-kernel bf16 path it replaces.  The fp8 form
     (both contractions on the e4m3 matrix cores, fp32 accumulation; e4m3 carries 3 mantissa bits, 2^-4 per element) is held to 1e-1
-    max-norm / 8e-2 L2 against that path: measured 4.7e-2 ... 8.5e-2 / 3.9e-2 ... 7.3e-2 from soft to sharp softmax (tools/attn_probe.py);
+    max-norm / 8e-2 L2 against that path: measured 4.7e-2 ... 8.5e-2 / 3.9e-2 ... 7.3e-2 from soft to sharp softmax (round 4's attention probe);
     the bf16 form measures 2e-3 ... 3.6e-3."""
     B, C = 5, 128
     g = torch.Generator().manual_seed(N + fp8)
