@@ -23,6 +23,8 @@ def instantiation(name):
         body = m.group(1)
         typ = "bf16" if "_Accum" in body or "bfloat" in body or "__bf16" in body else "f16"
         vals = [1 if t.strip() == "true" else 0 if t.strip() == "false" else int(t) for t in body.split(",") if t.strip() in ("true", "false") or t.strip().lstrip("-").isdigit()]
+        if "_Accum" in body and base == "conv3x3_halo_ws_kernel":
+            vals = [1] + vals      # the garbled bf16 form ("bool _Accum, bool, E, 16, ...") has lost the first literal, kPrefetchW (true in every shipped launch)
     tags = [typ]
     if base == "conv3x3_halo_ws_kernel":          # <T, kPrefetchW, kShape, kFuse, kSkip, kStamp, kMerge, kRes> (the merged / unmerged folded forms and the
                                                   # residual / no-residual plain forms share a key: same work per launch)

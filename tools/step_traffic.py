@@ -1,11 +1,11 @@
 """Whole-step HBM traffic at one configuration: PMC bytes per launch (profiles/rNN_traffic.json) x launches per step of the serial kernel trace
-(profiles/rNN_<cfg>_train_serial_kernel_stats.csv).   python tools/step_traffic.py [cfg2] [r05] [steps in the trace = 63]
+(profiles/rNN_<cfg>_train_serial_kernel_stats.csv).   python tools/step_traffic.py [cfg2] [r06] [steps in the trace = 63]
 The 3x3 halo / sub-pixel kernels are matched per template instantiation (fp16 forward, bf16 data gradient, folded skip convolution ...)."""
 import csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from kernel_names import instantiation, short
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r06"
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 63
 traffic = json.load(open(f"profiles/{tag}_traffic.json"))[cfg]["kernels"]
 calls, usec = {}, {}
