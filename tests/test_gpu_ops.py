@@ -738,6 +738,67 @@ def test_skip_convolution_folded_into_conv2(ops, dtype, S, B):
     assert torch.equal(out, out2)                                   # bit-reproducible
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("S,B", [(32, 2), (16, 70), (32, 80), (16, 3), (32, 300)])
+def test_merged_skip_schedule_is_bit_identical_to_the_thirteen_step_one(ops, dtype, S, B):
+    """Round 6: where a tile's halo fits 6 of the 7 fill pieces (32 x 32, 16 x 16) the folded skip convolution runs its dense sub-phases INSIDE the
+    tap steps (kMerge: 9 barriers per phase, dense weights in the free seventh piece of the half-buffers, fragment sets swapping roles).  Same products in
+    the same order as the 13-step schedule (GMK_DEV_VARIANT=12 keeps it): the same bits - a dense piece overwritten too early, a stale weight tile or
+    a missed wait would show here.  Whole and half jobs, several jobs per workgroup, tails."""
+    from generative_models_amd._lib import lib
+    C = 128
+    g = torch.Generator().manual_seed(S * 1000 + B)
+    ad = torch.randn((B, S, S, C), generator=g).to(dtype).cuda()
+    xd = [torch.randn((B, S, S, C), generator=g).to(dtype).cuda() for _ in range(2)]
+    w = (torch.randn((C, C, 3, 3), generator=g) / math.sqrt(C * 9)).cuda()
+    wsk = (torch.randn((C, 2 * C, 1, 1), generator=g) / math.sqrt(2 * C)).cuda()
+    bias, bias_sk = (0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    wf = torch.empty(w.numel(), device="cuda", dtype=dtype); wsf = torch.empty(wsk.numel(), device="cuda", dtype=dtype)
+    ops.pack_conv_weight(w, wf, None); ops.pack_conv_weight(wsk, wsf, None)
+    outs = {}
+    try:
+        lib.gmk_set_kernel_choice(3, -1, -1)
+        for variant in (0, 12, 0):
+            lib.gmk_set_dev_variant(variant)
+            outs.setdefault(variant, []).append(ops.conv3x3_skipfold(ad, wf, bias, xd, wsf, bias_sk))
+            assert lib.gmk_last_kernel() == 7
+    finally:
+        lib.gmk_set_kernel_choice(-1, -1, -1)
+        lib.gmk_set_dev_variant(0)
+    assert torch.equal(outs[0][0], outs[12][0]) and torch.equal(outs[0][0], outs[0][1])
+    assert bool(torch.isfinite(outs[0][0].float()).all()) and float(outs[0][0].float().abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("S,B,two", [(32, 2, False), (16, 70, False), (32, 80, True), (14, 400, False), (16, 300, True), (32, 300, False)])
+def test_four_slot_weight_ring_is_bit_identical_to_the_three_slot_one(ops, dtype, S, B, two):
+    """Round 6: the plain 3x3 halo kernel without a residual runs with 6-piece halos and a FOURTH weight-ring slot where a tile fits 384 slots
+    (32 x 32, 16 x 16, 14 x 14; kRing4: the weight tile of step q + 3 is issued in step q).  Same products, same order as the three-slot ring
+    (GMK_DEV_VARIANT=13 keeps it): the same bits.  One and two sources (K = 1152 / 2304), whole and half jobs, tails, several jobs per workgroup."""
+    from generative_models_amd._lib import lib
+    C = 128
+    g = torch.Generator().manual_seed(S * 1000 + B + 7)
+    srcs = [torch.randn((B, S, S, C), generator=g).to(dtype).cuda() for _ in range(2 if two else 1)]
+    cin = C * len(srcs)
+    w = (torch.randn((C, cin, 3, 3), generator=g) / math.sqrt(cin * 9)).cuda()
+    bias = (0.1 * torch.randn(C, generator=g)).cuda()
+    wf = torch.empty(w.numel(), device="cuda", dtype=dtype); ops.pack_conv_weight(w, wf, None)
+    outs = {}
+    try:
+        lib.gmk_set_kernel_choice(3, -1, -1)
+        for variant in (0, 13, 0):
+            lib.gmk_set_dev_variant(variant)
+            outs.setdefault(variant, []).append(ops.conv_igemm(srcs, wf, C, 3, ops.NORMAL, (S, S), bias=bias))
+            assert lib.gmk_last_kernel() == 4
+    finally:
+        lib.gmk_set_kernel_choice(-1, -1, -1)
+        lib.gmk_set_dev_variant(0)
+    assert torch.equal(outs[0][0], outs[13][0]) and torch.equal(outs[0][0], outs[0][1])
+    x = torch.cat([t.float() for t in srcs], 3).permute(0, 3, 1, 2)
+    ref = F.conv2d(x[:2].cpu(), w.to(dtype).float().cpu(), bias.cpu(), padding=1)
+    assert rel_err(nchw(outs[0][0][:2]), ref) < TOL[torch.bfloat16]
+
+
 SUBPIXEL_SHAPES = [(7, 9), (8, 37), (16, 3), (16, 300), (32, 2), (14, 5), (14, 330), (32, 66),      # (low-resolution size, batch)
                    (9, 6), (10, 3), (11, 5), (15, 4), (22, 2), (30, 2)]      # odd / non-power-of-two widths: inputs of 36, 40, 44, 60, 88, 120 pixels
 

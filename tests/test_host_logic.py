@@ -246,6 +246,56 @@ def test_gradient_exchange_two_ranks_gloo(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+_FORCED_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from generative_models_amd import parallel
+from generative_models_amd.diffusion.simple_unet import SimpleUnet
+dist.init_process_group("gloo")
+assert dist.get_world_size() == 1
+net = SimpleUnet(128)                        # CPU arena; only the exchange is exercised here
+g = torch.arange(net.flat_grads.numel(), dtype=torch.float32) * 1e-6
+# unforced: one rank exchanges nothing
+os.environ["GMK_FORCE_EXCHANGE"] = "0"
+assert not parallel.exchanging()
+sync = parallel.GradSync(net)
+net.flat_grads.copy_(g)
+for k in range(4):
+    sync.hook(k)
+assert not sync.works and not sync.issued
+sync.finish()
+# forced: the four buckets are all-reduced (a one-rank sum is the identity), in readiness order, tiling the arena
+os.environ["GMK_FORCE_EXCHANGE"] = "1"
+assert parallel.exchanging()
+sync = parallel.GradSync(net)
+for k in range(4):
+    sync.hook(k)
+assert [k for k, _, _ in sync.issued] == [0, 1, 2, 3] and len(sync.works) == 4
+assert sum(e - s for _, s, e in sync.issued) == net.flat_grads.numel()
+sync.finish()
+assert [k for k, _, _, _ in sync.last_issued] == [0, 1, 2, 3] and not sync.works
+assert torch.equal(net.flat_grads, g)
+d = sync.describe()
+assert d["world"] == 1 and d["forced"] and d["backend"] == "gloo"
+dist.destroy_process_group()
+print("forced one-rank exchange ok")
+"""
+
+
+def test_forced_exchange_with_one_rank_gloo(tmp_path):
+    """`GMK_FORCE_EXCHANGE=1` (round 6): with ONE rank the bucketed exchange still runs - what lets RCCL execute on a one-GPU box
+    (tests/test_gpu_ddp.py); here the host logic over gloo: nothing is issued unforced, four buckets in readiness order when forced, values unchanged."""
+    script = tmp_path / "forced_worker.py"
+    script.write_text(_FORCED_WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", free_port(), str(script), ROOT]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GMK_FORCE_EXCHANGE")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, OMP_NUM_THREADS="2"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "forced one-rank exchange ok" in r.stdout
+
+
 def test_mnist_idx_loader_and_transform(tmp_path):
     """Row N4: IDX reader + the reference's transform chain (gms/common.py:104-111) + shuffle / drop_last batching."""
     import numpy as np
