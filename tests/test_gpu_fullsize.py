@@ -111,6 +111,40 @@ def test_forward_is_bit_reproducible_with_the_skip_convs_on_the_side_stream(net)
     assert all(torch.equal(emb_off, o) for o in emb_on) and torch.equal(emb_off, plain)
 
 
+def test_bias_gather_is_stable_under_stream_overlap(net):
+    """Round 6: the 3x3 halo kernels take a tile's bias as the first MFMA's C operand and gather it from two registers per wave with ds_bpermute_b32
+    (conv_halo.hip load_bias) - the one ds_bpermute user in csrc/ (rounds 1-2 saw a miscompare, never explained below the ISA, in a GroupNorm build
+    whose REDUCTIONS used it, with a second stream active).  With live biases and every overlap on (weight gradients and 1x1 skip convolutions on
+    the side stream), 12 identical train passes and 12 forwards at the full batch give the same bits every time (tools/bias_gather_stress.py
+    runs 40 + 40 per shape)."""
+    from generative_models_amd import ops
+    from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    d = GaussianDiffusion(mean_type="v", num_steps=1000)
+    x, y, u, eps = data(11)
+    saved = net.flat_params.clone()
+    keep = ops.FWD_SIDE
+    try:
+        with torch.no_grad():
+            for n, p in net.named_parameters():
+                if n.endswith(".bias"):
+                    p.uniform_(-0.2, 0.2)
+        net.mark_params_changed()
+        ops.FWD_SIDE = True
+        ref = None
+        for _ in range(12):
+            out = d.train_forward_backward(net=partial(net, guide=y), x=x, grad_scale=1.0 / B, u=u, eps=eps)
+            cur = (out["loss"].clone(), net.flat_grads.clone(), net.forward_hip(x, u * 20 - 10, y, None).clone())
+            if ref is None:
+                ref = cur
+            assert all(torch.equal(a, b) for a, b in zip(cur, ref))
+        assert bool(torch.isfinite(ref[1]).all()) and float(ref[1].abs().max()) > 0
+    finally:
+        ops.FWD_SIDE = keep
+        with torch.no_grad():
+            net.flat_params.copy_(saved)
+        net.mark_params_changed()
+
+
 def test_backward_is_bit_reproducible_with_the_weight_gradients_on_the_side_stream(net):
     """The backward analogue of the test above, for the overlap that is ON by default (ops.WGRAD_STREAM: every weight gradient beside the
     data-gradient chain, the same co-residency pattern): eight identical train passes at the full batch give the same gradient arena bit for
