@@ -12,13 +12,16 @@
 //   2 x 448 slots x 128 B   halo half-buffers: channels [64*kh, 64*kh+64) of one source; while buffer hb is
 //                           consumed (9 taps = 9 K-steps) the next 64-channel half streams into hb^1
 //   3 x 16 KiB              ring of weight tiles [128 channels][64 k], two K-steps ahead
-// Slot s of a tile = ext-row * (W+2) + x + 1, ext rows = the tile's rows with a pad row above/below every image
+// Slot s of a tile = ext-row * (W+1) + x + 1, ext rows = the tile's rows with a pad row above/below every image
 // segment; with E = ext-row + y0 (y0 = first row's position in its image) the layout is (H+2)-periodic:
-// image k = E / (H+2), y = E % (H+2) - 1.  Pad rows / columns and rows of non-existent images read a zero through the
-// buffer descriptor's range check.  Swizzle: physical chunk c of slot s holds logical chunk c ^ ((n>>1)&7), n = s - 2*ext-row - 1
-// (the slot index with the two pad columns per row taken out; applied to the DMA source address and to the fragment reads).
+// image k = E / (H+2), y = E % (H+2) - 1.  ONE pad column per row (round 6; two before): the slot in front of a row's first pixel is
+// also the slot behind the previous row's last pixel - both are zero - so a tile needs ext-rows * (W+1) + 1 slots and 28 x 28
+// (13 x 29 + 1 = 378) and 8 x 8 (361) fit the 384 slots of the 6-piece forms (kRing4, kMerge).  Pad rows / columns and rows of
+// non-existent images read a zero through the buffer descriptor's range check.  Swizzle: physical chunk c of slot s holds logical chunk
+// c ^ ((n>>1)&7), n = s - ext-row - 1 (the slot index with the pad column of every row taken out; applied to the DMA source address and to
+// the fragment reads; a pad slot is read under two keys, as the left pad of its row and the right pad of the row above: it holds zeros in every chunk).
 // For any tap the 16 pixels a ds_read_b128 lane group touches have CONSECUTIVE n even where they wrap to the next image
-// row (their slots jump by 3 there), so every group is conflict-free; keying the swizzle on s itself cost 29 % extra LDS
+// row (their slots jump by 2 there), so every group is conflict-free; keying the swizzle on s itself cost 29 % extra LDS
 // cycles at W = 28 (two 2-way conflicts in every group that contains a wrap).
 //
 // Schedule: K-step q = (phase, tap); each step every wave issues the 2 DMA instructions of weight tile q+2 and, for
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
         int er = f_er0, xe = f_xe0;
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
-            const int n = p.variant == 1 ? er * WE + xe : er * WE + xe - 2 * er - 1;
+            const int n = p.variant == 1 ? er * WE + xe : er * WE + xe - er - 1;
             f_swz |= (unsigned)((n >> 1) & 7) << (3 * j);
             er += f_der; xe += f_dxe;
             if (xe >= WE) { xe -= WE; ++er; }
@@ -173,8 +176,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
             const int y = t - k * H;
             const int er = k * (H + 2) + y + 1 - y0;
             int s = er * WE + px_x[i] + 1;
-            int n = p.variant == 1 ? s : s - 2 * er - 1;
-            if (s < WE + 1 || s >= kHaloSlots - WE - 1) { s = WE + 1; n = WE - 2; }   // dead rows (m_local >= TP): any in-range slot
+            int n = p.variant == 1 ? s : s - er - 1;
+            if (s < WE + 1 || s >= kHaloSlots - WE - 1) { s = WE + 1; n = W; }   // dead rows (m_local >= TP): any in-range slot
             cslot[i] = s;
             cn[i] = n;
         }
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 int xe = f_xe0[u] + j * f_dxe, er = f_er0[u] + j * f_der;
                 const int wraps = div_small(xe, p.inv_we);
                 xe -= wraps * WE; er += wraps;
-                const int n = er * WE + xe - 2 * er - 1;
+                const int n = er * WE + xe - er - 1;
                 const int E = er + y0;
                 const int k = div_small(E, p.inv_hp2);
                 const int y = E - k * (H + 2) - 1;
@@ -1175,8 +1178,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
                 const int y = t - k * H;
                 const int er = k * (H + 2) + y + 1 - y0;
                 int s = er * WE + px_x[i] + 1;
-                int n = s - 2 * er - 1;
-                if (s < WE + 1 || s >= kHaloSlots - WE - 1) { s = WE + 1; n = WE - 2; }   // dead rows (m_local >= TP): any in-range slot
+                int n = s - er - 1;
+                if (s < WE + 1 || s >= kHaloSlots - WE - 1) { s = WE + 1; n = W; }   // dead rows (m_local >= TP): any in-range slot
                 cslot[i] = s;
                 cn[i] = n;
             }
@@ -1544,8 +1547,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_ws_kernel(const HaloParam
             const int y = t - k * H;
             const int er = k * (H + 2) + y + 1 - y0;
             int s = er * WE + px_x[i] + 1;
-            int n = s - 2 * er - 1;
-            if (s < WE + 1 || s >= kHaloSlots - WE - 1) { s = WE + 1; n = WE - 2; }   // dead rows (m_local >= TP): any in-range slot
+            int n = s - er - 1;
+            if (s < WE + 1 || s >= kHaloSlots - WE - 1) { s = WE + 1; n = W; }   // dead rows (m_local >= TP): any in-range slot
             cslot[i] = s;
             cn[i] = n;
         }
@@ -1851,7 +1854,8 @@ int gmk_halo_geometry(int B, int H, int W, int c0, int c1, int w_rows, int cout,
     if (ntiles < min_tiles) return 0;                         // not enough tiles to fill the chip: im2col kernels
     if (fused_gn && (upsample || R > H)) return 0;
     if (g) {
-        g->R = R; g->TP = R * W; g->slots = ner * (W + 2); g->rows_total = rows_total; g->M = M; g->ntiles = ntiles;
+        // slots: the halo kernels' one-pad-column layout (the capacity check above keeps the two-column count, which conv_subpixel.hip's own layout needs)
+        g->R = R; g->TP = R * W; g->slots = ner * (W + 1) + 1; g->rows_total = rows_total; g->M = M; g->ntiles = ntiles;
         g->nb0 = nb0; g->nb1 = nb1; g->nbw = nbw; g->nbo = nbo;
     }
     return 1;
@@ -1871,7 +1875,7 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     HaloParams p;
     p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.ktot = c0 + c1;
     p.shift = upsample ? 1 : 0; p.pmask = upsample == 2 ? 1 : 0;      // upsample: 1 nearest x2, 2 zero-stuffed x2 (transposed conv)
-    p.B = B; p.H = H; p.W = W; p.WE = W + 2; p.R = R; p.TP = TP; p.ntiles = (int)ntiles; p.rows_total = (int)rows_total;
+    p.B = B; p.H = H; p.W = W; p.WE = W + 1; p.R = R; p.TP = TP; p.ntiles = (int)ntiles; p.rows_total = (int)rows_total;
     p.w = w; p.w_tap_stride_b = (unsigned)w_rows * (unsigned)(c0 + c1) * 2u; p.n0 = n0;
     p.bias = bias; p.emb = emb; p.emb_stride = emb_stride; p.residual = residual; p.out = out; p.out_cstride = out_cstride;
     p.M = (int)M;
@@ -1880,7 +1884,7 @@ int gmk_conv3x3_halo_try(const void* src0, const void* src1, int c0, int c1, int
     p.stats = nullptr; p.stats_groups = out_cstride / 4; p.stamps = nullptr;
     p.variant = gmk_kernel_choice(3, "GMK_DEV_VARIANT") & 0xFF;      // code variant (A/B switches, see below)
     if (stats && cout == out_cstride && stats_bytes >= ntiles * 8 * 2 * (int64_t)(out_cstride / 4) * 2 * 4 && H * W >= 32) p.stats = stats;
-    p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 2); p.inv_w = 1.0f / (float)W;
+    p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 1); p.inv_w = 1.0f / (float)W;
     const int ncu = gmk_cu_limit();
     dim3 grid((unsigned)(ntiles < ncu ? ntiles : ncu), cout / 128);
     p.nfull = (int)ntiles; p.nhalf = 0;
@@ -1955,14 +1959,14 @@ extern "C" int gmk_conv3x3_skipfold(const void* src, int c0, int B, int H, int W
     HaloParams p = {};
     p.src0 = src; p.src1 = nullptr; p.c0 = c0; p.c1 = 0; p.ktot = c0;
     p.shift = 0; p.pmask = 0;
-    p.B = B; p.H = H; p.W = W; p.WE = W + 2; p.R = g.R; p.TP = g.TP; p.ntiles = (int)g.ntiles; p.rows_total = (int)g.rows_total;
+    p.B = B; p.H = H; p.W = W; p.WE = W + 1; p.R = g.R; p.TP = g.TP; p.ntiles = (int)g.ntiles; p.rows_total = (int)g.rows_total;
     p.w = w; p.w_tap_stride_b = (unsigned)w_rows * (unsigned)c0 * 2u; p.n0 = n0;
     p.bias = bias; p.emb = nullptr; p.emb_stride = 0; p.residual = nullptr; p.out = out; p.out_cstride = out_cstride;
     p.M = (int)g.M;
     p.nb0 = (unsigned)g.nb0; p.nb1 = 0; p.nbw = (unsigned)g.nbw; p.nbo = (unsigned)g.nbo;
     p.stats = nullptr; p.stats_groups = out_cstride / 4;
     p.variant = gmk_kernel_choice(3, "GMK_DEV_VARIANT") & 0xFF;
-    p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 2); p.inv_w = 1.0f / (float)W;
+    p.inv_hp2 = 1.0f / (float)(H + 2); p.inv_h = 1.0f / (float)H; p.inv_we = 1.0f / (float)(W + 1); p.inv_w = 1.0f / (float)W;
     p.sk0 = sk0; p.sk1 = sk1; p.wsk = wsk; p.bias2 = bias_sk; p.cs = cs; p.sk_ktot = 2 * cs; p.nsk0 = nsk0;
     p.nbs = (unsigned)((int64_t)g.M * cs * 2); p.nbws = (unsigned)((int64_t)wsk_rows * 2 * cs * 2);
     const int ncu = gmk_cu_limit();

@@ -739,9 +739,9 @@ def test_skip_convolution_folded_into_conv2(ops, dtype, S, B):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("S,B", [(32, 2), (16, 70), (32, 80), (16, 3), (32, 300)])
+@pytest.mark.parametrize("S,B", [(32, 2), (16, 70), (32, 80), (16, 3), (32, 300), (28, 3), (28, 400), (8, 37), (8, 1100), (14, 330)])
 def test_merged_skip_schedule_is_bit_identical_to_the_thirteen_step_one(ops, dtype, S, B):
-    """Round 6: where a tile's halo fits 6 of the 7 fill pieces (32 x 32, 16 x 16) the folded skip convolution runs its dense sub-phases INSIDE the
+    """Round 6: where a tile's halo fits 6 of the 7 fill pieces (with one pad column per row: 32 x 32, 28 x 28, 16 x 16, 14 x 14, 8 x 8) the folded skip convolution runs its dense sub-phases INSIDE the
     tap steps (kMerge: 9 barriers per phase, dense weights in the free seventh piece of the half-buffers, fragment sets swapping roles).  Same products in
     the same order as the 13-step schedule (GMK_DEV_VARIANT=12 keeps it): the same bits - a dense piece overwritten too early, a stale weight tile or
     a missed wait would show here.  Whole and half jobs, several jobs per workgroup, tails."""
@@ -770,10 +770,11 @@ def test_merged_skip_schedule_is_bit_identical_to_the_thirteen_step_one(ops, dty
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("S,B,two", [(32, 2, False), (16, 70, False), (32, 80, True), (14, 400, False), (16, 300, True), (32, 300, False)])
+@pytest.mark.parametrize("S,B,two", [(32, 2, False), (16, 70, False), (32, 80, True), (14, 400, False), (16, 300, True), (32, 300, False), (28, 90, False),
+                                     (28, 400, True), (8, 37, False), (8, 1100, True)])
 def test_four_slot_weight_ring_is_bit_identical_to_the_three_slot_one(ops, dtype, S, B, two):
     """Round 6: the plain 3x3 halo kernel without a residual runs with 6-piece halos and a FOURTH weight-ring slot where a tile fits 384 slots
-    (32 x 32, 16 x 16, 14 x 14; kRing4: the weight tile of step q + 3 is issued in step q).  Same products, same order as the three-slot ring
+    (one pad column per row: 32 x 32, 28 x 28, 16 x 16, 14 x 14, 8 x 8; kRing4: the weight tile of step q + 3 is issued in step q).  Same products, same order as the three-slot ring
     (GMK_DEV_VARIANT=13 keeps it): the same bits.  One and two sources (K = 1152 / 2304), whole and half jobs, tails, several jobs per workgroup."""
     from generative_models_amd._lib import lib
     C = 128
