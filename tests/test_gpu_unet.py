@@ -653,13 +653,25 @@ def test_attention_core_vs_the_references_own_attention(golden, N, mode):
     assert max(errs.values()) < gtol, errs
 
 
-@pytest.mark.parametrize("compute_dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("compute_dtype", ["bf16", "fp32", "fp32-split"])
 def test_training_learns_class_conditional_templates(compute_dtype):
     """End to end through the plugin surface only (train_step / sample): 200 steps on ten smooth class templates + noise.
     The loss must fall several-fold and class-conditional samples (guided DDIM, 50 steps) must land on their own template:
-    a wrong gradient, optimiser, label path or sampler update cannot pass this, whatever the unit tests say."""
+    a wrong gradient, optimiser, label path or sampler update cannot pass this, whatever the unit tests say.
+    ("fp32-split": the fp32 mode's fast form of round 6 - products as three bf16 MFMAs of hi / lo halves, gmk_set_fp32_exact(0).)"""
     from generative_models_amd import common
+    from generative_models_amd._lib import lib
     from generative_models_amd.diffusion.diffusion_model import DiffusionModel
+    split = compute_dtype == "fp32-split"
+    compute_dtype = compute_dtype.split("-")[0]
+    try:
+        lib.gmk_set_fp32_exact(0 if split else 1)
+        _learns_class_conditional_templates(common, DiffusionModel, compute_dtype)
+    finally:
+        lib.gmk_set_fp32_exact(1)
+
+
+def _learns_class_conditional_templates(common, DiffusionModel, compute_dtype):
     G = common.AttrDict(DiffusionModel.DG)
     G.update(dict(lr=3e-4, timesteps=50, eval_heavy=0, seed=1, compute_dtype=compute_dtype))
     torch.manual_seed(0)        # the net's default init draws from torch's global generator (as the reference's does): without this the outcome
