@@ -1,6 +1,6 @@
 """Stress for the one ds_bpermute user in csrc/ (round 6: the 3x3 halo kernels gather a tile's bias from two registers, conv_halo.hip load_bias):
 identical train passes and forwards with every overlap ON (weight gradients and 1x1 skip convolutions on the side stream) must stay bit-identical.
-    python tools/bias_gather_stress.py"""
+    python tools/bias_gather_stress.py [passes per shape = 40]"""
 import sys, torch
 sys.path.insert(0, ".")
 from functools import partial
@@ -8,7 +8,8 @@ from generative_models_amd import ops
 from generative_models_amd.diffusion.simple_unet import SimpleUnet
 from generative_models_amd.diffusion.gaussian_diffusion import GaussianDiffusion
 torch.manual_seed(0)
-for (B, S, cin) in ((1024, 28, 1), (2048, 32, 3)):
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+for (B, S, cin) in ((1024, 28, 1), (2048, 32, 3), (512, 64, 3)):
     net = SimpleUnet(128, 0.0, in_channels=cin, compute_dtype=torch.bfloat16)
     with torch.no_grad():
         for n, p in net.named_parameters():
@@ -22,13 +23,13 @@ for (B, S, cin) in ((1024, 28, 1), (2048, 32, 3)):
     ops.FWD_SIDE = True
     ref_l = ref_g = ref_f = None
     bad = 0
-    for it in range(40):
+    for it in range(N):
         out = d.train_forward_backward(net=partial(net, guide=y), x=x, grad_scale=1.0 / B, u=u, eps=eps)
         l, gr = out["loss"].clone(), net.flat_grads.clone()
         f = net.forward_hip(x, u * 20 - 10, y, None).clone()
         if ref_l is None: ref_l, ref_g, ref_f = l, gr, f
         else: bad += int(not (torch.equal(l, ref_l) and torch.equal(gr, ref_g) and torch.equal(f, ref_f)))
-    print(f"{cin}x{S}x{S} B={B}: 40 train passes + 40 forwards with the side streams on: {bad} differing", flush=True)
+    print(f"{cin}x{S}x{S} B={B}: {N} train passes + {N} forwards with the side streams on: {bad} differing", flush=True)
     assert bad == 0
     del net
     torch.cuda.empty_cache()
