@@ -64,6 +64,7 @@ KERNEL_DESC = {
     "conv1x1_pair_stream_kernel": "data gradient of the 1x1 skip convolution, both 128-channel halves from one read: weights resident in LDS, 128-pixel tiles streamed",
     "conv_wgrad_slots_kernel": "3x3 weight gradient over padded slots, 8 compute waves (+ slab reduce)",
     "conv_wgrad_slots_ws_kernel": "3x3 weight gradient over padded slots, wave-specialised (+ slab reduce)",
+    "conv_wgrad_slots_ws_kernel[stride-2 planes]": "weight gradient of the stride-2 3x3 convolution: the slot kernel on the four parity planes of the input (+ slab reduce)",
     "conv_wgrad_kernel": "im2col split-K weight gradient (+ slab reduce)",
     "conv_subpixel_ws_kernel[upsample]": "`Upsample` (nearest x2 + 3x3) as four output parities of 2x2 taps on pre-summed weights, low-resolution halo resident for all four (16 of 36 tap-products; FLOPs quoted are the reference op's)",
     "conv_subpixel_ws_kernel[transposed]": "data gradient of the stride-2 convs: output parities meet 1 / 2 / 2 / 4 taps over the gradient's own grid (9 of 36 tap-products of the zero-stuffed form)",

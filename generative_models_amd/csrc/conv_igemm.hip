@@ -1260,9 +1260,11 @@ extern "C" int gmk_conv_wgrad(const void* dy, int dy_cstride, const void* src0, 
     const int taps = ksize * ksize;
     // kernel choice: 0 = automatic, 1 = im2col split-K, 2 = padded-slot correlation (3x3 s1 bf16)
     const int wforce = gmk_kernel_choice(1, "GMK_WGRAD_KERNEL");
-    if (wforce != 1 && dtype == GMK_BF16 && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2) && ksize == 3) {
+    // stride 2 (round 6): the four-plane form of the slot kernel where the source is exactly twice the output (GMK_WGRAD_KERNEL=1 keeps the im2col kernel)
+    const bool s2 = mode == GMK_CONV_STRIDE2 && hs == 2 * ho && ws == 2 * wo;
+    if (wforce != 1 && dtype == GMK_BF16 && (mode == GMK_CONV_NORMAL || mode == GMK_CONV_UPSAMPLE2 || s2) && ksize == 3) {
         const int ns2 = gmk_conv_wgrad_slots_try(dy, dy_cstride, src0, src1, c0, c1, B, ho, wo, cout, (float*)workspace,
-                                                 workspace_bytes, wforce, mode == GMK_CONV_UPSAMPLE2, xf16, gmk_stream(stream));
+                                                 workspace_bytes, wforce, mode == GMK_CONV_UPSAMPLE2, xf16, gmk_stream(stream), s2);
         if (ns2 > 0) {
             int rc2 = gmk_check_launch("gmk_conv_wgrad(slots)");
             if (rc2) return rc2;

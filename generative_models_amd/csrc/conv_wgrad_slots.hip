@@ -44,6 +44,7 @@ struct SlotParams {
     int c0, c1, ktot, cout;
     int B, H, W, WE, RE;         // WE = W + 1 slots per row, RE = H + 1 rows per image (borders shared, see the header)
     int xshift;                  // 1: X is the half-resolution tensor (nearest x2 upsample folded into the gather)
+    int HS, WS, ntile;           // kS2 (stride-2 convolution): X is the (HS, WS) = (2 H, 2 W) tensor; ntile = 64-channel tiles of X (blockIdx.y = plane * ntile + tile)
     float* slab;                 // [nsplit][9][cout][ktot]
     int nchunks, chunks_per_split;
     unsigned nbdy, nb0, nb1;
@@ -251,14 +252,24 @@ template <int LOOK> struct SlotWsLds {
 // ahead of the dY stream - so the producers decode each chunk's slots ONCE (for X) and the dY issue LOOK steps later reuses the pixel
 // indices from a (LOOK + 1)-deep register FIFO.  Halves the producers' address arithmetic, which sits on the kernel's critical path
 // (producers = DMA issue + ~90 VALU per step against the consumers' 36 MFMAs: adding 30 VALU cost 5 - 8 %, round 3).
-template <int LOOK, bool kXF16 = false, bool kShare = false>
-__global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotParams p) {
+// kS2 (round 6): the weight gradient of the STRIDE-2 convolution (Downsample, simple_unet.py:81,97,100) on the same machinery.  The slots are those of
+// the LOW-resolution gradient dY (H x W = the convolution's output); the input X (2H x 2W) is seen as its four parity planes
+//     P_ab[slot (ye, xe)] = X[2 (ye - 1) + a][2 (xe - 1) + b]          (zero in border slots),
+// and filter row ky reads plane row-parity a = (ky != 1) at slot-row offset (ky == 0 ? -1 : 0), likewise the columns: every tap is again a CONSTANT
+// slot offset into ONE plane - (1,1) in P_00; (1,0), (1,2) in P_01; (0,1), (2,1) in P_10; (0,0), (0,2), (2,0), (2,2) in P_11.  blockIdx.y carries
+// (plane, 64-channel tile): a workgroup streams dY and its plane of X once (the producers gather the plane's pixels, nothing else changes for them)
+// and its consumers form the plane's 1, 2 or 4 taps - 9 tap-products per output pixel in total, none of them with a zero (the im2col kernel it
+// replaces re-gathered X once per tap: 2.25 reads of every input pixel through the vector-memory -> LDS path).
+template <int LOOK, bool kXF16 = false, bool kShare = false, bool kS2 = false>
+__global__ __launch_bounds__(512, kS2 ? 1 : 2) void conv_wgrad_slots_ws_kernel(const SlotParams p) {
+    static_assert(!(kS2 && !kShare) && !(kS2 && LOOK != 1), "stride-2 planes: the slot is decoded once (kShare); offsets reach one row back");
     __shared__ __attribute__((aligned(16))) char smem[SlotWsLds<LOOK>::kBytes];
     constexpr unsigned kBadPix = 0x00FFFFFFu;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int H = p.H, W = p.W, WE = p.WE, RE = p.RE;
-    const int cis = blockIdx.y, cob = blockIdx.z;            // 64-ci tile, 64-co tile
+    const int plane = kS2 ? (int)blockIdx.y / p.ntile : 0;   // kS2: (row parity, column parity) of the X plane this workgroup reads
+    const int cis = kS2 ? (int)blockIdx.y - plane * p.ntile : (int)blockIdx.y, cob = blockIdx.z;            // 64-ci tile, 64-co tile
     const int c_begin = blockIdx.x * p.chunks_per_split;
     const int c_end = min(c_begin + p.chunks_per_split, p.nchunks);
     if (c_begin >= c_end) return;
@@ -294,6 +305,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
             const unsigned rowpix = mad24((unsigned)b, (unsigned)(H >> shift), (unsigned)((ye - 1) >> shift));
             return ok ? mad24(rowpix, (unsigned)(W >> shift), (unsigned)((xe - 1) >> shift)) : kBadPix;
         };
+        const unsigned plane_add = (unsigned)(p.WS * (plane >> 1) + (plane & 1));      // kS2: 2W a + b' (WS = 2W)
         int xc = c_begin - LOOK, yc = c_begin;
         int xrow, xxe, yrow, yxe;
         decode(64 * max(xc, 0) + 16 * pw + (lane >> 3), xrow, xxe);
@@ -305,16 +317,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
         for (int i = 0; i <= LOOK; ++i) { hist[i][0] = kBadPix; hist[i][1] = kBadPix; }
         auto x_pixels = [&](unsigned& pix0, unsigned& pix1) {      // decode the next X chunk's two slots of this lane (and remember them)
             pix0 = kBadPix; pix1 = kBadPix;
+            unsigned lo0 = kBadPix, lo1 = kBadPix;
             if (xc >= 0) {
                 int r1 = xrow, x1 = xxe;
                 advance(r1, x1, d8r, d8x);
                 pix0 = pixel(xrow, xxe, kShare ? 0 : p.xshift); pix1 = pixel(r1, x1, kShare ? 0 : p.xshift);
+                if constexpr (kS2) {       // the slot's own (low-resolution) pixel goes to the dY FIFO; X reads the plane's pixel behind it:
+                    lo0 = pix0; lo1 = pix1;      // (b 2H + 2 (ye-1) + a) 2W + 2 (xe-1) + b' = 4 pixel - 2 (xe-1) + (2W a + b')
+                    pix0 = lo0 == kBadPix ? kBadPix : 4u * lo0 - 2u * (unsigned)(xxe - 1) + plane_add;
+                    pix1 = lo1 == kBadPix ? kBadPix : 4u * lo1 - 2u * (unsigned)(x1 - 1) + plane_add;
+                }
                 advance(xrow, xxe, d64r, d64x);
             }
             if constexpr (kShare) {
 #pragma unroll
                 for (int i = 0; i < LOOK; ++i) { hist[i][0] = hist[i + 1][0]; hist[i][1] = hist[i + 1][1]; }
-                hist[LOOK][0] = pix0; hist[LOOK][1] = pix1;
+                hist[LOOK][0] = kS2 ? lo0 : pix0; hist[LOOK][1] = kS2 ? lo1 : pix1;
             }
         };
         auto issue_x = [&]() -> int {      // -> number of DMA instructions (2, or 4 with the mirror copy)
@@ -354,7 +372,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
         };
         if constexpr (kXF16) {
             typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-            constexpr int FA = 5;                            // blocks issued ahead (the X ring only holds WRITTEN chunks here, the dY ring has 8 slots)
+            // blocks issued ahead (the X ring only holds WRITTEN chunks here, the dY ring has 8 slots).  kS2: its consumers have 4 - 16 MFMAs per
+            // step, the step is the producers' - and with 4 blocks (64 KiB per CU) in flight it was the memory latency's (1,300 cycles per 16 KiB);
+            // one workgroup per CU leaves the producers 256 registers: 8 blocks in flight
+            constexpr int FA = kS2 ? 9 : 5;
             constexpr int NSET = FA - 1;                     // register sets: blocks s + 2 .. s + FA are live during step s
             // the X descriptor as four scalars for the inline-asm loads (same words as make_buffer_rsrc: base, size, raw 32-bit format): a
             // border slot's out-of-range offset reads zeros, as in the DMA form - no validity masks, 32-bit address arithmetic only
@@ -443,16 +464,24 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
                 __builtin_amdgcn_s_barrier();
                 load_x(xr[LSET], xrp[LSET]);
                 load_y(yr[LSET], yrp[LSET]);
-                static_assert(FA == 5, "the literal below is 4 x (FA - 2)");
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (FA - 2)) : "memory");
                 store_x(xr[SSET], xrp[SSET]);
                 store_y(yr[SSET], yrp[SSET]);
             };
-            for (int s = 0; s < nsteps;) {        // load set (s + FA) % NSET = (s + 1) % 4, store set (s + 2) % 4: statically indexed
+            for (int s = 0; s < nsteps;) {        // load set (s + FA) % NSET = (s + 1) % NSET, store set (s + 2) % NSET: statically indexed
                 step(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}); ++s;
                 if (s < nsteps) { step(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}); ++s; }
-                if (s < nsteps) { step(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}); ++s; }
-                if (s < nsteps) { step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); ++s; }
+                if (s < nsteps) { step(std::integral_constant<int, 3>{}, std::integral_constant<int, 4 % NSET>{}); ++s; }
+                if constexpr (NSET == 4) {
+                    if (s < nsteps) { step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); ++s; }
+                } else {
+                    static_assert(NSET == 4 || NSET == 8, "the unrolled set rotation below");
+                    if (s < nsteps) { step(std::integral_constant<int, 4 % NSET>{}, std::integral_constant<int, 5 % NSET>{}); ++s; }
+                    if (s < nsteps) { step(std::integral_constant<int, 5 % NSET>{}, std::integral_constant<int, 6 % NSET>{}); ++s; }
+                    if (s < nsteps) { step(std::integral_constant<int, 6 % NSET>{}, std::integral_constant<int, 7 % NSET>{}); ++s; }
+                    if (s < nsteps) { step(std::integral_constant<int, 7 % NSET>{}, std::integral_constant<int, 0>{}); ++s; }
+                    if (s < nsteps) { step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); ++s; }
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             return;
@@ -489,6 +518,74 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_slots_ws_kernel(const SlotP
     // transposed fragment reads, 16-lane group gg, lane-in-group 4q + pp: rows = slots 16 kk + 8 hh + 4 t + q of the chunk, the
     // 64-B half of a row is the wave's 32-channel block flipped by bit 1 of the slot index
     const int dy_lane = kWsDyBase + (8 * hh + q) * 128 + ((wco ^ ((q >> 1) & 1)) << 6) + cblk * 32 + pp * 8;
+    if constexpr (kS2) {
+        // the plane's taps: ky in (a ? {0, 2} : {1}), kx in (b ? {0, 2} : {1}); slot offset (ky == 0 ? -WE : 0) + (kx == 0 ? -1 : 0)
+        const int pa = plane >> 1, pb = plane & 1;
+        int x_off[4], tap_id[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ky = pa ? 2 * (t >> (pb ? 1 : 0) & 1) : 1, kx = pb ? 2 * (t & 1) : 1;
+            const int off = (ky == 0 ? -WE : 0) + (kx == 0 ? -1 : 0);
+            const int cls = (off + 64) & 3;
+            x_off[t] = kWsXBase + (8 * hh + q + 64 * LOOK + off) * 128 + ((wci ^ (((q + cls) >> 1) & 1)) << 6) + cblk * 32 + pp * 8;
+            tap_id[t] = ky * 3 + kx;
+        }
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        auto ld_a = [&](int c, int kk) -> bf16x8 {
+            const char* yb = smem + (c & 7) * 8192 + dy_lane + (16 * kk) * 128;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)yb);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)(yb + 4 * 128));
+            const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, v);
+        };
+        auto ld_b = [&](int c, int kk, int xo) -> bf16x8 {
+            const char* xb = smem + (((c - LOOK) & 7) << 13) + xo + (16 * kk) * 128;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)xb);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GMK_LDS s16x4*)(xb + 4 * 128));
+            const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, v);
+        };
+        // NT taps per 16-slot k-block; the workgroup is bound by its data stream (16 KiB per step for 4 NT MFMAs), so the fragment reads are
+        // simply issued one k-block ahead of their MFMAs (the next step's first block is valid already: see the header)
+        auto run = [&](auto nt_tag) {
+            constexpr int NT = decltype(nt_tag)::value;
+            f32x16 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+            bf16x8 a[2], b[2][NT];
+            __builtin_amdgcn_s_barrier();             // step 0's barrier
+            a[0] = ld_a(c_begin, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[0][t] = ld_b(c_begin, 0, x_off[t]);
+            for (int c = c_begin; c < c_end; ++c) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int cn = kk < 3 ? c : c + 1, kn = (kk + 1) & 3;
+                    a[(kk + 1) & 1] = ld_a(cn, kn);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) b[(kk + 1) & 1][t] = ld_b(cn, kn, x_off[t]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk & 1], b[kk & 1][t], acc[t], 0, 0, 0);
+                }
+                if (c + 1 < c_end) __builtin_amdgcn_s_barrier();
+            }
+            const int r = lane & 31, h = lane >> 5;
+            float* slab = p.slab + (((int64_t)blockIdx.x * 9) * p.cout + cob * 64 + wco * 32) * p.ktot + cis * 64 + wci * 32 + r;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    slab[((int64_t)tap_id[t] * p.cout + co) * p.ktot] = acc[t][e];
+                }
+        };
+        if (plane == 3) run(std::integral_constant<int, 4>{});
+        else if (plane == 0) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 2>{});
+        return;
+    }
     int x_tap[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -561,11 +658,13 @@ int gmk_wgrad_slots_nsplit(int cout, int ktot) {
 }
 
 // Returns the number of splits written (>= 1) if the slot kernel was launched, 0 if the problem is not eligible.
+// stride2: (H, W) is the convolution's OUTPUT (= dY) size, the source is (2H, 2W): the four-plane form of the wave-specialised kernel (kS2)
 int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B, int H,
                              int W, int cout, float* slab, int64_t slab_bytes, int forced, int upsample, bool x_f16,
-                             hipStream_t stream) {
+                             hipStream_t stream, int stride2) {
     if (c0 % 64 || c1 % 64 || cout % 128) return 0;
     if (x_f16 && forced == 2) return 0;                      // the 8-compute-wave A/B kernel has no fp16-activation form
+    if (stride2 && (upsample || c1 || forced == 2 || W + 2 > 64)) return 0;
     const int WE = W + 1, RE = H + 1;
     if (WE + 1 > 128 || W < 4 || H < 2) return 0;
     const bool wide = WE + 1 > 64;
@@ -573,7 +672,8 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
     const int64_t total = (int64_t)B * RE * WE;              // the last image's lower border lies beyond: b == B reads as zero
     if (M >= 0x00FFFFFF || total >= (1ll << 30)) return 0;
     if (upsample && ((H | W) & 1)) return 0;
-    const int64_t Msrc = upsample ? M / 4 : M;
+    const int64_t Msrc = upsample ? M / 4 : stride2 ? M * 4 : M;
+    if (Msrc >= 0x00FFFFFF) return 0;
     const int64_t nbdy = M * dy_cstride * 2, nb0 = Msrc * c0 * 2, nb1 = Msrc * c1 * 2;
     const int64_t lim = 0xFFFF0000ll;     // below (kBadPix * bytes-per-pixel) mod 2^32 for pixels of up to 4 KiB
     if (nbdy >= lim || nb0 >= lim || nb1 >= lim || c0 > 2048 || c1 > 2048 || dy_cstride > 2048) return 0;
@@ -590,6 +690,7 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
     SlotParams p;
     p.dy = dy; p.dy_cstride = dy_cstride; p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.ktot = ktot; p.cout = cout;
     p.xshift = upsample ? 1 : 0;
+    p.HS = 2 * H; p.WS = 2 * W; p.ntile = ktot / 64;
     p.B = B; p.H = H; p.W = W; p.WE = WE; p.RE = RE; p.slab = slab; p.nchunks = nchunks; p.chunks_per_split = cps;
     p.nbdy = (unsigned)nbdy; p.nb0 = (unsigned)nb0; p.nb1 = (unsigned)nb1;
     p.variant = gmk_kernel_choice(3, "GMK_DEV_VARIANT") & 0xFF;
@@ -598,7 +699,8 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
     // docs/EXPERIMENTS.md 7b.11); 2 the 8-compute-wave kernel (A/B)
     const bool ws = forced != 2;
     if (ws) {
-        int ns3 = gmk_cu_limit() / ((cout / 64) * (ktot / 64));
+        const int ytiles = (stride2 ? 4 : 1) * (ktot / 64);
+        int ns3 = gmk_cu_limit() / ((cout / 64) * ytiles);
         if (ns3 >= 8) {                   // workgroups that stream the same dY / X are ns3 block ids apart: a multiple of 8 keeps them on one XCD
             const int all8 = ns3 & ~7, two = ns3 & ~3;       // (a multiple of 4: on two XCDs) - taken when the CU limit of a data-parallel
             ns3 = all8 * 16 < ns3 * 15 ? two : all8;      // run (248) would otherwise leave 10 % of the CUs without a workgroup (1.18 -> 1.25 PFLOP/s at 64 x 64)
@@ -609,7 +711,13 @@ int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, c
         ns3 = (nchunks + cps3 - 1) / cps3;
         if ((int64_t)ns3 * 9 * cout * ktot * 4 > slab_bytes) return 0;
         p.chunks_per_split = cps3;
-        dim3 grid3(ns3, ktot / 64, cout / 64);
+        dim3 grid3(ns3, ytiles, cout / 64);
+        if (stride2) {
+            if (x_f16) conv_wgrad_slots_ws_kernel<1, true, true, true><<<grid3, 512, 0, stream>>>(p);
+            else conv_wgrad_slots_ws_kernel<1, false, true, true><<<grid3, 512, 0, stream>>>(p);
+            gmk_note_kernel(17);
+            return ns3;
+        }
         const bool share = !upsample;          // dY slot S and X slot S are the same pixel: decode once (kShare)
 #define GMK_SLOT_WS(LK)                                                                                        \
     do {                                                                                                       \

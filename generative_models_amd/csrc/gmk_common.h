@@ -58,7 +58,7 @@ int gmk_halo_geometry(int B, int H, int W, int c0, int c1, int w_rows, int cout,
 int gmk_wgrad_slots_nsplit(int cout, int ktot);
 int gmk_conv_wgrad_slots_try(const void* dy, int dy_cstride, const void* src0, const void* src1, int c0, int c1, int B, int H,
                              int W, int cout, float* slab, int64_t slab_bytes, int forced, int upsample, bool x_f16,
-                             hipStream_t stream);
+                             hipStream_t stream, int stride2 = 0);
 
 
 static inline hipStream_t gmk_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -35,6 +35,8 @@ KERNEL_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_dma_kernel", 3: "conv3x3_
                 # stride-2 data gradient where the halo kernel declines (fp32, small problems): four output-parity phase launches of the LDS-DMA kernel
                 6: "conv_igemm_dma_kernel[stride-2 dgrad phases]",
                 # sub-pixel (output-parity) forms: `Upsample` as four 2x2-tap parities on pre-summed weights, the stride-2 data gradient as 1 / 2 / 2 / 4 taps
+                # the slot weight-gradient kernel on the four parity planes of a stride-2 convolution's input (round 6): its own line (4 - 16 MFMAs per step, not 36)
+                17: "conv_wgrad_slots_ws_kernel[stride-2 planes]",
                 8: "conv_subpixel_ws_kernel[upsample]", 9: "conv_subpixel_ws_kernel[transposed]", 10: "conv_subpixel_ws_kernel[upsample dgrad]",
                 21: "gn_silu_fwd_reg_kernel", 22: "gn_silu_fwd_kernel", 23: "gn_silu_bwd_hybrid_kernel", 24: "gn_silu_bwd_kernel"}
 
@@ -50,6 +52,8 @@ def instantiation_key(name, dtype):
         return f"{name}<{t}>"
     if name == "conv3x3_halo_ws_kernel[+1x1 skip]":
         return f"conv3x3_halo_ws_kernel<{t},+skip>"
+    if name == "conv_wgrad_slots_ws_kernel[stride-2 planes]":
+        return "conv_wgrad_slots_ws_kernel<stride-2 planes>"
     if name.startswith("conv_subpixel_ws_kernel["):
         return f"conv_subpixel_ws_kernel<{t},{name[len('conv_subpixel_ws_kernel['):-1]}>"
     return None

@@ -36,7 +36,7 @@ int gmk_version(void);
 const char* gmk_last_error(void);
 /* profiling aid: which kernel the calling thread's last gmk_conv_igemm / gmk_conv_wgrad / gmk_gn_* call launched
  * (1 conv_igemm_kernel, 2 conv_igemm_dma_kernel, 3 conv3x3_halo_kernel, 4 conv3x3_halo_ws_kernel, 7 conv3x3_halo_ws_kernel with the folded 1x1 skip convolution, 8 / 9 / 10 conv_subpixel_ws_kernel (upsample / transposed / upsample data gradient), 5 a halo kernel on the zero-stuffed source of GMK_CONV_TRANSPOSED2 (GMK_CONV_KERNEL=3), 6 the four parity-phase launches of the LDS-DMA kernel for GMK_CONV_TRANSPOSED2, 11 conv_wgrad_kernel,
- * 12 conv_wgrad_slots_kernel, 13 conv_wgrad_slots_ws_kernel, 16 conv_wgrad_subpixel_ws_kernel, 14 conv1x1_pair_stream_kernel, 15 conv1x1_wgrad_stream_kernel, 21 gn_silu_fwd_reg_kernel, 22 gn_silu_fwd_kernel, 23 gn_silu_bwd_hybrid_kernel, 24 gn_silu_bwd_kernel) */
+ * 12 conv_wgrad_slots_kernel, 13 conv_wgrad_slots_ws_kernel, 17 its four-plane form for GMK_CONV_STRIDE2, 16 conv_wgrad_subpixel_ws_kernel, 14 conv1x1_pair_stream_kernel, 15 conv1x1_wgrad_stream_kernel, 21 gn_silu_fwd_reg_kernel, 22 gn_silu_fwd_kernel, 23 gn_silu_bwd_hybrid_kernel, 24 gn_silu_bwd_kernel) */
 int gmk_last_kernel(void);
 /* development aid: force kernel variants (0 = automatic; see GMK_CONV_KERNEL / GMK_WGRAD_KERNEL / GMK_GN_KERNEL); -1 = unset */
 int gmk_set_kernel_choice(int conv, int wgrad, int gn);

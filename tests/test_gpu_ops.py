@@ -368,6 +368,54 @@ def test_forced_kernel_variants_agree_with_torch(ops, two, S, B, mode):
         lib.gmk_set_dev_variant(0)
 
 
+@pytest.mark.parametrize("xdt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("S,B", [(28, 2), (14, 3), (32, 2), (16, 5), (8, 3), (64, 1), (32, 40), (32, 300), (16, 1100), (26, 7)])
+def test_stride2_wgrad_on_parity_planes(ops, xdt, S, B):
+    """Weight gradient of `Downsample`'s stride-2 convolution (reference simple_unet.py:81,97,100) on the slot kernel's four-plane form (round 6):
+    the input's parity planes against the low-resolution gradient's slots, every tap a constant slot offset into one plane.  Against autograd in
+    fp32 on the rounded operands, against the im2col kernel it replaces (the same bf16 x bf16 products, fp32 sums in another order),
+    bit-reproducible; small problems take it only when forced, the train step's sizes automatically; odd input sizes keep the im2col kernel."""
+    from generative_models_amd._lib import lib
+    C = 128
+    x = q(rnd(B, C, S, S, seed=340), xdt)
+    w = (rnd(C, C, 3, 3, seed=341) / math.sqrt(C * 9)).requires_grad_(True)
+    out = F.conv2d(q(x, torch.bfloat16), w, None, stride=2, padding=1)               # the kernels multiply bf16(x)
+    dy = q(rnd(*out.shape, seed=342), torch.bfloat16)
+    out.backward(dy)
+    xd, dyd = nhwc(x, xdt), nhwc(dy, torch.bfloat16)
+    dw = torch.empty((C, C, 3, 3), device="cuda")
+    big = B * (S // 2 + 1) ** 2 >= 65536                     # >= 8 chunks of 64 slots for each of the 128 splits the planner asks for
+    try:
+        if not big:
+            ops.conv_wgrad(dyd, [xd], 3, ops.STRIDE2, dw)
+            assert lib.gmk_last_kernel() == 11              # automatic: the im2col kernel
+            lib.gmk_set_kernel_choice(-1, 3, -1)
+        ops.conv_wgrad(dyd, [xd], 3, ops.STRIDE2, dw)
+        assert lib.gmk_last_kernel() == 17
+        e = rel_err(dw, w.grad)
+        assert e < TOL[torch.bfloat16], e
+        dw2 = torch.empty_like(dw)
+        ops.conv_wgrad(dyd, [xd], 3, ops.STRIDE2, dw2)
+        assert torch.equal(dw, dw2)
+        lib.gmk_set_kernel_choice(-1, 1, -1)
+        dw_old = torch.empty_like(dw)
+        ops.conv_wgrad(dyd, [xd], 3, ops.STRIDE2, dw_old)
+        assert lib.gmk_last_kernel() == 11
+        assert rel_err(dw, dw_old) < 1e-4, rel_err(dw, dw_old)
+        assert e <= rel_err(dw_old, w.grad) + 1e-4
+    finally:
+        lib.gmk_set_kernel_choice(-1, -1, -1)
+    if S == 26:                                              # 13 x 13 -> 7 x 7: not twice the output
+        xo = nhwc(q(rnd(B, C, 13, 13, seed=343), xdt), xdt)
+        dyo = nhwc(q(rnd(B, C, 7, 7, seed=344), torch.bfloat16), torch.bfloat16)
+        lib.gmk_set_kernel_choice(-1, 3, -1)
+        try:
+            ops.conv_wgrad(dyo, [xo], 3, ops.STRIDE2, dw2)
+            assert lib.gmk_last_kernel() == 11
+        finally:
+            lib.gmk_set_kernel_choice(-1, -1, -1)
+
+
 @pytest.mark.parametrize("S,B", [(28, 3), (14, 5), (32, 2), (64, 1), (8, 37)])
 def test_transposed_dgrad_on_halo_kernels(ops, S, B):
     """Data gradient of the stride-2 conv, the older form (GMK_CONV_KERNEL=3): on the halo kernels as a 3x3 conv of the zero-stuffed gradient

@@ -800,8 +800,9 @@ def _check_register_loads_in_flight(src, name_regex, n_instances, vm_per_step, m
 
 def test_wgrad_register_loads_stay_untouched_while_in_flight():
     """The advisor's medium finding of round 3 (csrc/conv_wgrad_slots.hip, kXF16 producers: activation AND dY chunks through registers since
-    round 4; four VMEM operations per step, `vmcnt(12)`): LOOK in {1, 2} x kShare in {0, 1}, all with kXF16 = true."""
-    _check_register_loads_in_flight("conv_wgrad_slots.hip", r"conv_wgrad_slots_ws_kernelILi\dELb1ELb[01]E", 4, 4, 16)
+    round 4; four VMEM operations per step, `vmcnt(12)`): LOOK in {1, 2} x kShare in {0, 1}, all with kXF16 = true - and the stride-2 four-plane
+    form of round 6 (kS2: eight blocks in flight, `vmcnt(28)`, eight unrolled steps)."""
+    _check_register_loads_in_flight("conv_wgrad_slots.hip", r"conv_wgrad_slots_ws_kernelILi\dELb1ELb[01]ELb[01]E", 5, 4, 16)
 
 
 def test_subpixel_wgrad_register_loads_stay_untouched_while_in_flight():

@@ -7,6 +7,10 @@ def instantiation(name):
     folded skip convolution, the sub-pixel phase forms): each gets its OWN record, keyed `conv3x3_halo_ws_kernel<f16>`, `<bf16>`, `<f16,+skip>` ...
     (rocprofv3 prints some instantiations demangled - bf16 as "bool _Accum, bool, E" - and some mangled)."""
     base = short(name)
+    if base == "conv_wgrad_slots_ws_kernel":      # <LOOK, kXF16, kShare, kS2>: the stride-2 four-plane form (round 6) forms 4 - 16 MFMAs per step
+        m = re.search(r"kernelI((?:L[bi]\d+E)+)E", name) if name.startswith("_Z") else re.search(r"kernel<(.*?)>\(", name)      # where the others form 36
+        lits = re.findall(r"L[bi](\d+)E", m.group(1)) if m and name.startswith("_Z") else [t.strip() for t in m.group(1).split(",")] if m else []
+        return f"{base}<stride-2 planes>" if len(lits) >= 4 and lits[3] in ("1", "true") else None
     if not base.startswith("conv3x3_halo") and not base.startswith("conv_subpixel"):
         return None
     if name.startswith("_Z"):

@@ -69,8 +69,9 @@ fi
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 cp $OUT/bench.json profiles/r06_bench.json                     # the compact line (what the driver parses)
 cp gpurun_out/bench_detail.json profiles/r06_bench_detail.json   # the full record of the same run
+python tools/wgrad_s2_ab.py 2>/dev/null > profiles/r06_wgrad_stride2_ab.txt || exit 1      # stride-2 weight gradient: four-plane slot form vs im2col, per launch
 python tests/parity_report.py > profiles/r06_parity_report.txt 2>/dev/null || exit 1
 python tests/trajectory_report.py 150 2>/dev/null | grep -v "^oracle step" > profiles/r06_trajectory_report.txt || exit 1
-cp profiles/r06_bench.json profiles/r06_bench_detail.json profiles/r06_parity_report.txt profiles/r06_trajectory_report.txt $KEEP/
+cp profiles/r06_bench.json profiles/r06_bench_detail.json profiles/r06_parity_report.txt profiles/r06_trajectory_report.txt profiles/r06_wgrad_stride2_ab.txt $KEEP/
 cp $OUT/*.log $OUT/bench.err $KEEP/ 2>/dev/null
 tail -c 300 $OUT/bench.json
