@@ -369,14 +369,14 @@ def test_forced_kernel_variants_agree_with_torch(ops, two, S, B, mode):
 
 
 @pytest.mark.parametrize("xdt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("S,B", [(28, 2), (14, 3), (32, 2), (16, 5), (8, 3), (64, 1), (32, 40), (32, 300), (16, 1100), (26, 7)])
-def test_stride2_wgrad_on_parity_planes(ops, xdt, S, B):
+@pytest.mark.parametrize("S,B,C", [(28, 2, 128), (14, 3, 128), (32, 2, 128), (16, 5, 128), (8, 3, 128), (64, 1, 128), (32, 40, 128), (32, 300, 128),
+                                   (16, 1100, 128), (26, 7, 128), (16, 9, 256), (32, 150, 256)])
+def test_stride2_wgrad_on_parity_planes(ops, xdt, S, B, C):
     """Weight gradient of `Downsample`'s stride-2 convolution (reference simple_unet.py:81,97,100) on the slot kernel's four-plane form (round 6):
     the input's parity planes against the low-resolution gradient's slots, every tap a constant slot offset into one plane.  Against autograd in
     fp32 on the rounded operands, against the im2col kernel it replaces (the same bf16 x bf16 products, fp32 sums in another order),
     bit-reproducible; small problems take it only when forced, the train step's sizes automatically; odd input sizes keep the im2col kernel."""
     from generative_models_amd._lib import lib
-    C = 128
     x = q(rnd(B, C, S, S, seed=340), xdt)
     w = (rnd(C, C, 3, 3, seed=341) / math.sqrt(C * 9)).requires_grad_(True)
     out = F.conv2d(q(x, torch.bfloat16), w, None, stride=2, padding=1)               # the kernels multiply bf16(x)
@@ -384,7 +384,7 @@ def test_stride2_wgrad_on_parity_planes(ops, xdt, S, B):
     out.backward(dy)
     xd, dyd = nhwc(x, xdt), nhwc(dy, torch.bfloat16)
     dw = torch.empty((C, C, 3, 3), device="cuda")
-    big = B * (S // 2 + 1) ** 2 >= 65536                     # >= 8 chunks of 64 slots for each of the 128 splits the planner asks for
+    big = B * (S // 2 + 1) ** 2 >= 65536 * 128 // C          # >= 8 chunks of 64 slots for each of the 256 / (C / 64) splits the planner asks for
     try:
         if not big:
             ops.conv_wgrad(dyd, [xd], 3, ops.STRIDE2, dw)
